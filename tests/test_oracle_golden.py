@@ -336,18 +336,21 @@ def test_interpolatef_simd_path_equals_scalar_path_without_delay(cplx):
     x = orc.fill_uniform(e * 600, 99, -10, 10, np.float64)
     simd, p1 = orc.interpolatef(x, cplx, 1, 0.35, 4.0, 0.0, 12)
     assert p1 == 1 and simd.size == e * 2400
-    # scalar path of the same factor, forced through a non-integer-looking factor is not possible;
-    # restate the scalar formula directly: y[i] = sum_{n=r-L}^{r+L} x[n mod N] h(n - i/f)
-    pts = 600
+    # Inner region (outputs (2L+1)*f .. new_points-(2L+1)*f): same window as the scalar path
+    # y[i] = sum_{n=r-L}^{r+L} x[n mod N] h(n - i/f) (interpolation.rs:92-131) up to taps that sit
+    # on zeros of the function.  Edges use interpolate_priv_simd_step's window r-L+1 .. r+L+1
+    # (interpolation.rs:293-315), which differs by one end tap: a reference quirk we keep.
+    pts, L, f = 600, 12, 4
+    edge = (2 * L + 1) * f
     xs = x.view(np.complex128) if cplx else x
-    ref = np.zeros(2400, dtype=xs.dtype)
-    for i in range(0, 2400, 7):
+    got = simd.view(np.complex128) if cplx else simd
+    for i in list(range(0, 2400, 7)):
         t = i / 4.0
         r = int(np.floor(t))
-        ref[i] = sum(xs[n % pts] * orc.conv_time(1, 0.35, n - t, np.float64)
-                     for n in range(r - 12, r + 13))
-    got = simd.view(np.complex128) if cplx else simd
-    np.testing.assert_allclose(got[::7], ref[::7], atol=1e-10)
+        lo = r - L if edge <= i < 2400 - edge else r - L + 1
+        ref = sum(xs[n % pts] * orc.conv_time(1, 0.35, n - t, np.float64)
+                  for n in range(lo, lo + 2 * L + 1))
+        assert abs(got[i] - ref) <= 1e-10, (i, got[i], ref)
 
 
 def test_interpolatef_new_len_is_even():
