@@ -1,0 +1,121 @@
+"""ctypes binding of libbasic_dsp_hip.so (include/basic_dsp_hip.h).
+
+The shared library is the product; this module only loads it and declares prototypes.  There is no
+CPU fallback: if the library (or a gfx950 device) is missing, every operation raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libbasic_dsp_hip.so")
+
+
+class BackendError(RuntimeError):
+    """The HIP backend reported a failure (result code <= -100) or could not be loaded."""
+
+
+class VectorInteropResult32(C.Structure):
+    _fields_ = [("result_code", C.c_int32), ("vector", C.c_void_p)]
+
+
+class VectorInteropResult64(C.Structure):
+    _fields_ = [("result_code", C.c_int32), ("vector", C.c_void_p)]
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise BackendError(
+            "libbasic_dsp_hip.so is not built (expected %s); run `python -c 'import "
+            "__graft_entry__ as g; g.build()'` or `make -C basic_dsp_amd/csrc`" % LIB_PATH)
+    return C.CDLL(LIB_PATH)
+
+
+lib = _load()
+
+# Every symbol include/basic_dsp_hip.h declares; tests/test_abi.py checks the header against it.
+_P, _SZ, _I, _U = C.c_void_p, C.c_size_t, C.c_int, C.c_uint
+_F, _D = C.c_float, C.c_double
+
+
+def _proto(name, restype, *argtypes):
+    fn = getattr(lib, name)
+    fn.restype = restype
+    fn.argtypes = list(argtypes)
+    return fn
+
+
+_proto("bdsp_hip_last_error", C.c_char_p)
+_proto("bdsp_hip_version", C.c_char_p)
+for _s, _t in (("f32", _F), ("f64", _D)):
+    _proto("bdsp_hip_has_gpu_support_" + _s, _I)
+    _proto("bdsp_hip_is_supported_fft_len_" + _s, _I, _I, _SZ)
+    _proto("bdsp_hip_fft_" + _s, _I, _I, _P, _SZ, _I)
+    _proto("bdsp_hip_convolve_vector_" + _s, _I, _I, _P, _SZ, _P, _SZ, _P, _SZ,
+           C.POINTER(_SZ), C.POINTER(_SZ))
+    _proto("bdsp_hip_overlap_discard_" + _s, _SZ, _P, _SZ, _P, _SZ, _P, _SZ, _P, _SZ, _SZ, _SZ)
+
+for _s, _t, _R in (("32", _F, VectorInteropResult32), ("64", _D, VectorInteropResult64)):
+    _proto("new" + _s, _P, C.c_int32, C.c_int32, _t, _SZ, _t)
+    _proto("new_with_performance_options" + _s, _P, C.c_int32, C.c_int32, _t, _SZ, _t, _SZ, _I)
+    _proto("delete_vector" + _s, None, _P)
+    _proto("clone" + _s, _P, _P)
+    _proto("bdsp_hip_vec_clone" + _s, _P, _P)
+    _proto("get_value" + _s, _t, _P, _SZ)
+    _proto("get_len" + _s, _SZ, _P)
+    _proto("get_points" + _s, _SZ, _P)
+    _proto("get_delta" + _s, _t, _P)
+    _proto("is_complex" + _s, C.c_int32, _P)
+    _proto("get_domain" + _s, C.c_int32, _P)
+    _proto("data" + _s, _P, _P)
+    _proto("overwrite_data" + _s, _R, _P, _P, _SZ)
+    _proto("set_len" + _s, None, _P, _SZ)
+    _proto("bdsp_hip_vec_device_ptr" + _s, _P, _P)
+    for _n in ("real_offset", "real_scale"):
+        _proto(_n + _s, _R, _P, _t)
+    for _n in ("complex_offset", "complex_scale", "multiply_complex_exponential"):
+        _proto(_n + _s, _R, _P, _t, _t)
+    for _n in ("add", "sub", "mul", "div", "convolve_signal"):
+        _proto(_n + _s, _R, _P, _P)
+    for _n in ("conj", "magnitude", "magnitude_squared", "to_real", "to_imag", "phase", "to_complex",
+               "reverse", "swap_halves", "fft_shift", "ifft_shift", "mirror", "plain_fft",
+               "plain_ifft", "fft", "ifft"):
+        _proto(_n + _s, _R, _P)
+    for _n in ("apply_window", "unapply_window", "windowed_fft", "windowed_ifft",
+               "zero_interleave"):
+        _proto(_n + _s, _R, _P, C.c_int32)
+    _proto("zero_pad" + _s, _R, _P, _SZ, C.c_int32)
+    _proto("interpolatef" + _s, _R, _P, C.c_int32, _t, _t, _t, _SZ)
+
+_proto("bdsp_hip_dev_fft", _I, _I, _P, _P, _SZ, _SZ, _U, _D, _I, _D, C.POINTER(_I), _P)
+_proto("bdsp_hip_dev_convolve", _I, _I, _P, _P, _SZ, _SZ, _P, _SZ, _P)
+_proto("bdsp_hip_conv_spectrum_points", _SZ)
+_proto("bdsp_hip_dev_conv_prepare", _I, _I, _P, _SZ, _P, _P)
+_proto("bdsp_hip_dev_convolve_prepared", _I, _I, _P, _P, _SZ, _SZ, _P, _SZ, _P)
+_proto("bdsp_hip_dev_real_scale", _I, _I, _P, _SZ, _D, _P)
+_proto("bdsp_hip_dev_real_offset", _I, _I, _P, _SZ, _I, _D, _P)
+_proto("bdsp_hip_interpolatef_new_len", _SZ, _I, _SZ, _D)
+_proto("bdsp_hip_dev_interpolatef", _I, _I, _P, _P, _SZ, _I, _I, _D, _D, _D, _SZ, _D, _P)
+_proto("bdsp_hip_synchronize", _I, _P)
+_proto("bdsp_hip_set_device", _I, _I)
+_proto("bdsp_hip_event_create", _P)
+_proto("bdsp_hip_event_record", _I, _P, _P)
+_proto("bdsp_hip_event_elapsed_ms", _I, _P, _P, C.POINTER(_F))
+_proto("bdsp_hip_event_destroy", None, _P)
+
+FFT_INVERSE, FFT_SHIFT_OUT, FFT_SHIFT_IN, FFT_MAGNITUDE = 1, 2, 4, 8
+
+
+def last_error():
+    return lib.bdsp_hip_last_error().decode()
+
+
+def check(code, what=""):
+    """Raise on backend failures (<= -100); reference-style codes (-1, 1..14) are returned."""
+    if code <= -100:
+        raise BackendError("%s failed with code %d: %s" % (what or "backend call", code, last_error()))
+    return code
+
+
+def require_gpu():
+    if not lib.bdsp_hip_has_gpu_support_f32():
+        raise BackendError("no usable gfx950 device: %s" % last_error())

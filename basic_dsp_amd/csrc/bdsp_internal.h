@@ -1,0 +1,126 @@
+// bdsp_internal.h -- shared declarations of libbasic_dsp_hip.so (not installed).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+#include <string>
+
+#include "../../include/basic_dsp_hip.h"
+#include "fft_core.h"
+
+namespace bdsp {
+
+// ---------------------------------------------------------------- errors
+void set_last_error(const std::string& msg);
+int hip_fail(hipError_t e, const char* what, const char* file, int line);
+
+#define BDSP_HIP_TRY(expr)                                                                         \
+    do {                                                                                           \
+        hipError_t _e = (expr);                                                                    \
+        if (_e != hipSuccess) return ::bdsp::hip_fail(_e, #expr, __FILE__, __LINE__);              \
+    } while (0)
+#define BDSP_TRY(expr)                                                                             \
+    do {                                                                                           \
+        int _c = (expr);                                                                           \
+        if (_c != BDSP_OK) return _c;                                                              \
+    } while (0)
+#define BDSP_LAUNCH_CHECK() BDSP_HIP_TRY(hipGetLastError())
+
+// ---------------------------------------------------------------- runtime
+// One context per (process, device).  B1/B2 work runs on the library's own non-blocking stream;
+// B3 callers pass theirs.  Workspace blocks are cached per stream so that a block freed on one
+// stream is never handed to work queued on another.
+int device_ready();                       // BDSP_OK or BDSP_ERR_NO_DEVICE
+hipStream_t lib_stream();                 // library stream of the current device
+inline hipStream_t pick_stream(void* s) { return s ? reinterpret_cast<hipStream_t>(s) : lib_stream(); }
+int ws_alloc(void** p, size_t bytes, hipStream_t stream);
+void ws_free(void* p, hipStream_t stream);
+int num_cus();
+
+struct WsBlock { // RAII workspace
+    void* p = nullptr;
+    hipStream_t s = nullptr;
+    int alloc(size_t bytes, hipStream_t stream) { s = stream; return ws_alloc(&p, bytes, stream); }
+    ~WsBlock() { if (p) ws_free(p, s); }
+    template <typename U> U* as() const { return reinterpret_cast<U*>(p); }
+};
+
+// Forward twiddle table exp(-2*pi*i*m/n), m in [0, n), generated on the host in double precision,
+// rounded once, cached per (device, n, precision).  n <= 8192.
+template <typename T> int twiddle_table(int n, const cpx<T>** table);
+
+// ---------------------------------------------------------------- fused FFT prologue / epilogue
+template <typename T>
+struct FftIo {
+    const void* in;
+    void* out;
+    size_t n;          // points per vector
+    size_t in_stride;  // elements (of the input element type) between consecutive batch vectors
+    size_t out_stride; // elements (of the output element type) between consecutive batch vectors
+    unsigned flags;    // BDSP_FFT_* (SHIFT_IN, SHIFT_OUT, MAGNITUDE) + internal bits below
+    T in_scale;        // applied to every input element (1 = none)
+    int window_id;     // -1 none; else reference window id (4 = Hann)
+    T window_alpha;
+};
+constexpr unsigned FFT_IN_REAL = 1u << 8;        // input is a real vector (zero imaginary parts)
+constexpr unsigned FFT_WINDOW_OUT_DIV = 1u << 9; // divide OUTPUT by the window (windowed_ifft)
+constexpr unsigned FFT_OUT_REAL = 1u << 10;      // write only the real parts
+
+// ---------------------------------------------------------------- kernel launchers (per .hip TU)
+// fft.hip
+template <typename T>
+int fft_pow2(const FftIo<T>& io, T* scratch_a, T* scratch_b, size_t batch, bool inverse,
+             hipStream_t s);
+template <typename T>
+int fft_any(const FftIo<T>& io, size_t batch, bool inverse, hipStream_t s);
+bool is_pow2(size_t n);
+
+// conv.hip
+template <typename T>
+int convolve_overlap_save(const T* in, T* out, size_t points, size_t batch, const T* taps_dev,
+                          size_t taps, long long in_off, long long out_off, size_t nblocks_limit,
+                          T* last_block_out, const T* h_freq_dev, hipStream_t s);
+template <typename T>
+int convolve_direct(const T* in, T* out, size_t points, size_t batch, const T* taps_dev,
+                    size_t taps, bool is_complex, hipStream_t s);
+size_t conv_fft_len(size_t taps);
+template <typename T>
+int conv_prepare_spectrum(const T* taps_dev, size_t taps, const T* h_freq_dev, T* hs, hipStream_t s);
+template <typename T>
+int conv_run_blocks(const T* in, T* out, size_t points, size_t batch, const T* hs, size_t taps,
+                    long long in_off, long long out_off, size_t nblocks_limit, T* last_block_out,
+                    hipStream_t s);
+template <typename T> int mul_bcast(T* z, const T* h, size_t l, size_t nb, T scale, hipStream_t s);
+template <typename T>
+int scatter_valid(const T* z, T* x, size_t l, size_t skip, size_t step, size_t dst_off, size_t nb,
+                  size_t x_points, hipStream_t s);
+
+// elementwise.hip
+template <typename T> int ew_real_scale(T* x, size_t len, T f, hipStream_t s);
+template <typename T> int ew_real_offset(T* x, size_t len, bool is_complex, T f, hipStream_t s);
+template <typename T> int ew_complex_scale(T* x, size_t len, T re, T im, hipStream_t s);
+template <typename T> int ew_complex_offset(T* x, size_t len, T re, T im, hipStream_t s);
+template <typename T> int ew_binary(T* x, const T* y, size_t len, bool is_complex, int op, hipStream_t s);
+template <typename T> int ew_conj(T* x, size_t len, hipStream_t s);
+template <typename T> int ew_mul_cexp(T* x, size_t len, T a, T b, hipStream_t s);
+template <typename T> int ew_complex_to_real(const T* x, T* out, size_t len, int kind, hipStream_t s);
+template <typename T> int ew_window(T* x, size_t len, bool is_complex, int id, T alpha, bool unapply, hipStream_t s);
+template <typename T> int ew_fill(T* x, size_t len, T value, hipStream_t s);
+
+// reorg.hip
+template <typename T> int rg_rotate(const T* in, T* out, size_t points, size_t elem, size_t shift, hipStream_t s);
+template <typename T> int rg_reverse(const T* in, T* out, size_t points, size_t elem, hipStream_t s);
+template <typename T> int rg_zero_pad(const T* in, T* out, size_t len_before, bool is_complex, size_t points, int option, hipStream_t s);
+template <typename T> int rg_zero_interleave(const T* in, T* out, size_t len, size_t elem, size_t factor, hipStream_t s);
+template <typename T> int rg_mirror(const T* in, T* out, size_t len, hipStream_t s);
+
+// interp.hip
+template <typename T>
+int interpolatef_dev(const T* in, T* out, size_t len, bool is_complex, int fid, T rolloff, T factor,
+                     T delay, size_t conv_len, T delta, hipStream_t s);
+template <typename T> size_t interpolatef_new_len(size_t len, T factor);
+
+// window value shared by fft.hip and elementwise.hip (device) -- defined inline in window.h
+} // namespace bdsp

@@ -1,0 +1,873 @@
+// capi.cpp -- the C ABI of libbasic_dsp_hip.so (include/basic_dsp_hip.h):
+//   B1  GpuSupport<T> entry points on host slices   (vector/src/gpu_support/mod.rs:18-46)
+//   B2  the reference's C facade on HBM-resident vectors (interop/src/facade32.rs, lib.rs)
+//   B3  the same kernels on caller-owned device pointers
+// The host-side logic here mirrors the reference's operator layer for the hot path: type-state
+// checks, result codes, delta/valid_len bookkeeping and the buffer "trade" of DspVec
+// (vector/src/vector_types/mod.rs:125-229, support_std.rs:78-124).
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <vector>
+
+#include "bdsp_internal.h"
+
+using namespace bdsp;
+
+namespace {
+
+// ----------------------------------------------------------------------------------------------
+// FFT driver on two equally sized device buffers a (holds the input) and b (scratch).
+// Both must hold batch * 2 * points scalars.  *in_b tells where the result ended up.
+// ----------------------------------------------------------------------------------------------
+template <typename T>
+int fft_any_len(T* a, T* b, size_t points, size_t batch, bool inverse, unsigned flags, T in_scale,
+                int window_id, T window_alpha, bool* in_b, hipStream_t s);
+
+template <typename T>
+int fft_two_buffers(T* a, T* b, size_t points, size_t batch, bool inverse, unsigned flags,
+                    T in_scale, int window_id, T window_alpha, bool* in_b, hipStream_t s)
+{
+    *in_b = false;
+    if (points == 0 || batch == 0) return BDSP_OK;
+    if (!is_pow2(points))
+        return fft_any_len<T>(a, b, points, batch, inverse, flags, in_scale, window_id, window_alpha,
+                              in_b, s);
+    FftIo<T> io{};
+    io.n = points;
+    io.flags = flags;
+    io.in_scale = in_scale;
+    io.window_id = window_id;
+    io.window_alpha = window_alpha;
+    io.in_stride = points;  // elements of the input type (real or complex) per vector
+    io.out_stride = points; // elements of the output type per vector
+    const bool reshaping = (flags & (FFT_IN_REAL | BDSP_FFT_MAGNITUDE | FFT_OUT_REAL)) != 0;
+    if (points <= 4096) {
+        io.in = a;
+        if (reshaping && batch > 1) { io.out = b; *in_b = true; }
+        else if (flags & FFT_IN_REAL) { io.out = b; *in_b = true; }
+        else io.out = a;
+        return fft_pow2<T>(io, nullptr, nullptr, batch, inverse, s);
+    }
+    const bool three = points > (size_t(1) << 20);
+    io.in = a;
+    if (!three) { // a -> b -> a
+        io.out = a;
+        return fft_pow2<T>(io, b, nullptr, batch, inverse, s);
+    }
+    io.out = b; // a -> b -> a -> b
+    *in_b = true;
+    return fft_pow2<T>(io, b, a, batch, inverse, s);
+}
+
+// Bluestein chirp-z for lengths that are not powers of two (any N, like rustfft):
+//   X[k] = conj(c[k]) * sum_n (x[n] conj(c[n])) c[k-n],   c[n] = exp(+i*pi*n^2/N) (forward)
+// evaluated as a circular convolution of length m = next_pow2(2N-1) on the pow2 kernels.
+// The chirp is generated on the host in double (exact n^2 mod 2N) and cached per call; prologue
+// and epilogue options are honoured by separate elementwise passes (this is the slow path).
+template <typename T>
+int fft_any_len(T* a, T* b, size_t n, size_t batch, bool inverse, unsigned flags, T in_scale,
+                int window_id, T window_alpha, bool* in_b, hipStream_t s)
+{
+    *in_b = false;
+    if (flags & (FFT_IN_REAL | BDSP_FFT_MAGNITUDE | FFT_OUT_REAL | FFT_WINDOW_OUT_DIV)) {
+        set_last_error("non power-of-two FFT: fused real/magnitude options are not implemented");
+        return BDSP_ERR_UNSUPPORTED;
+    }
+    size_t m = 1;
+    while (m < 2 * n - 1) m <<= 1;
+    if (m > (size_t(1) << 30)) { set_last_error("Bluestein length above 2^30"); return BDSP_ERR_UNSUPPORTED; }
+    // host chirp
+    std::vector<T> chirp(2 * n), bk(2 * m, (T)0);
+    for (size_t i = 0; i < n; ++i) {
+        unsigned __int128 sq = (unsigned __int128)i * i;
+        size_t r = (size_t)(sq % (2 * n));
+        long double ang = (inverse ? -1.0L : 1.0L) * 3.14159265358979323846264338327950288L *
+                          (long double)r / (long double)n;
+        chirp[2 * i] = (T)cosl(ang);
+        chirp[2 * i + 1] = (T)sinl(ang);
+        bk[2 * i] = chirp[2 * i];
+        bk[2 * i + 1] = chirp[2 * i + 1];
+        if (i) { bk[2 * (m - i)] = chirp[2 * i]; bk[2 * (m - i) + 1] = chirp[2 * i + 1]; }
+    }
+    WsBlock wc, wb, wa, wt;
+    BDSP_TRY(wc.alloc(sizeof(T) * 2 * n, s));
+    BDSP_TRY(wb.alloc(sizeof(T) * 2 * m, s));
+    BDSP_TRY(wa.alloc(sizeof(T) * 2 * m * batch, s));
+    BDSP_TRY(wt.alloc(sizeof(T) * 2 * m * batch, s));
+    BDSP_HIP_TRY(hipMemcpyAsync(wc.p, chirp.data(), sizeof(T) * 2 * n, hipMemcpyHostToDevice, s));
+    BDSP_HIP_TRY(hipMemcpyAsync(wb.p, bk.data(), sizeof(T) * 2 * m, hipMemcpyHostToDevice, s));
+    BDSP_HIP_TRY(hipStreamSynchronize(s)); // host vectors go out of scope
+    T* dc = wc.as<T>();
+    T* db = wb.as<T>();
+    T* da = wa.as<T>();
+    T* dt = wt.as<T>();
+    // optional prologue on the input itself (window / shift / scale), in place or via b
+    T* src = a;
+    if (flags & BDSP_FFT_SHIFT_IN) {
+        for (size_t v = 0; v < batch; ++v)
+            BDSP_TRY(rg_rotate<T>(a + 2 * n * v, b + 2 * n * v, n, 2, n / 2, s));
+        src = b;
+    }
+    if (window_id >= 0)
+        for (size_t v = 0; v < batch; ++v)
+            BDSP_TRY(ew_window<T>(src + 2 * n * v, 2 * n, true, window_id, window_alpha, false, s));
+    if (in_scale != (T)1) BDSP_TRY(ew_real_scale<T>(src, 2 * n * batch, in_scale, s));
+    // a_pad[v] = x[v] * conj(c), zero padded to m
+    BDSP_HIP_TRY(hipMemsetAsync(da, 0, sizeof(T) * 2 * m * batch, s));
+    BDSP_HIP_TRY(hipMemcpy2DAsync(da, sizeof(T) * 2 * m, src, sizeof(T) * 2 * n, sizeof(T) * 2 * n,
+                                  batch, hipMemcpyDeviceToDevice, s));
+    {
+        // multiply by conj(chirp): conj the chirp once into dt[0..2n), then broadcast-multiply
+        BDSP_HIP_TRY(hipMemsetAsync(dt, 0, sizeof(T) * 2 * m, s));
+        BDSP_HIP_TRY(hipMemcpyAsync(dt, dc, sizeof(T) * 2 * n, hipMemcpyDeviceToDevice, s));
+        BDSP_TRY(ew_conj<T>(dt, 2 * n, s));
+        // positions >= n of dt are zero and da is zero there too, so a plain broadcast product works
+        BDSP_TRY(mul_bcast<T>(da, dt, m, batch, (T)1, s));
+    }
+    bool rb = false;
+    // B = FFT_m(b)
+    BDSP_TRY(fft_two_buffers<T>(db, dt, m, 1, false, 0, (T)1, -1, (T)0, &rb, s));
+    T* spec_b = rb ? dt : db;
+    T* other = rb ? db : dt;
+    (void)other;
+    // A = FFT_m(a_pad) (batch), needs its own scratch
+    WsBlock ws2;
+    BDSP_TRY(ws2.alloc(sizeof(T) * 2 * m * batch, s));
+    bool ra = false;
+    BDSP_TRY(fft_two_buffers<T>(da, ws2.as<T>(), m, batch, false, 0, (T)1, -1, (T)0, &ra, s));
+    T* spec_a = ra ? ws2.as<T>() : da;
+    T* scr_a = ra ? da : ws2.as<T>();
+    BDSP_TRY(mul_bcast<T>(spec_a, spec_b, m, batch, (T)1 / (T)m, s));
+    bool rc = false;
+    BDSP_TRY(fft_two_buffers<T>(spec_a, scr_a, m, batch, true, 0, (T)1, -1, (T)0, &rc, s));
+    T* conv = rc ? scr_a : spec_a;
+    // X[k] = conv[k] * conj(c[k]), k < n: reuse dt (conj chirp, zero beyond n) on the m-strided rows
+    BDSP_HIP_TRY(hipMemsetAsync(dt, 0, sizeof(T) * 2 * m, s));
+    BDSP_HIP_TRY(hipMemcpyAsync(dt, dc, sizeof(T) * 2 * n, hipMemcpyDeviceToDevice, s));
+    BDSP_TRY(ew_conj<T>(dt, 2 * n, s));
+    BDSP_TRY(mul_bcast<T>(conv, dt, m, batch, (T)1, s));
+    T* dst = a;
+    if (flags & BDSP_FFT_SHIFT_OUT) {
+        // gather rows into b, then rotate into a
+        BDSP_HIP_TRY(hipMemcpy2DAsync(b, sizeof(T) * 2 * n, conv, sizeof(T) * 2 * m, sizeof(T) * 2 * n,
+                                      batch, hipMemcpyDeviceToDevice, s));
+        for (size_t v = 0; v < batch; ++v)
+            BDSP_TRY(rg_rotate<T>(b + 2 * n * v, a + 2 * n * v, n, 2, n - n / 2, s));
+    } else {
+        BDSP_HIP_TRY(hipMemcpy2DAsync(dst, sizeof(T) * 2 * n, conv, sizeof(T) * 2 * m, sizeof(T) * 2 * n,
+                                      batch, hipMemcpyDeviceToDevice, s));
+    }
+    return BDSP_OK;
+}
+
+template <typename T> constexpr int elem_of() { return sizeof(T) == 8; }
+
+int check_device()
+{
+    int c = device_ready();
+    return c;
+}
+
+// ----------------------------------------------------------------------------------------------
+// B1 implementations
+// ----------------------------------------------------------------------------------------------
+template <typename T>
+int b1_fft(int is_complex, T* signal, size_t len, int inverse)
+{
+    if (!is_complex) { set_last_error("real fft isn't supported, call is_supported_fft_len first"); return BDSP_ERR_UNSUPPORTED; }
+    BDSP_TRY(check_device());
+    size_t points = len / 2;
+    if (points == 0) return BDSP_OK;
+    hipStream_t s = lib_stream();
+    WsBlock a, b;
+    BDSP_TRY(a.alloc(sizeof(T) * len, s));
+    BDSP_TRY(b.alloc(sizeof(T) * len, s));
+    BDSP_HIP_TRY(hipMemcpyAsync(a.p, signal, sizeof(T) * len, hipMemcpyHostToDevice, s));
+    bool in_b = false;
+    BDSP_TRY(fft_two_buffers<T>(a.as<T>(), b.as<T>(), points, 1, inverse != 0, 0, (T)1, -1, (T)0, &in_b, s));
+    BDSP_HIP_TRY(hipMemcpyAsync(signal, in_b ? b.p : a.p, sizeof(T) * len, hipMemcpyDeviceToHost, s));
+    BDSP_HIP_TRY(hipStreamSynchronize(s));
+    return BDSP_OK;
+}
+
+// complex convolution of device vectors; picks the block kernel whenever it applies
+template <typename T>
+int conv_complex_dev(const T* in, T* out, size_t points, size_t batch, const T* taps, size_t ntaps,
+                     hipStream_t s)
+{
+    if (ntaps >= 1 && ntaps - 1 <= 1024 && ntaps <= points && points >= 1)
+        return convolve_overlap_save<T>(in, out, points, batch, taps, ntaps, -(long long)(ntaps / 2), 0, 0,
+                                        nullptr, nullptr, s);
+    return convolve_direct<T>(in, out, points, batch, taps, ntaps, true, s);
+}
+
+// real data: complexify (zero imaginary parts), run the complex path, keep the real parts
+template <typename T>
+int conv_real_dev(const T* in, T* out, size_t points, const T* taps, size_t ntaps, hipStream_t s)
+{
+    if (!(ntaps >= 1 && ntaps - 1 <= 1024 && ntaps <= points))
+        return convolve_direct<T>(in, out, points, 1, taps, ntaps, false, s);
+    WsBlock xc, yc, hc;
+    BDSP_TRY(xc.alloc(sizeof(T) * 2 * points, s));
+    BDSP_TRY(yc.alloc(sizeof(T) * 2 * points, s));
+    BDSP_TRY(hc.alloc(sizeof(T) * 2 * ntaps, s));
+    BDSP_TRY(rg_zero_interleave<T>(in, xc.as<T>(), points, 1, 2, s));
+    BDSP_TRY(rg_zero_interleave<T>(taps, hc.as<T>(), ntaps, 1, 2, s));
+    BDSP_TRY(conv_complex_dev<T>(xc.as<T>(), yc.as<T>(), points, 1, hc.as<T>(), ntaps, s));
+    return ew_complex_to_real<T>(yc.as<T>(), out, 2 * points, 2, s);
+}
+
+template <typename T>
+int b1_convolve(int is_complex, const T* src, size_t src_len, T* dst, size_t dst_len, const T* imp,
+                size_t imp_len, size_t* range_start, size_t* range_end)
+{
+    const size_t elem = is_complex ? 2 : 1;
+    const size_t points = src_len / elem, ntaps = imp_len / elem;
+    if (points == 0 || ntaps == 0 || ntaps > points || dst_len < src_len) return 0; // None
+    int c = check_device();
+    if (c != BDSP_OK) return c;
+    hipStream_t s = lib_stream();
+    WsBlock dx, dy, dh;
+    BDSP_TRY(dx.alloc(sizeof(T) * src_len, s));
+    BDSP_TRY(dy.alloc(sizeof(T) * src_len, s));
+    BDSP_TRY(dh.alloc(sizeof(T) * imp_len, s));
+    BDSP_HIP_TRY(hipMemcpyAsync(dx.p, src, sizeof(T) * src_len, hipMemcpyHostToDevice, s));
+    BDSP_HIP_TRY(hipMemcpyAsync(dh.p, imp, sizeof(T) * imp_len, hipMemcpyHostToDevice, s));
+    if (is_complex) BDSP_TRY(conv_complex_dev<T>(dx.as<T>(), dy.as<T>(), points, 1, dh.as<T>(), ntaps, s));
+    else BDSP_TRY(conv_real_dev<T>(dx.as<T>(), dy.as<T>(), points, dh.as<T>(), ntaps, s));
+    BDSP_HIP_TRY(hipMemcpyAsync(dst, dy.p, sizeof(T) * src_len, hipMemcpyDeviceToHost, s));
+    BDSP_HIP_TRY(hipStreamSynchronize(s));
+    if (range_start) *range_start = 0;
+    if (range_end) *range_end = src_len;
+    return 1; // Some(0..src_len)
+}
+
+// GpuSupport::overlap_discard, any power-of-two fft_len (ocl/mod.rs:361-520): batched block FFTs
+// over overlapping windows of the uploaded signal (in_stride = step), one broadcast spectrum
+// product, batched inverse FFTs, one scatter of the valid parts.
+template <typename T>
+size_t b1_overlap_discard(T* x_time, size_t x_len, T* tmp, size_t tmp_len, const T* h_freq,
+                          size_t h_len, size_t imp_len, size_t step_size)
+{
+    const size_t l = h_len / 2, xp = x_len / 2, m = imp_len / 2, step = step_size / 2;
+    if (l == 0 || !is_pow2(l) || step == 0 || xp < l || tmp_len < h_len || m == 0 || m > l) {
+        set_last_error("overlap_discard: unsupported argument combination");
+        return 0;
+    }
+    if (check_device() != BDSP_OK) return 0;
+    // blocks at positions 0, step, 2*step, ... : the first one always, then while pos + l < xp
+    size_t nb = 1;
+    while (nb * step + l < xp) ++nb;
+    hipStream_t s = lib_stream();
+    auto run = [&]() -> int {
+        WsBlock dx, dz, dz2, dh;
+        BDSP_TRY(dx.alloc(sizeof(T) * x_len, s));
+        BDSP_TRY(dz.alloc(sizeof(T) * 2 * l * nb, s));
+        BDSP_TRY(dz2.alloc(sizeof(T) * 2 * l * nb, s));
+        BDSP_TRY(dh.alloc(sizeof(T) * h_len, s));
+        BDSP_HIP_TRY(hipMemcpyAsync(dx.p, x_time, sizeof(T) * x_len, hipMemcpyHostToDevice, s));
+        BDSP_HIP_TRY(hipMemcpyAsync(dh.p, h_freq, sizeof(T) * h_len, hipMemcpyHostToDevice, s));
+        // forward FFT of the overlapping windows straight from the signal (row stride = step
+        // points), never touching the signal buffer itself: in -> sa [-> sb] -> out
+        bool r1 = false;
+        {
+            FftIo<T> io{};
+            io.n = l; io.in = dx.p; io.in_stride = step; io.out_stride = l; io.flags = 0;
+            io.in_scale = (T)1; io.window_id = -1; io.window_alpha = (T)0;
+            if (l <= 4096) { io.out = dz.p; BDSP_TRY(fft_pow2<T>(io, nullptr, nullptr, nb, false, s)); }
+            else if (l <= (size_t(1) << 20)) { io.out = dz.p; BDSP_TRY(fft_pow2<T>(io, dz2.as<T>(), nullptr, nb, false, s)); }
+            else { io.out = dz2.p; r1 = true; BDSP_TRY(fft_pow2<T>(io, dz2.as<T>(), dz.as<T>(), nb, false, s)); }
+        }
+        T* spec = r1 ? dz2.as<T>() : dz.as<T>();
+        T* scr = r1 ? dz.as<T>() : dz2.as<T>();
+        BDSP_TRY(mul_bcast<T>(spec, dh.as<T>(), l, nb, (T)1 / (T)l, s));
+        bool r2 = false;
+        BDSP_TRY(fft_two_buffers<T>(spec, scr, l, nb, true, 0, (T)1, -1, (T)0, &r2, s));
+        T* z = r2 ? scr : spec;
+        // head computed by the caller: tmp[0 .. imp_len/2) -> x_time[0 .. imp_len/2)
+        BDSP_HIP_TRY(hipMemcpyAsync(dx.p, tmp, sizeof(T) * (imp_len / 2), hipMemcpyHostToDevice, s));
+        // valid parts of all blocks but the last: z[b][m-1 .. l) -> x[b*step + m/2 ..]
+        if (nb > 1) BDSP_TRY(scatter_valid<T>(z, dx.as<T>(), l, m - 1, step, m / 2, nb - 1, xp, s));
+        BDSP_HIP_TRY(hipMemcpyAsync(x_time, dx.p, sizeof(T) * x_len, hipMemcpyDeviceToHost, s));
+        BDSP_HIP_TRY(hipMemcpyAsync(tmp, z + 2 * l * (nb - 1), sizeof(T) * 2 * l, hipMemcpyDeviceToHost, s));
+        BDSP_HIP_TRY(hipStreamSynchronize(s));
+        return BDSP_OK;
+    };
+    if (run() != BDSP_OK) return 0;
+    return nb * step_size;
+}
+
+// ----------------------------------------------------------------------------------------------
+// B2: HBM-resident vector behind the facade handle
+// ----------------------------------------------------------------------------------------------
+template <typename T>
+struct DevVec {
+    T* data = nullptr; // live buffer
+    T* buf = nullptr;  // trade buffer (reference: SingleBuffer, support_std.rs:78-124)
+    size_t cap = 0;    // scalars each buffer can hold
+    size_t valid_len = 0;
+    T delta = (T)1;
+    bool complex_ = false;
+    bool freq = false;
+    std::vector<T> mirror; // host copy handed out by data32/data64
+
+    size_t points() const { return complex_ ? valid_len / 2 : valid_len; }
+    bool erroneous() const { return valid_len == 0 && std::isnan((double)delta); }
+    void poison() { valid_len = 0; delta = std::numeric_limits<T>::quiet_NaN(); } // mod.rs:226-229
+    void trade() { T* t = data; data = buf; buf = t; }
+
+    int reserve(size_t scalars)
+    {
+        if (scalars <= cap) return BDSP_OK;
+        hipStream_t s = lib_stream();
+        size_t ncap = scalars + scalars / 8 + 64;
+        void *nd = nullptr, *nb = nullptr;
+        BDSP_TRY(ws_alloc(&nd, sizeof(T) * ncap, s));
+        int c = ws_alloc(&nb, sizeof(T) * ncap, s);
+        if (c != BDSP_OK) { ws_free(nd, s); return c; }
+        if (data && valid_len)
+            BDSP_HIP_TRY(hipMemcpyAsync(nd, data, sizeof(T) * valid_len, hipMemcpyDeviceToDevice, s));
+        if (data) ws_free(data, s);
+        if (buf) ws_free(buf, s);
+        data = (T*)nd;
+        buf = (T*)nb;
+        cap = ncap;
+        return BDSP_OK;
+    }
+    ~DevVec()
+    {
+        hipStream_t s = lib_stream();
+        if (data) ws_free(data, s);
+        if (buf) ws_free(buf, s);
+    }
+};
+
+template <typename T> struct ResultOf;
+template <> struct ResultOf<float> { using type = VectorInteropResult32; using handle = VecBuf32; };
+template <> struct ResultOf<double> { using type = VectorInteropResult64; using handle = VecBuf64; };
+
+template <typename T> DevVec<T>* H(typename ResultOf<T>::handle* h) { return reinterpret_cast<DevVec<T>*>(h); }
+template <typename T> const DevVec<T>* H(const typename ResultOf<T>::handle* h) { return reinterpret_cast<const DevVec<T>*>(h); }
+
+// convert_vec / trans_vec result convention (interop/src/lib.rs:28-76): an Err(reason) maps to its
+// code; otherwise -1 if the vector is poisoned, else 0.  Backend failures use the <= -100 range.
+template <typename T>
+typename ResultOf<T>::type finish(DevVec<T>* v, int code)
+{
+    typename ResultOf<T>::type r;
+    r.vector = reinterpret_cast<typename ResultOf<T>::handle*>(v);
+    if (code == BDSP_OK) code = v->erroneous() ? BDSP_ERR_POISONED : BDSP_OK;
+    r.result_code = code;
+    return r;
+}
+
+template <typename T>
+DevVec<T>* vec_new(int is_complex, int domain, T init, size_t length, T delta)
+{
+    if (device_ready() != BDSP_OK) return nullptr;
+    DevVec<T>* v = new DevVec<T>();
+    v->complex_ = is_complex != 0;
+    v->freq = domain != 0;
+    v->delta = delta;
+    if (v->reserve(length ? length : 1) != BDSP_OK) { delete v; return nullptr; }
+    v->valid_len = length;
+    // to_gen_dsp_vec on an odd-length complex vector yields valid_len 0 (support_std.rs:288-291)
+    if (v->complex_ && length % 2 != 0) v->valid_len = 0;
+    if (length) {
+        if (init == (T)0) (void)hipMemsetAsync(v->data, 0, sizeof(T) * length, lib_stream());
+        else (void)ew_fill<T>(v->data, length, init, lib_stream());
+    }
+    return v;
+}
+
+template <typename T>
+DevVec<T>* vec_clone(const DevVec<T>* o)
+{
+    DevVec<T>* v = new DevVec<T>();
+    v->complex_ = o->complex_;
+    v->freq = o->freq;
+    v->delta = o->delta;
+    if (v->reserve(o->valid_len ? o->valid_len : 1) != BDSP_OK) { delete v; return nullptr; }
+    v->valid_len = o->valid_len;
+    if (o->valid_len)
+        (void)hipMemcpyAsync(v->data, o->data, sizeof(T) * o->valid_len, hipMemcpyDeviceToDevice, lib_stream());
+    return v;
+}
+
+// assert_meta_data! (elementary.rs:370-381, convolution.rs:257-268)
+template <typename T>
+bool meta_agrees(const DevVec<T>* a, const DevVec<T>* b)
+{
+    T ratio = a->delta / b->delta;
+    return a->complex_ == b->complex_ && a->freq == b->freq && !(ratio > (T)1.1) && !(ratio < (T)0.9);
+}
+
+template <typename T>
+int op_binary(DevVec<T>* v, const DevVec<T>* o, int op)
+{
+    if (v->valid_len != o->valid_len) return BDSP_ERR_SAME_SIZE; // elementary.rs:392
+    if (!meta_agrees(v, o)) return BDSP_ERR_META_DATA;
+    return ew_binary<T>(v->data, o->data, v->valid_len, v->complex_, op, lib_stream());
+}
+
+template <typename T>
+int op_complex_to_real(DevVec<T>* v, int kind)
+{
+    if (!v->complex_) { v->poison(); return BDSP_OK; } // assert_complex!, complex_to_real.rs:352-362
+    BDSP_TRY(ew_complex_to_real<T>(v->data, v->buf, v->valid_len, kind, lib_stream()));
+    v->trade();
+    v->valid_len /= 2;
+    v->complex_ = false;
+    return BDSP_OK;
+}
+
+// window ids: facade ids 0..3 (interop/src/lib.rs:153-164, unknown -> rectangular) + 4 = Hann
+template <typename T>
+void map_window(int id, int* wid, T* alpha)
+{
+    *alpha = (T)0.54;
+    if (id == 4) { *wid = 1; *alpha = (T)0.5; }
+    else if (id >= 0 && id <= 3) *wid = id;
+    else *wid = 3;
+}
+
+// plain_fft / fft / windowed_fft (time_to_freq.rs:136-176) and plain_ifft / ifft / windowed_ifft
+// (freq_to_time.rs:136-177) with the shift, window and 1/N scale fused into the transform.
+template <typename T>
+int op_fft(DevVec<T>* v, bool inverse, bool shift, int window /* -1 none */)
+{
+    hipStream_t s = lib_stream();
+    if (!inverse) {
+        if (v->freq) { v->poison(); v->complex_ = true; v->freq = true; return BDSP_OK; } // :140-145
+    } else {
+        if (!v->freq) { v->poison(); v->complex_ = true; v->freq = true; return BDSP_OK; } // :142-147
+    }
+    unsigned flags = 0;
+    size_t points = v->points();
+    if (!v->complex_) { // real input is zero-interleaved to complex first (:147-150)
+        flags |= FFT_IN_REAL;
+        BDSP_TRY(v->reserve(2 * v->valid_len));
+    }
+    int wid = -1;
+    T alpha = 0;
+    T in_scale = (T)1;
+    if (!inverse) {
+        if (window >= 0) map_window<T>(window, &wid, &alpha);
+        if (shift) flags |= BDSP_FFT_SHIFT_OUT;
+    } else if (shift) {
+        // ifft = scale(1/points) -> ifft_shift -> plain_ifft (freq_to_time.rs:160-168)
+        in_scale = (T)1 / (T)points;
+        flags |= BDSP_FFT_SHIFT_IN;
+        if (window >= 0) { map_window<T>(window, &wid, &alpha); flags |= FFT_WINDOW_OUT_DIV; }
+    }
+    if (points == 0) { v->complex_ = true; v->freq = !inverse; return BDSP_OK; }
+    if (!is_pow2(points) && (flags & (FFT_IN_REAL | FFT_WINDOW_OUT_DIV))) {
+        // slow path pieces the fused kernels do not cover for Bluestein lengths
+        if (flags & FFT_IN_REAL) {
+            BDSP_TRY(rg_zero_interleave<T>(v->data, v->buf, v->valid_len, 1, 2, s));
+            v->trade();
+            v->valid_len *= 2;
+            v->complex_ = true;
+            flags &= ~FFT_IN_REAL;
+        }
+    }
+    bool out_div = (flags & FFT_WINDOW_OUT_DIV) && !is_pow2(points);
+    if (out_div) flags &= ~FFT_WINDOW_OUT_DIV;
+    int fwid = (out_div ? -1 : wid);
+    bool in_b = false;
+    BDSP_TRY(fft_two_buffers<T>(v->data, v->buf, points, 1, inverse, flags, in_scale, fwid, alpha, &in_b, s));
+    if (in_b) v->trade();
+    v->valid_len = 2 * points;
+    v->complex_ = true;
+    if (out_div) BDSP_TRY(ew_window<T>(v->data, v->valid_len, true, wid, alpha, true, s));
+    // fft(): delta <- points * delta (time_freq/mod.rs:54-55; the reference's own GPU branch
+    // forgets this, SURVEY.md section 3.1 -- the CPU behaviour is the contract)
+    v->delta = (T)points * v->delta;
+    // Deviation, documented in DESIGN.md: the reference leaves a GenDspVec in the FREQUENCY domain
+    // after plain_ifft (freq_to_time.rs:153 calls to_freq()); we report Time.
+    v->freq = !inverse;
+    return BDSP_OK;
+}
+
+template <typename T>
+int op_convolve_signal(DevVec<T>* v, const DevVec<T>* h)
+{
+    if (!meta_agrees(v, h)) return BDSP_ERR_META_DATA;  // convolution.rs:485
+    if (v->freq) return BDSP_ERR_MUST_BE_TIME;           // :486-488
+    if (v->points() < h->points()) return BDSP_ERR_ARG_LENGTH; // :490-492
+    if (v->points() == 0 || h->points() == 0) return BDSP_OK;
+    hipStream_t s = lib_stream();
+    if (v->complex_) BDSP_TRY(conv_complex_dev<T>(v->data, v->buf, v->points(), 1, h->data, h->points(), s));
+    else BDSP_TRY(conv_real_dev<T>(v->data, v->buf, v->points(), h->data, h->points(), s));
+    v->trade();
+    return BDSP_OK;
+}
+
+template <typename T>
+int op_interpolatef(DevVec<T>* v, int fid, T rolloff, T factor, T delay, size_t conv_len)
+{
+    size_t new_len = interpolatef_new_len<T>(v->valid_len, factor);
+    BDSP_TRY(v->reserve(new_len > v->valid_len ? new_len : v->valid_len));
+    if (v->valid_len == 0) return BDSP_OK;
+    BDSP_TRY(interpolatef_dev<T>(v->data, v->buf, v->valid_len, v->complex_, fid, rolloff, factor, delay,
+                                 conv_len, v->delta, lib_stream()));
+    v->trade();
+    v->valid_len = new_len; // interpolation.rs:481; delta is left alone by interpolatef
+    return BDSP_OK;
+}
+
+template <typename T>
+int op_swap(DevVec<T>* v, bool forward)
+{
+    size_t p = v->points();
+    if (p == 0) return BDSP_OK;
+    size_t shift = forward ? p - p / 2 : p / 2;
+    BDSP_TRY(rg_rotate<T>(v->data, v->buf, p, v->complex_ ? 2 : 1, shift, lib_stream()));
+    v->trade();
+    return BDSP_OK;
+}
+
+template <typename T>
+int op_zero_pad(DevVec<T>* v, size_t points, int option)
+{
+    size_t step = v->complex_ ? 2 : 1, len = points * step;
+    if (len <= v->valid_len) return BDSP_ERR_ARG_LENGTH; // data_reorganization.rs:415-417
+    BDSP_TRY(v->reserve(len));
+    int opt = option == 0 ? 0 : (option == 1 ? 1 : 2); // interop/src/lib.rs:194-200
+    BDSP_TRY(rg_zero_pad<T>(v->data, v->buf, v->valid_len, v->complex_, points, opt, lib_stream()));
+    v->trade();
+    v->valid_len = len;
+    return BDSP_OK;
+}
+
+template <typename T>
+int op_zero_interleave(DevVec<T>* v, int factor)
+{
+    if (factor <= 1) return BDSP_OK; // data_reorganization.rs:256-258
+    size_t nl = v->valid_len * (size_t)factor;
+    BDSP_TRY(v->reserve(nl));
+    BDSP_TRY(rg_zero_interleave<T>(v->data, v->buf, v->valid_len, v->complex_ ? 2 : 1, (size_t)factor, lib_stream()));
+    v->trade();
+    v->valid_len = nl;
+    return BDSP_OK;
+}
+
+template <typename T>
+int op_to_complex(DevVec<T>* v)
+{
+    if (v->complex_) { v->poison(); return BDSP_OK; } // real_to_complex.rs: assert_real!
+    size_t nl = 2 * v->valid_len;
+    BDSP_TRY(v->reserve(nl));
+    BDSP_TRY(rg_zero_interleave<T>(v->data, v->buf, v->valid_len, 1, 2, lib_stream()));
+    v->trade();
+    v->valid_len = nl;
+    v->complex_ = true;
+    return BDSP_OK;
+}
+
+template <typename T>
+int op_mirror(DevVec<T>* v)
+{
+    if (!v->freq && !v->complex_) { v->poison(); return BDSP_OK; } // freq.rs:56-59
+    if (v->valid_len < 2) return BDSP_OK;
+    size_t nl = 2 * v->valid_len - 2;
+    BDSP_TRY(v->reserve(nl));
+    BDSP_TRY(rg_mirror<T>(v->data, v->buf, v->valid_len, lib_stream()));
+    v->trade();
+    v->valid_len = nl;
+    return BDSP_OK;
+}
+
+template <typename T>
+int op_window(DevVec<T>* v, int window, bool unapply)
+{
+    int wid;
+    T alpha;
+    map_window<T>(window, &wid, &alpha);
+    return ew_window<T>(v->data, v->valid_len, v->complex_, wid, alpha, unapply, lib_stream());
+}
+
+template <typename T>
+const T* vec_download(DevVec<T>* v)
+{
+    v->mirror.resize(v->valid_len ? v->valid_len : 1);
+    hipStream_t s = lib_stream();
+    if (v->valid_len) {
+        if (hipMemcpyAsync(v->mirror.data(), v->data, sizeof(T) * v->valid_len, hipMemcpyDeviceToHost, s) != hipSuccess)
+            return nullptr;
+    }
+    if (hipStreamSynchronize(s) != hipSuccess) return nullptr;
+    return v->mirror.data();
+}
+
+} // namespace
+
+// ==============================================================================================
+// extern "C"
+// ==============================================================================================
+extern "C" {
+
+int bdsp_hip_has_gpu_support_f32(void) { return device_ready() == BDSP_OK; }
+int bdsp_hip_has_gpu_support_f64(void) { return device_ready() == BDSP_OK; }
+
+static int supported_len(int is_complex, size_t len)
+{
+    // complex only (like ocl/mod.rs:277-281), at least one point, interleaved length even
+    return is_complex && len >= 2 && len % 2 == 0 && (len / 2) <= (size_t(1) << 29);
+}
+int bdsp_hip_is_supported_fft_len_f32(int is_complex, size_t len) { return supported_len(is_complex, len); }
+int bdsp_hip_is_supported_fft_len_f64(int is_complex, size_t len) { return supported_len(is_complex, len); }
+
+int bdsp_hip_fft_f32(int is_complex, float* signal, size_t len, int inverse) { return b1_fft<float>(is_complex, signal, len, inverse); }
+int bdsp_hip_fft_f64(int is_complex, double* signal, size_t len, int inverse) { return b1_fft<double>(is_complex, signal, len, inverse); }
+
+int bdsp_hip_convolve_vector_f32(int is_complex, const float* src, size_t src_len, float* dst, size_t dst_len,
+                                 const float* imp, size_t imp_len, size_t* range_start, size_t* range_end)
+{ return b1_convolve<float>(is_complex, src, src_len, dst, dst_len, imp, imp_len, range_start, range_end); }
+int bdsp_hip_convolve_vector_f64(int is_complex, const double* src, size_t src_len, double* dst, size_t dst_len,
+                                 const double* imp, size_t imp_len, size_t* range_start, size_t* range_end)
+{ return b1_convolve<double>(is_complex, src, src_len, dst, dst_len, imp, imp_len, range_start, range_end); }
+
+size_t bdsp_hip_overlap_discard_f32(float* x_time, size_t x_len, float* tmp, size_t tmp_len, float*, size_t,
+                                    const float* h_freq, size_t h_len, size_t imp_len, size_t step_size)
+{ return b1_overlap_discard<float>(x_time, x_len, tmp, tmp_len, h_freq, h_len, imp_len, step_size); }
+size_t bdsp_hip_overlap_discard_f64(double* x_time, size_t x_len, double* tmp, size_t tmp_len, double*, size_t,
+                                    const double* h_freq, size_t h_len, size_t imp_len, size_t step_size)
+{ return b1_overlap_discard<double>(x_time, x_len, tmp, tmp_len, h_freq, h_len, imp_len, step_size); }
+
+// ---------------------------------------------------------------------------------------------- B2
+#define BDSP_FACADE(SFX, T, VB, RES)                                                                        \
+    VB* new##SFX(int32_t is_complex, int32_t domain, T init_value, size_t length, T delta)                  \
+    { return reinterpret_cast<VB*>(vec_new<T>(is_complex, domain, init_value, length, delta)); }           \
+    VB* new_with_performance_options##SFX(int32_t is_complex, int32_t domain, T init_value, size_t length, \
+                                          T delta, size_t, int)                                             \
+    { return reinterpret_cast<VB*>(vec_new<T>(is_complex, domain, init_value, length, delta)); }           \
+    void delete_vector##SFX(VB* vector) { delete H<T>(vector); }                                            \
+    VB* bdsp_hip_vec_clone##SFX(const VB* vector) { return reinterpret_cast<VB*>(vec_clone<T>(H<T>(vector))); } \
+    VB* clone##SFX(VB* vector)                                                                              \
+    { VB* c = reinterpret_cast<VB*>(vec_clone<T>(H<T>(vector))); delete H<T>(vector); return c; }          \
+    T get_value##SFX(const VB* vector, size_t index)                                                        \
+    {                                                                                                       \
+        T out = 0;                                                                                          \
+        const DevVec<T>* v = H<T>(vector);                                                                  \
+        if (index >= v->valid_len) return std::numeric_limits<T>::quiet_NaN();                             \
+        (void)hipMemcpyAsync(&out, v->data + index, sizeof(T), hipMemcpyDeviceToHost, lib_stream());        \
+        (void)hipStreamSynchronize(lib_stream());                                                           \
+        return out;                                                                                         \
+    }                                                                                                       \
+    size_t get_len##SFX(const VB* vector) { return H<T>(vector)->valid_len; }                               \
+    size_t get_points##SFX(const VB* vector) { return H<T>(vector)->points(); }                             \
+    T get_delta##SFX(const VB* vector) { return H<T>(vector)->delta; }                                      \
+    int32_t is_complex##SFX(const VB* vector) { return H<T>(vector)->complex_ ? 1 : 0; }                    \
+    int32_t get_domain##SFX(const VB* vector) { return H<T>(vector)->freq ? 1 : 0; }                        \
+    const T* data##SFX(VB* vector) { return vec_download<T>(H<T>(vector)); }                                \
+    void* bdsp_hip_vec_device_ptr##SFX(VB* vector) { return H<T>(vector)->data; }                           \
+    RES overwrite_data##SFX(VB* vector, const T* data, size_t len)                                          \
+    {                                                                                                       \
+        DevVec<T>* v = H<T>(vector);                                                                        \
+        if (len > v->valid_len) return finish<T>(v, BDSP_ERR_ARG_LENGTH);                                   \
+        hipStream_t s = lib_stream();                                                                       \
+        if (len && hipMemcpyAsync(v->data, data, sizeof(T) * len, hipMemcpyHostToDevice, s) != hipSuccess)  \
+            return finish<T>(v, BDSP_ERR_HIP);                                                              \
+        if (hipStreamSynchronize(s) != hipSuccess) return finish<T>(v, BDSP_ERR_HIP);                       \
+        return finish<T>(v, BDSP_OK);                                                                       \
+    }                                                                                                       \
+    void set_len##SFX(VB* vector, size_t len)                                                               \
+    {                                                                                                       \
+        DevVec<T>* v = H<T>(vector); /* resize (vec_impl_and_indexers.rs): grow within the allocation */    \
+        if (v->complex_ && len % 2 != 0) return;                                                            \
+        if (v->reserve(len) == BDSP_OK) v->valid_len = len;                                                 \
+    }                                                                                                       \
+    RES real_offset##SFX(VB* vector, T value)                                                               \
+    { DevVec<T>* v = H<T>(vector); return finish<T>(v, ew_real_offset<T>(v->data, v->valid_len, v->complex_, value, lib_stream())); } \
+    RES real_scale##SFX(VB* vector, T value)                                                                \
+    { DevVec<T>* v = H<T>(vector); return finish<T>(v, ew_real_scale<T>(v->data, v->valid_len, value, lib_stream())); } \
+    RES complex_offset##SFX(VB* vector, T re, T im)                                                         \
+    {                                                                                                       \
+        DevVec<T>* v = H<T>(vector);                                                                        \
+        if (!v->complex_) { v->poison(); return finish<T>(v, BDSP_OK); } /* elementary.rs:273-279 */        \
+        return finish<T>(v, ew_complex_offset<T>(v->data, v->valid_len, re, im, lib_stream()));             \
+    }                                                                                                       \
+    RES complex_scale##SFX(VB* vector, T re, T im)                                                          \
+    {                                                                                                       \
+        DevVec<T>* v = H<T>(vector);                                                                        \
+        if (!v->complex_) { v->poison(); return finish<T>(v, BDSP_OK); }                                    \
+        return finish<T>(v, ew_complex_scale<T>(v->data, v->valid_len, re, im, lib_stream()));              \
+    }                                                                                                       \
+    RES add##SFX(VB* vector, const VB* operand) { DevVec<T>* v = H<T>(vector); return finish<T>(v, op_binary<T>(v, H<T>(operand), 0)); } \
+    RES sub##SFX(VB* vector, const VB* operand) { DevVec<T>* v = H<T>(vector); return finish<T>(v, op_binary<T>(v, H<T>(operand), 1)); } \
+    RES mul##SFX(VB* vector, const VB* operand) { DevVec<T>* v = H<T>(vector); return finish<T>(v, op_binary<T>(v, H<T>(operand), 2)); } \
+    RES div##SFX(VB* vector, const VB* operand) { DevVec<T>* v = H<T>(vector); return finish<T>(v, op_binary<T>(v, H<T>(operand), 3)); } \
+    RES conj##SFX(VB* vector)                                                                               \
+    {                                                                                                       \
+        DevVec<T>* v = H<T>(vector);                                                                        \
+        if (!v->complex_) { v->complex_ = false; v->poison(); return finish<T>(v, BDSP_OK); } /* complex_ops.rs:65-72 */ \
+        return finish<T>(v, ew_conj<T>(v->data, v->valid_len, lib_stream()));                               \
+    }                                                                                                       \
+    RES multiply_complex_exponential##SFX(VB* vector, T a, T b)                                             \
+    {                                                                                                       \
+        DevVec<T>* v = H<T>(vector);                                                                        \
+        if (!v->complex_) { v->poison(); return finish<T>(v, BDSP_OK); }                                    \
+        return finish<T>(v, ew_mul_cexp<T>(v->data, v->valid_len, a * v->delta, b * v->delta, lib_stream())); \
+    }                                                                                                       \
+    RES magnitude##SFX(VB* vector) { DevVec<T>* v = H<T>(vector); return finish<T>(v, op_complex_to_real<T>(v, 0)); } \
+    RES magnitude_squared##SFX(VB* vector) { DevVec<T>* v = H<T>(vector); return finish<T>(v, op_complex_to_real<T>(v, 1)); } \
+    RES to_real##SFX(VB* vector) { DevVec<T>* v = H<T>(vector); return finish<T>(v, op_complex_to_real<T>(v, 2)); } \
+    RES to_imag##SFX(VB* vector) { DevVec<T>* v = H<T>(vector); return finish<T>(v, op_complex_to_real<T>(v, 3)); } \
+    RES phase##SFX(VB* vector) { DevVec<T>* v = H<T>(vector); return finish<T>(v, op_complex_to_real<T>(v, 4)); } \
+    RES to_complex##SFX(VB* vector) { DevVec<T>* v = H<T>(vector); return finish<T>(v, op_to_complex<T>(v)); } \
+    RES reverse##SFX(VB* vector)                                                                            \
+    {                                                                                                       \
+        DevVec<T>* v = H<T>(vector);                                                                        \
+        int c = rg_reverse<T>(v->data, v->buf, v->points(), v->complex_ ? 2 : 1, lib_stream());             \
+        if (c == BDSP_OK && v->points()) v->trade();                                                        \
+        return finish<T>(v, c);                                                                             \
+    }                                                                                                       \
+    RES swap_halves##SFX(VB* vector) { DevVec<T>* v = H<T>(vector); return finish<T>(v, op_swap<T>(v, true)); } \
+    RES fft_shift##SFX(VB* vector) { DevVec<T>* v = H<T>(vector); return finish<T>(v, op_swap<T>(v, true)); } \
+    RES ifft_shift##SFX(VB* vector) { DevVec<T>* v = H<T>(vector); return finish<T>(v, op_swap<T>(v, false)); } \
+    RES zero_pad##SFX(VB* vector, size_t points, int32_t option) { DevVec<T>* v = H<T>(vector); return finish<T>(v, op_zero_pad<T>(v, points, option)); } \
+    RES zero_interleave##SFX(VB* vector, int32_t factor) { DevVec<T>* v = H<T>(vector); return finish<T>(v, op_zero_interleave<T>(v, factor)); } \
+    RES mirror##SFX(VB* vector) { DevVec<T>* v = H<T>(vector); return finish<T>(v, op_mirror<T>(v)); }     \
+    RES apply_window##SFX(VB* vector, int32_t window) { DevVec<T>* v = H<T>(vector); return finish<T>(v, op_window<T>(v, window, false)); } \
+    RES unapply_window##SFX(VB* vector, int32_t window) { DevVec<T>* v = H<T>(vector); return finish<T>(v, op_window<T>(v, window, true)); } \
+    RES plain_fft##SFX(VB* vector) { DevVec<T>* v = H<T>(vector); return finish<T>(v, op_fft<T>(v, false, false, -1)); } \
+    RES plain_ifft##SFX(VB* vector) { DevVec<T>* v = H<T>(vector); return finish<T>(v, op_fft<T>(v, true, false, -1)); } \
+    RES fft##SFX(VB* vector) { DevVec<T>* v = H<T>(vector); return finish<T>(v, op_fft<T>(v, false, true, -1)); } \
+    RES ifft##SFX(VB* vector) { DevVec<T>* v = H<T>(vector); return finish<T>(v, op_fft<T>(v, true, true, -1)); } \
+    RES windowed_fft##SFX(VB* vector, int32_t window) { DevVec<T>* v = H<T>(vector); return finish<T>(v, op_fft<T>(v, false, true, window < 0 ? 3 : window)); } \
+    RES windowed_ifft##SFX(VB* vector, int32_t window) { DevVec<T>* v = H<T>(vector); return finish<T>(v, op_fft<T>(v, true, true, window < 0 ? 3 : window)); } \
+    RES convolve_signal##SFX(VB* vector, const VB* impulse_response)                                        \
+    { DevVec<T>* v = H<T>(vector); return finish<T>(v, op_convolve_signal<T>(v, H<T>(impulse_response))); } \
+    RES interpolatef##SFX(VB* vector, int32_t impulse_response, T rolloff, T interpolation_factor, T delay, size_t conv_len) \
+    { DevVec<T>* v = H<T>(vector); return finish<T>(v, op_interpolatef<T>(v, impulse_response == 0 ? 0 : 1, rolloff, interpolation_factor, delay, conv_len)); }
+
+BDSP_FACADE(32, float, VecBuf32, VectorInteropResult32)
+BDSP_FACADE(64, double, VecBuf64, VectorInteropResult64)
+#undef BDSP_FACADE
+
+// ---------------------------------------------------------------------------------------------- B3
+int bdsp_hip_dev_fft(int elem, void* data, void* scratch, size_t points, size_t batch, unsigned flags,
+                     double in_scale, int window_id, double window_alpha, int* result_in_scratch, void* stream)
+{
+    BDSP_TRY(check_device());
+    hipStream_t s = pick_stream(stream);
+    bool inverse = (flags & BDSP_FFT_INVERSE) != 0;
+    unsigned f = flags & (BDSP_FFT_SHIFT_OUT | BDSP_FFT_SHIFT_IN | BDSP_FFT_MAGNITUDE);
+    bool in_b = false;
+    int c;
+    if (elem == 0) {
+        int wid = -1; float alpha = (float)window_alpha;
+        if (window_id >= 0) { map_window<float>(window_id, &wid, &alpha); if (window_id == 1) alpha = (float)window_alpha; }
+        c = fft_two_buffers<float>((float*)data, (float*)scratch, points, batch, inverse, f, (float)in_scale, wid, alpha, &in_b, s);
+    } else {
+        int wid = -1; double alpha = window_alpha;
+        if (window_id >= 0) { map_window<double>(window_id, &wid, &alpha); if (window_id == 1) alpha = window_alpha; }
+        c = fft_two_buffers<double>((double*)data, (double*)scratch, points, batch, inverse, f, in_scale, wid, alpha, &in_b, s);
+    }
+    if (result_in_scratch) *result_in_scratch = in_b ? 1 : 0;
+    return c;
+}
+
+int bdsp_hip_dev_convolve(int elem, const void* in, void* out, size_t points, size_t batch, const void* taps_dev,
+                          size_t taps, void* stream)
+{
+    BDSP_TRY(check_device());
+    if (in == out) { set_last_error("dev_convolve: out must not alias in"); return BDSP_ERR_UNSUPPORTED; }
+    if (taps > points) return BDSP_ERR_ARG_LENGTH;
+    hipStream_t s = pick_stream(stream);
+    if (elem == 0) return conv_complex_dev<float>((const float*)in, (float*)out, points, batch, (const float*)taps_dev, taps, s);
+    return conv_complex_dev<double>((const double*)in, (double*)out, points, batch, (const double*)taps_dev, taps, s);
+}
+
+size_t bdsp_hip_conv_spectrum_points(void) { return conv_fft_len(0); }
+
+int bdsp_hip_dev_conv_prepare(int elem, const void* taps_dev, size_t taps, void* spectrum_dev, void* stream)
+{
+    BDSP_TRY(check_device());
+    hipStream_t s = pick_stream(stream);
+    if (elem == 0) return conv_prepare_spectrum<float>((const float*)taps_dev, taps, nullptr, (float*)spectrum_dev, s);
+    return conv_prepare_spectrum<double>((const double*)taps_dev, taps, nullptr, (double*)spectrum_dev, s);
+}
+
+int bdsp_hip_dev_convolve_prepared(int elem, const void* in, void* out, size_t points, size_t batch,
+                                   const void* spectrum_dev, size_t taps, void* stream)
+{
+    BDSP_TRY(check_device());
+    if (in == out) { set_last_error("dev_convolve: out must not alias in"); return BDSP_ERR_UNSUPPORTED; }
+    if (taps > points || taps == 0) return BDSP_ERR_ARG_LENGTH;
+    hipStream_t s = pick_stream(stream);
+    if (elem == 0)
+        return conv_run_blocks<float>((const float*)in, (float*)out, points, batch, (const float*)spectrum_dev, taps,
+                                      -(long long)(taps / 2), 0, 0, nullptr, s);
+    return conv_run_blocks<double>((const double*)in, (double*)out, points, batch, (const double*)spectrum_dev, taps,
+                                   -(long long)(taps / 2), 0, 0, nullptr, s);
+}
+
+int bdsp_hip_dev_real_scale(int elem, void* data, size_t len, double factor, void* stream)
+{
+    BDSP_TRY(check_device());
+    hipStream_t s = pick_stream(stream);
+    if (elem == 0) return ew_real_scale<float>((float*)data, len, (float)factor, s);
+    return ew_real_scale<double>((double*)data, len, factor, s);
+}
+
+int bdsp_hip_dev_real_offset(int elem, void* data, size_t len, int is_complex, double offset, void* stream)
+{
+    BDSP_TRY(check_device());
+    hipStream_t s = pick_stream(stream);
+    if (elem == 0) return ew_real_offset<float>((float*)data, len, is_complex != 0, (float)offset, s);
+    return ew_real_offset<double>((double*)data, len, is_complex != 0, offset, s);
+}
+
+size_t bdsp_hip_interpolatef_new_len(int elem, size_t len, double factor)
+{
+    return elem == 0 ? interpolatef_new_len<float>(len, (float)factor) : interpolatef_new_len<double>(len, factor);
+}
+
+int bdsp_hip_dev_interpolatef(int elem, const void* in, void* out, size_t len, int is_complex, int function_id,
+                              double rolloff, double factor, double delay, size_t conv_len, double delta, void* stream)
+{
+    BDSP_TRY(check_device());
+    hipStream_t s = pick_stream(stream);
+    if (elem == 0)
+        return interpolatef_dev<float>((const float*)in, (float*)out, len, is_complex != 0, function_id == 0 ? 0 : 1,
+                                       (float)rolloff, (float)factor, (float)delay, conv_len, (float)delta, s);
+    return interpolatef_dev<double>((const double*)in, (double*)out, len, is_complex != 0, function_id == 0 ? 0 : 1,
+                                    rolloff, factor, delay, conv_len, delta, s);
+}
+
+int bdsp_hip_synchronize(void* stream)
+{
+    BDSP_TRY(check_device());
+    BDSP_HIP_TRY(hipStreamSynchronize(pick_stream(stream)));
+    return BDSP_OK;
+}
+
+int bdsp_hip_set_device(int ordinal)
+{
+    BDSP_HIP_TRY(hipSetDevice(ordinal));
+    return device_ready();
+}
+
+void* bdsp_hip_event_create(void)
+{
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+}
+int bdsp_hip_event_record(void* event, void* stream)
+{
+    BDSP_HIP_TRY(hipEventRecord((hipEvent_t)event, pick_stream(stream)));
+    return BDSP_OK;
+}
+int bdsp_hip_event_elapsed_ms(void* start, void* stop, float* ms)
+{
+    BDSP_HIP_TRY(hipEventSynchronize((hipEvent_t)stop));
+    BDSP_HIP_TRY(hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop));
+    return BDSP_OK;
+}
+void bdsp_hip_event_destroy(void* event) { if (event) (void)hipEventDestroy((hipEvent_t)event); }
+
+} // extern "C"

@@ -1,0 +1,372 @@
+// conv.hip -- convolve_signal on gfx950: fused overlap-save blocks (+ a direct form for the
+// shapes overlap-save cannot take).
+//
+// Reference semantics (vector/src/vector_types/time_freq/mod.rs:455-473, convolution.rs:477-542):
+//     y[i] = sum_{k=0}^{M-1} x[(i + ceil(M/2) - 1 - k) mod N] * h[k]        (centred, circular)
+// Reference schedule being replaced: overlap_discard (convolution.rs:304-461) = per block
+// FFT -> xH/fft_len -> IFFT with three trips through memory, a scalar O(N*M/2) tail, and on the
+// OpenCL backend one context + plan + upload per call (ocl/mod.rs:361-520).
+//
+// Here ONE kernel does load -> FFT_L -> xH -> IFFT_L -> store of the valid part, with the block
+// resident in registers/LDS the whole time: HBM sees each input sample once (plus the M-1 overlap,
+// normally an L2 hit) and each output sample once = 16 B per complex f32 sample.
+// Block b produces outputs [b*V, (b+1)*V), V = L-(M-1), from inputs x[(b*V - floor(M/2) + n) mod N],
+// n = 0..L-1; the wrap-around makes the head and tail ordinary blocks (no scalar loops).
+// L = 4096, 256 threads x 16 points, three radix-16 Stockham stages each way; the forward
+// transform leaves X[t + 256 r] in register r of thread t, which is exactly what the inverse
+// transform's first stage wants, so the spectrum never visits LDS.  Inner-stage twiddles live in
+// registers for the whole (persistent) workgroup in the f32 build.
+#include "bdsp_internal.h"
+
+namespace bdsp {
+
+constexpr int CONV_L = 4096;
+
+size_t conv_fft_len(size_t) { return CONV_L; }
+
+// Grid: x = persistent workgroups walking the blocks of one vector with a grid stride,
+//       y = vector of the batch.  All per-vector indices are 32-bit (points < 2^31).
+template <typename T, bool REGTW>
+__global__ __launch_bounds__(256, 2) void k_overlap_save(
+    const cpx<T>* __restrict__ x, cpx<T>* __restrict__ y, const cpx<T>* __restrict__ hs,
+    const cpx<T>* __restrict__ wtab, unsigned n, int m_taps, long long in_off, long long out_off,
+    unsigned blocks_per_vec, unsigned out_limit, int store_all)
+{
+    constexpr int L = CONV_L, NT = 256;
+    using F = WgFft<T, L, NT>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    cpx<T>* lds = reinterpret_cast<cpx<T>*>(smem_raw);
+    const int t = threadIdx.x;
+    const int ov = m_taps - 1;
+    const unsigned V = (unsigned)(L - ov);
+    auto tw = [&](int mm) { return wtab[mm]; };
+
+    cpx<T> tw2[REGTW ? 15 : 1], tw3[REGTW ? 15 : 1];
+    if constexpr (REGTW) {
+        F::template load_twiddles<16, 16>(tw2, t, tw);
+        F::template load_twiddles<16, 256>(tw3, t, tw);
+    }
+    const size_t vec = blockIdx.y;
+    const cpx<T>* __restrict__ xv = x + vec * (size_t)n;
+    cpx<T>* __restrict__ yv = y + vec * (size_t)(store_all ? (unsigned)L : n);
+
+    for (unsigned b = blockIdx.x; b < blocks_per_vec; b += gridDim.x) {
+        // Keep the spectrum (and, without register twiddles, the twiddle table) out of loop-invariant
+        // code motion: hoisted they would pin 32..150 VGPRs for the whole persistent loop.
+        const cpx<T>* hp = hs + t;
+        const cpx<T>* wt = wtab;
+        asm volatile("" : "+v"(hp));
+        if constexpr (!REGTW) asm volatile("" : "+s"(wt));
+        auto twl = [&](int mm) { return wt[mm]; };
+        // first input index of the block, reduced into [0, n) once (uniform -> scalar registers)
+        long long base = (long long)b * V + in_off;
+        cpx<T> v[16];
+        // Global addressing is  uniform 64-bit base (scalar registers) + small unsigned lane index,
+        // so no per-register 64-bit addresses are kept alive across the loop.
+        const unsigned ut = (unsigned)t;
+        if (base >= 0 && base + L <= (long long)n) {
+            const cpx<T>* xb = xv + base;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = xb[ut + 256u * r];
+        } else {
+            long long sb = base % (long long)n;
+            if (sb < 0) sb += n;
+            const unsigned idx = (unsigned)sb + ut;
+            if (n >= (unsigned)L) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    unsigned i = idx + 256u * r;
+                    if (i >= n) i -= n;
+                    v[r] = xv[i];
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] = xv[(idx + 256u * r) % n];
+            }
+        }
+
+        // ---- forward FFT_L
+        F::template compute<16, 1, -1>(v, t, twl);
+        __syncthreads(); // previous block's last gather is done
+        F::template scatter<16, 1>(v, t, lds);
+        __syncthreads();
+        F::template gather<16>(v, t, lds);
+        if constexpr (REGTW) F::template compute_pre<16, 16, -1>(v, tw2);
+        else F::template compute<16, 16, -1>(v, t, twl);
+        __syncthreads();
+        F::template scatter<16, 16>(v, t, lds);
+        __syncthreads();
+        F::template gather<16>(v, t, lds);
+        if constexpr (REGTW) F::template compute_pre<16, 256, -1>(v, tw3);
+        else F::template compute<16, 256, -1>(v, t, twl);
+
+        // ---- spectrum product (hs already carries the 1/L of the inverse transform)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = cmul(v[r], hp[256 * r]);
+
+        // ---- inverse FFT_L
+        F::template compute<16, 1, 1>(v, t, twl);
+        __syncthreads();
+        F::template scatter<16, 1>(v, t, lds);
+        __syncthreads();
+        F::template gather<16>(v, t, lds);
+        if constexpr (REGTW) F::template compute_pre<16, 16, 1>(v, tw2);
+        else F::template compute<16, 16, 1>(v, t, twl);
+        __syncthreads();
+        F::template scatter<16, 16>(v, t, lds);
+        __syncthreads();
+        F::template gather<16>(v, t, lds);
+        if constexpr (REGTW) F::template compute_pre<16, 256, 1>(v, tw3);
+        else F::template compute<16, 256, 1>(v, t, twl);
+
+        // ---- store: z[n'] for n' >= M-1 is output b*V + out_off + (n' - (M-1))
+        if (store_all) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) yv[ut + 256u * r] = v[r];
+        } else {
+            // output index = obase + n', valid for ov <= n' < lim (both bounds uniform)
+            const long long obase = (long long)b * V + out_off - ov;
+            long long room = (long long)out_limit - obase;
+            const unsigned lim = room <= 0 ? 0u : (room > L ? (unsigned)L : (unsigned)room);
+            cpx<T>* yb = yv + obase;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                unsigned np = ut + 256u * r;
+                if (np >= (unsigned)ov && np < lim) yb[np] = v[r];
+            }
+        }
+    }
+}
+
+// Direct form for everything the block kernel cannot take (taps > 1025, real vectors handled by
+// the caller through complexification, tiny vectors): one output per thread, taps streamed from
+// L2, wrap-around by modular indexing.  O(N*M): a correctness net, not a fast path.
+template <typename T, bool CPLX>
+__global__ __launch_bounds__(256) void k_conv_direct(const T* __restrict__ x, T* __restrict__ y,
+                                                     const T* __restrict__ h, long long n,
+                                                     long long count, long long conv_len,
+                                                     long long total)
+{
+    long long gi = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gi >= total) return;
+    long long vec = gi / n, i = gi % n;
+    const T* xv = x + vec * n * (CPLX ? 2 : 1);
+    long long pos = (i + conv_len) % n;
+    if (CPLX) {
+        T sr = 0, si = 0;
+        for (long long k = 0; k < count; ++k) {
+            pos = pos > 0 ? pos - 1 : n - 1;
+            T ar = xv[2 * pos], ai = xv[2 * pos + 1], br = h[2 * k], bi = h[2 * k + 1];
+            sr = sr + (ar * br - ai * bi);
+            si = si + (ar * bi + ai * br);
+        }
+        y[2 * gi] = sr;
+        y[2 * gi + 1] = si;
+    } else {
+        T sr = 0;
+        for (long long k = 0; k < count; ++k) {
+            pos = pos > 0 ? pos - 1 : n - 1;
+            sr = sr + xv[pos] * h[k];
+        }
+        y[gi] = sr;
+    }
+}
+
+template <typename T>
+static size_t conv_lds_bytes() { return (size_t)(CONV_L + (CONV_L >> 4)) * sizeof(cpx<T>); }
+
+// Filter spectrum for the block kernel: hs[0..L) = FFT_L(zero-padded taps) / L in natural order
+// (the 1/L of the unnormalised inverse transform is folded in here).  Exactly one of
+// (taps_dev, h_freq_dev) is used: `taps` complex time-domain taps, or an UNSCALED length-L
+// spectrum handed in by GpuSupport::overlap_discard.
+template <typename T>
+int conv_prepare_spectrum(const T* taps_dev, size_t taps, const T* h_freq_dev, T* hs, hipStream_t s)
+{
+    constexpr int L = CONV_L;
+    if (h_freq_dev) {
+        BDSP_HIP_TRY(hipMemcpyAsync(hs, h_freq_dev, sizeof(cpx<T>) * L, hipMemcpyDeviceToDevice, s));
+        return ew_real_scale<T>(hs, 2 * (size_t)L, (T)1 / (T)L, s);
+    }
+    if (taps == 0 || taps > (size_t)L) return BDSP_ERR_ARG_LENGTH;
+    BDSP_HIP_TRY(hipMemsetAsync(hs, 0, sizeof(cpx<T>) * L, s));
+    BDSP_HIP_TRY(hipMemcpyAsync(hs, taps_dev, sizeof(cpx<T>) * taps, hipMemcpyDeviceToDevice, s));
+    FftIo<T> io{};
+    io.n = L; io.in_stride = L; io.out_stride = L; io.flags = 0; io.window_id = -1;
+    io.window_alpha = 0; io.in_scale = (T)1 / (T)L;
+    io.in = hs; io.out = hs;
+    return fft_pow2<T>(io, nullptr, nullptr, 1, false, s);
+}
+
+// The fused overlap-save launch on a prepared spectrum.  in/out: `batch` contiguous complex
+// vectors of `points`.  Block b reads x[(b*V + in_off + n) mod points] and writes outputs
+// b*V + out_off + m, m < V, below `points`; all blocks (nblocks_limit = 0) or only the first
+// nblocks_limit.  last_block_out (optional): the full L-point time-domain result of block
+// nblocks_limit goes there.
+template <typename T>
+int conv_run_blocks(const T* in, T* out, size_t points, size_t batch, const T* hs, size_t taps,
+                    long long in_off, long long out_off, size_t nblocks_limit, T* last_block_out,
+                    hipStream_t s)
+{
+    constexpr int L = CONV_L;
+    if (taps == 0 || taps - 1 > (size_t)L / 4 || points == 0) {
+        set_last_error("convolve_overlap_save: taps out of range for the block kernel");
+        return BDSP_ERR_UNSUPPORTED;
+    }
+    const cpx<T>* wtab;
+    BDSP_TRY(twiddle_table<T>(L, &wtab));
+    if (points >= (size_t(1) << 31) || batch > 65535) {
+        set_last_error("convolve_overlap_save: vector too long or batch above 65535");
+        return BDSP_ERR_UNSUPPORTED;
+    }
+    const long long V = L - (long long)(taps - 1);
+    long long per_vec = nblocks_limit ? (long long)nblocks_limit : ((long long)points + V - 1) / V;
+    size_t lds = conv_lds_bytes<T>();
+    constexpr bool REGTW = sizeof(T) == 4;
+    auto kern = k_overlap_save<T, REGTW>;
+    if (lds > 64 * 1024)
+        BDSP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    // persistent-ish grid: enough workgroups to fill every CU at the occupancy LDS/VGPRs allow,
+    // each walking blocks with a grid stride so the register-resident twiddles are loaded once
+    int per_cu = 2; // register budget of the current build: 2 workgroups (8 waves) per CU
+    long long want = (long long)num_cus() * per_cu;
+    long long gx = (want + (long long)batch - 1) / (long long)batch;
+    if (gx > per_vec) gx = per_vec;
+    if (gx < 1) gx = 1;
+    if (per_vec > 0) {
+        hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)batch), dim3(256), lds, s,
+                           reinterpret_cast<const cpx<T>*>(in), reinterpret_cast<cpx<T>*>(out),
+                           reinterpret_cast<const cpx<T>*>(hs), wtab, (unsigned)points, (int)taps,
+                           in_off, out_off, (unsigned)per_vec, (unsigned)points, 0);
+        BDSP_LAUNCH_CHECK();
+    }
+    if (last_block_out) {
+        long long b = (long long)nblocks_limit;
+        hipLaunchKernelGGL(kern, dim3(1, 1), dim3(256), lds, s,
+                           reinterpret_cast<const cpx<T>*>(in),
+                           reinterpret_cast<cpx<T>*>(last_block_out),
+                           reinterpret_cast<const cpx<T>*>(hs), wtab, (unsigned)points, (int)taps,
+                           in_off + b * V, 0LL, 1u, (unsigned)L, 1);
+        BDSP_LAUNCH_CHECK();
+    }
+    return BDSP_OK;
+}
+
+template <typename T>
+int convolve_overlap_save(const T* in, T* out, size_t points, size_t batch, const T* taps_dev,
+                          size_t taps, long long in_off, long long out_off, size_t nblocks_limit,
+                          T* last_block_out, const T* h_freq_dev, hipStream_t s)
+{
+    WsBlock hsb;
+    BDSP_TRY(hsb.alloc(sizeof(cpx<T>) * CONV_L, s));
+    BDSP_TRY(conv_prepare_spectrum<T>(taps_dev, taps, h_freq_dev, hsb.as<T>(), s));
+    return conv_run_blocks<T>(in, out, points, batch, hsb.as<T>(), taps, in_off, out_off,
+                              nblocks_limit, last_block_out, s);
+}
+
+template <typename T>
+int convolve_direct(const T* in, T* out, size_t points, size_t batch, const T* taps_dev,
+                    size_t taps, bool is_complex, hipStream_t s)
+{
+    // (h', count, conv_len) as time_freq/mod.rs:284-296
+    size_t start = 0, count = taps;
+    long long conv_len = (long long)(taps - taps / 2);
+    if (taps > points) {
+        size_t center = taps / 2, cl = points / 2;
+        start = center - cl;
+        count = 2 * cl;
+        conv_len = (long long)cl;
+    }
+    long long total = (long long)points * (long long)batch;
+    if (total == 0) return BDSP_OK;
+    unsigned grid = (unsigned)((total + 255) / 256);
+    if (is_complex)
+        hipLaunchKernelGGL((k_conv_direct<T, true>), dim3(grid), dim3(256), 0, s, in, out,
+                           taps_dev + 2 * start, (long long)points, (long long)count, conv_len, total);
+    else
+        hipLaunchKernelGGL((k_conv_direct<T, false>), dim3(grid), dim3(256), 0, s, in, out,
+                           taps_dev + start, (long long)points, (long long)count, conv_len, total);
+    BDSP_LAUNCH_CHECK();
+    return BDSP_OK;
+}
+
+template int convolve_overlap_save<float>(const float*, float*, size_t, size_t, const float*, size_t,
+                                          long long, long long, size_t, float*, const float*, hipStream_t);
+template int convolve_overlap_save<double>(const double*, double*, size_t, size_t, const double*, size_t,
+                                           long long, long long, size_t, double*, const double*, hipStream_t);
+template int conv_prepare_spectrum<float>(const float*, size_t, const float*, float*, hipStream_t);
+template int conv_prepare_spectrum<double>(const double*, size_t, const double*, double*, hipStream_t);
+template int conv_run_blocks<float>(const float*, float*, size_t, size_t, const float*, size_t, long long, long long, size_t, float*, hipStream_t);
+template int conv_run_blocks<double>(const double*, double*, size_t, size_t, const double*, size_t, long long, long long, size_t, double*, hipStream_t);
+template int convolve_direct<float>(const float*, float*, size_t, size_t, const float*, size_t, bool, hipStream_t);
+template int convolve_direct<double>(const double*, double*, size_t, size_t, const double*, size_t, bool, hipStream_t);
+
+} // namespace bdsp
+
+// ---- helpers for the generic (any power-of-two fft_len) GpuSupport::overlap_discard path --------
+namespace bdsp {
+
+// z[b][k] *= h[k] * scale   (multiply_vector of the OpenCL backend, ocl_kernels32.rs:68-78, with
+// the 1/fft_len that clFFT's inverse applied folded in)
+template <typename T>
+__global__ __launch_bounds__(256) void k_mul_bcast(cpx<T>* __restrict__ z, const cpx<T>* __restrict__ h,
+                                                    size_t l, size_t total, T scale)
+{
+    for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < total;
+         g += (size_t)gridDim.x * blockDim.x) {
+        cpx<T> hv = h[g % l];
+        hv.x = hv.x * scale;
+        hv.y = hv.y * scale;
+        z[g] = cmul(z[g], hv);
+    }
+}
+
+// x[b*step + dst_off + m] = z[b][skip + m], m < l - skip, for b < nb
+template <typename T>
+__global__ __launch_bounds__(256) void k_scatter_valid(const cpx<T>* __restrict__ z, cpx<T>* __restrict__ x,
+                                                        size_t l, size_t skip, size_t step, size_t dst_off,
+                                                        size_t nb, size_t x_points)
+{
+    size_t per = l - skip, total = per * nb;
+    for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < total;
+         g += (size_t)gridDim.x * blockDim.x) {
+        size_t b = g / per, m = g % per;
+        size_t o = b * step + dst_off + m;
+        if (o < x_points) x[o] = z[b * l + skip + m];
+    }
+}
+
+template <typename T>
+int mul_bcast(T* z, const T* h, size_t l, size_t nb, T scale, hipStream_t s)
+{
+    size_t total = l * nb;
+    if (total == 0) return BDSP_OK;
+    size_t blocks = (total + 255) / 256, cap = (size_t)num_cus() * 8;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL((k_mul_bcast<T>), dim3((unsigned)blocks), dim3(256), 0, s,
+                       reinterpret_cast<cpx<T>*>(z), reinterpret_cast<const cpx<T>*>(h), l, total, scale);
+    BDSP_LAUNCH_CHECK();
+    return BDSP_OK;
+}
+
+template <typename T>
+int scatter_valid(const T* z, T* x, size_t l, size_t skip, size_t step, size_t dst_off, size_t nb,
+                  size_t x_points, hipStream_t s)
+{
+    size_t total = (l - skip) * nb;
+    if (total == 0) return BDSP_OK;
+    size_t blocks = (total + 255) / 256, cap = (size_t)num_cus() * 8;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL((k_scatter_valid<T>), dim3((unsigned)blocks), dim3(256), 0, s,
+                       reinterpret_cast<const cpx<T>*>(z), reinterpret_cast<cpx<T>*>(x), l, skip, step,
+                       dst_off, nb, x_points);
+    BDSP_LAUNCH_CHECK();
+    return BDSP_OK;
+}
+
+template int mul_bcast<float>(float*, const float*, size_t, size_t, float, hipStream_t);
+template int mul_bcast<double>(double*, const double*, size_t, size_t, double, hipStream_t);
+template int scatter_valid<float>(const float*, float*, size_t, size_t, size_t, size_t, size_t, size_t, hipStream_t);
+template int scatter_valid<double>(const double*, double*, size_t, size_t, size_t, size_t, size_t, size_t, hipStream_t);
+
+} // namespace bdsp

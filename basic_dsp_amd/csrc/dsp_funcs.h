@@ -1,0 +1,74 @@
+// dsp_funcs.h -- device-side window and convolution functions, evaluated in T exactly like the
+// reference evaluates them on the CPU (same formula, same operation order).
+//   windows:        vector/src/window_functions.rs:26-132
+//   conv functions: vector/src/conv_types.rs:391-516
+#pragma once
+#include "fft_core.h"
+
+namespace bdsp {
+
+template <typename T> __device__ __forceinline__ T dev_cos(T x);
+template <> __device__ __forceinline__ float dev_cos<float>(float x) { return cosf(x); }
+template <> __device__ __forceinline__ double dev_cos<double>(double x) { return cos(x); }
+template <typename T> __device__ __forceinline__ T dev_sin(T x);
+template <> __device__ __forceinline__ float dev_sin<float>(float x) { return sinf(x); }
+template <> __device__ __forceinline__ double dev_sin<double>(double x) { return sin(x); }
+template <typename T> __device__ __forceinline__ T dev_abs(T x) { return x < 0 ? -x : x; }
+
+// window ids: 0 triangular, 1 Hamming(alpha), 2 Blackman-Harris, 3 rectangular
+// (interop/src/lib.rs:153-164); callers map the Hann addition (id 4) to (1, alpha = 0.5).
+template <typename T>
+__device__ __forceinline__ T window_value(int id, T alpha, size_t n_, size_t length_)
+{
+    const T one = (T)1, two = (T)2, pi = (T)3.14159265358979323846;
+    T n = (T)n_, length = (T)length_;
+    switch (id) {
+    case 0:
+        return one - dev_abs((n - (length - one) / two) / (length / two));
+    case 1: {
+        T beta = one - alpha;
+        return alpha - beta * dev_cos(two * pi * n / (length - one));
+    }
+    case 2: {
+        const T four = (T)4, six = (T)6;
+        const T a0 = (T)0.35875, a1 = (T)0.48829, a2 = (T)0.14128, a3 = (T)0.01168;
+        return a0 - a1 * dev_cos(two * pi * n / (length - one)) +
+               a2 * dev_cos(four * pi * n / (length - one)) -
+               a3 * dev_cos(six * pi * n / (length - one));
+    }
+    default:
+        return one;
+    }
+}
+
+// Symmetric evaluation (vector_types/mod.rs:567-594): w(j) is computed for the first ceil(P/2)
+// points and reused for the mirrored point P-1-j.
+template <typename T>
+__device__ __forceinline__ T window_value_sym(int id, T alpha, size_t i, size_t points)
+{
+    size_t half = points - points / 2;
+    size_t j = i < half ? i : points - 1 - i;
+    return window_value<T>(id, alpha, j, points);
+}
+
+// conv function ids (interop/src/lib.rs:166-192): 0 sinc, otherwise raised cosine(rolloff)
+template <typename T>
+__device__ __forceinline__ T conv_time_value(int id, T rolloff, T x)
+{
+    const T one = (T)1, two = (T)2, pi = (T)3.14159265358979323846;
+    if (x == (T)0) return one;
+    if (id == 0) {
+        T pi_x = pi * x;
+        return dev_sin(pi_x) / pi_x;
+    }
+    const T four = two * two;
+    if (dev_abs(x) == one / (two * rolloff)) {
+        T arg = pi / two / rolloff;
+        return dev_sin(arg) / arg * pi / four;
+    }
+    T pi_x = pi * x;
+    T arg = two * rolloff * x;
+    return dev_sin(pi_x) * dev_cos(pi_x * rolloff) / pi_x / (one - (arg * arg));
+}
+
+} // namespace bdsp

@@ -1,0 +1,298 @@
+// elementwise.hip -- coalesced 16-byte-per-lane elementwise kernels (real and complex arithmetic,
+// complex->real maps, windows).  Built with -ffp-contract=off: the reference performs each
+// multiply and add as a separately rounded IEEE operation (Rust never contracts to FMA), so these
+// kernels reproduce vector/src/vector_types/general/elementary.rs:283-360, 540-589 and
+// complex/complex_ops.rs:81-116 bit for bit wherever the math library is not involved.
+#include "bdsp_internal.h"
+#include "dsp_funcs.h"
+
+namespace bdsp {
+
+template <typename T> struct Vec16;
+template <> struct Vec16<float> { using type = float4; static constexpr int N = 4; };
+template <> struct Vec16<double> { using type = double2; static constexpr int N = 2; };
+
+static inline unsigned ew_grid(size_t work_items)
+{
+    size_t blocks = (work_items + 255) / 256;
+    size_t cap = (size_t)num_cus() * 8;
+    if (blocks > cap) blocks = cap;
+    if (blocks == 0) blocks = 1;
+    return (unsigned)blocks;
+}
+
+// Generic in-place map over `len` scalars in 16-byte packets.  OP::apply(e, i0, p) sees V
+// consecutive scalars starting at scalar index i0 (i0 is a multiple of V, so complex pairs never
+// straddle packets); the unaligned head/tail of odd-sized buffers goes through OP::apply1/2.
+template <typename T, typename OP>
+__global__ __launch_bounds__(256) void k_map_inplace(T* __restrict__ x, size_t len, typename OP::Params p)
+{
+    using V = typename Vec16<T>::type;
+    constexpr int VN = Vec16<T>::N;
+    const size_t nvec = len / VN;
+    V* xv = reinterpret_cast<V*>(x);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec;
+         i += (size_t)gridDim.x * blockDim.x) {
+        V pk = xv[i];
+        T* e = reinterpret_cast<T*>(&pk);
+        OP::apply(e, VN, i * VN, p);
+        xv[i] = pk;
+    }
+    // tail (fewer than VN scalars; always an even count for complex data)
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        size_t done = nvec * VN;
+        if (done < len) OP::apply(x + done, (int)(len - done), done, p);
+    }
+}
+
+template <typename T, typename OP>
+static int launch_map(T* x, size_t len, typename OP::Params p, hipStream_t s)
+{
+    if (len == 0) return BDSP_OK;
+    if (reinterpret_cast<uintptr_t>(x) % 16 != 0) {
+        set_last_error("elementwise: buffer must be 16-byte aligned");
+        return BDSP_ERR_UNSUPPORTED;
+    }
+    hipLaunchKernelGGL((k_map_inplace<T, OP>), dim3(ew_grid(len / Vec16<T>::N + 1)), dim3(256), 0, s, x, len, p);
+    BDSP_LAUNCH_CHECK();
+    return BDSP_OK;
+}
+
+// ---- ops -------------------------------------------------------------------------------------
+template <typename T> struct OpRealScale {
+    struct Params { T f; };
+    static __device__ __forceinline__ void apply(T* e, int n, size_t, Params p)
+    {
+#pragma unroll 4
+        for (int i = 0; i < n; ++i) e[i] = e[i] * p.f; // elementary.rs:327-342
+    }
+};
+template <typename T> struct OpRealOffset {
+    struct Params { T f; };
+    static __device__ __forceinline__ void apply(T* e, int n, size_t, Params p)
+    {
+#pragma unroll 4
+        for (int i = 0; i < n; ++i) e[i] = e[i] + p.f; // elementary.rs:298-304
+    }
+};
+template <typename T> struct OpComplexOffset {
+    struct Params { T re, im; };
+    static __device__ __forceinline__ void apply(T* e, int n, size_t, Params p)
+    {
+#pragma unroll 2
+        for (int i = 0; i + 1 < n; i += 2) { e[i] = e[i] + p.re; e[i + 1] = e[i + 1] + p.im; }
+    }
+};
+template <typename T> struct OpComplexScale {
+    struct Params { T re, im; };
+    static __device__ __forceinline__ void apply(T* e, int n, size_t, Params p)
+    {
+#pragma unroll 2
+        for (int i = 0; i + 1 < n; i += 2) {
+            T a = e[i], b = e[i + 1];
+            e[i] = a * p.re - b * p.im; // num-complex Mul, elementary.rs:344-360
+            e[i + 1] = a * p.im + b * p.re;
+        }
+    }
+};
+template <typename T> struct OpConj {
+    struct Params { int unused; };
+    static __device__ __forceinline__ void apply(T* e, int n, size_t, Params)
+    {
+#pragma unroll 2
+        for (int i = 1; i < n; i += 2) e[i] = -e[i]; // complex_ops.rs:107-116
+    }
+};
+// multiply_complex_exponential: z[k] *= exp(j*(a*k + b)) with a, b already multiplied by delta
+// (complex_ops.rs:81-105).  The reference advances a running product per element, whose error
+// grows with the index; here every element gets its own phase, reduced in double, so the result
+// is at least as close to the exact value as the reference's (compared with tolerance).
+template <typename T> struct OpMulCexp {
+    struct Params { double a, b; };
+    static __device__ __forceinline__ void apply(T* e, int n, size_t i0, Params p)
+    {
+        for (int i = 0; i + 1 < n; i += 2) {
+            double k = (double)((i0 + i) / 2);
+            double s, c;
+            sincos(p.a * k + p.b, &s, &c);
+            T wr = (T)c, wi = (T)s, zr = e[i], zi = e[i + 1];
+            e[i] = zr * wr - zi * wi;
+            e[i + 1] = zr * wi + zi * wr;
+        }
+    }
+};
+template <typename T> struct OpWindow {
+    struct Params { int id; T alpha; size_t points; int is_complex; int unapply; };
+    static __device__ __forceinline__ void apply(T* e, int n, size_t i0, Params p)
+    {
+        // time.rs:32-66 -> vector_types/mod.rs:526-597
+        if (p.is_complex) {
+            for (int i = 0; i + 1 < n; i += 2) {
+                T w = window_value_sym<T>(p.id, p.alpha, (i0 + i) / 2, p.points);
+                if (p.unapply) w = (T)1 / w;
+                T re = e[i], im = e[i + 1];
+                e[i] = re * w - im * (T)0; // Complex * Complex::new(w, 0)
+                e[i + 1] = re * (T)0 + im * w;
+            }
+        } else {
+            for (int i = 0; i < n; ++i) {
+                T w = window_value_sym<T>(p.id, p.alpha, i0 + i, p.points);
+                if (p.unapply) w = (T)1 / w;
+                e[i] = e[i] * w;
+            }
+        }
+    }
+};
+template <typename T> struct OpFill {
+    struct Params { T v; };
+    static __device__ __forceinline__ void apply(T* e, int n, size_t, Params p)
+    {
+        for (int i = 0; i < n; ++i) e[i] = p.v;
+    }
+};
+
+template <typename T> int ew_real_scale(T* x, size_t len, T f, hipStream_t s)
+{ return launch_map<T, OpRealScale<T>>(x, len, {f}, s); }
+template <typename T> int ew_real_offset(T* x, size_t len, bool is_complex, T f, hipStream_t s)
+{
+    // a real offset on a complex vector adds (f, 0) to every point (elementary.rs:291-297)
+    if (is_complex) return launch_map<T, OpComplexOffset<T>>(x, len, {f, (T)0}, s);
+    return launch_map<T, OpRealOffset<T>>(x, len, {f}, s);
+}
+template <typename T> int ew_complex_scale(T* x, size_t len, T re, T im, hipStream_t s)
+{ return launch_map<T, OpComplexScale<T>>(x, len, {re, im}, s); }
+template <typename T> int ew_complex_offset(T* x, size_t len, T re, T im, hipStream_t s)
+{ return launch_map<T, OpComplexOffset<T>>(x, len, {re, im}, s); }
+template <typename T> int ew_conj(T* x, size_t len, hipStream_t s)
+{ return launch_map<T, OpConj<T>>(x, len, {0}, s); }
+template <typename T> int ew_mul_cexp(T* x, size_t len, T a, T b, hipStream_t s)
+{ return launch_map<T, OpMulCexp<T>>(x, len, {(double)a, (double)b}, s); }
+template <typename T> int ew_window(T* x, size_t len, bool is_complex, int id, T alpha, bool unapply, hipStream_t s)
+{
+    size_t points = is_complex ? len / 2 : len;
+    return launch_map<T, OpWindow<T>>(x, len, {id, alpha, points, (int)is_complex, (int)unapply}, s);
+}
+template <typename T> int ew_fill(T* x, size_t len, T value, hipStream_t s)
+{ return launch_map<T, OpFill<T>>(x, len, {value}, s); }
+
+// ---- binary vector (.) vector, in place on x (elementary.rs:540-589) ------------------------------
+template <typename T, int OP, bool CPLX>
+__global__ __launch_bounds__(256) void k_binary(T* __restrict__ x, const T* __restrict__ y, size_t len)
+{
+    using V = typename Vec16<T>::type;
+    constexpr int VN = Vec16<T>::N;
+    const size_t nvec = len / VN;
+    V* xv = reinterpret_cast<V*>(x);
+    const V* yv = reinterpret_cast<const V*>(y);
+    auto op = [](T* a, const T* b, int n) {
+        if (!CPLX || OP < 2) {
+            for (int i = 0; i < n; ++i) {
+                if (OP == 0) a[i] = a[i] + b[i];
+                else if (OP == 1) a[i] = a[i] - b[i];
+                else if (OP == 2) a[i] = a[i] * b[i];
+                else a[i] = a[i] / b[i];
+            }
+        } else {
+            for (int i = 0; i + 1 < n; i += 2) {
+                T ar = a[i], ai = a[i + 1], br = b[i], bi = b[i + 1];
+                if (OP == 2) {
+                    a[i] = ar * br - ai * bi;
+                    a[i + 1] = ar * bi + ai * br;
+                } else { // num-complex Div
+                    T nn = br * br + bi * bi;
+                    a[i] = (ar * br + ai * bi) / nn;
+                    a[i + 1] = (ai * br - ar * bi) / nn;
+                }
+            }
+        }
+    };
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec;
+         i += (size_t)gridDim.x * blockDim.x) {
+        V pa = xv[i];
+        V pb = yv[i];
+        op(reinterpret_cast<T*>(&pa), reinterpret_cast<const T*>(&pb), VN);
+        xv[i] = pa;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        size_t done = nvec * VN;
+        if (done < len) op(x + done, y + done, (int)(len - done));
+    }
+}
+
+template <typename T> int ew_binary(T* x, const T* y, size_t len, bool is_complex, int op, hipStream_t s)
+{
+    if (len == 0) return BDSP_OK;
+    dim3 grid(ew_grid(len / Vec16<T>::N + 1)), block(256);
+#define BDSP_BIN(OPV)                                                                              \
+    do {                                                                                           \
+        if (is_complex) hipLaunchKernelGGL((k_binary<T, OPV, true>), grid, block, 0, s, x, y, len); \
+        else hipLaunchKernelGGL((k_binary<T, OPV, false>), grid, block, 0, s, x, y, len);           \
+    } while (0)
+    switch (op) {
+    case 0: BDSP_BIN(0); break;
+    case 1: BDSP_BIN(1); break;
+    case 2: BDSP_BIN(2); break;
+    default: BDSP_BIN(3); break;
+    }
+#undef BDSP_BIN
+    BDSP_LAUNCH_CHECK();
+    return BDSP_OK;
+}
+
+// ---- complex -> real (complex_to_real.rs:374-478); out may alias x (in-place compaction) -----------
+template <typename T> __device__ __forceinline__ T dev_hypot2(T a, T b);
+template <> __device__ __forceinline__ float dev_hypot2<float>(float a, float b) { return hypotf(a, b); }
+template <> __device__ __forceinline__ double dev_hypot2<double>(double a, double b) { return hypot(a, b); }
+template <typename T> __device__ __forceinline__ T dev_atan2(T a, T b);
+template <> __device__ __forceinline__ float dev_atan2<float>(float a, float b) { return atan2f(a, b); }
+template <> __device__ __forceinline__ double dev_atan2<double>(double a, double b) { return atan2(a, b); }
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_complex_to_real(const cpx<T>* __restrict__ x, T* __restrict__ out,
+                                                          size_t points, int kind)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < points;
+         i += (size_t)gridDim.x * blockDim.x) {
+        cpx<T> z = x[i];
+        T r;
+        switch (kind) {
+        case 0: r = dev_hypot2<T>(z.x, z.y); break;
+        case 1: r = z.x * z.x + z.y * z.y; break;
+        case 2: r = z.x; break;
+        case 3: r = z.y; break;
+        default: r = dev_atan2<T>(z.y, z.x); break;
+        }
+        out[i] = r;
+    }
+}
+
+template <typename T> int ew_complex_to_real(const T* x, T* out, size_t len, int kind, hipStream_t s)
+{
+    size_t points = len / 2;
+    if (points == 0) return BDSP_OK;
+    if (static_cast<const void*>(x) == static_cast<const void*>(out)) {
+        set_last_error("complex_to_real: in-place compaction is not race free on a GPU; pass the trade buffer");
+        return BDSP_ERR_UNSUPPORTED;
+    }
+    hipLaunchKernelGGL((k_complex_to_real<T>), dim3(ew_grid(points)), dim3(256), 0, s,
+                       reinterpret_cast<const cpx<T>*>(x), out, points, kind);
+    BDSP_LAUNCH_CHECK();
+    return BDSP_OK;
+}
+
+#define BDSP_INST(T)                                                                               \
+    template int ew_real_scale<T>(T*, size_t, T, hipStream_t);                                     \
+    template int ew_real_offset<T>(T*, size_t, bool, T, hipStream_t);                              \
+    template int ew_complex_scale<T>(T*, size_t, T, T, hipStream_t);                               \
+    template int ew_complex_offset<T>(T*, size_t, T, T, hipStream_t);                              \
+    template int ew_binary<T>(T*, const T*, size_t, bool, int, hipStream_t);                       \
+    template int ew_conj<T>(T*, size_t, hipStream_t);                                              \
+    template int ew_mul_cexp<T>(T*, size_t, T, T, hipStream_t);                                    \
+    template int ew_complex_to_real<T>(const T*, T*, size_t, int, hipStream_t);                    \
+    template int ew_window<T>(T*, size_t, bool, int, T, bool, hipStream_t);                        \
+    template int ew_fill<T>(T*, size_t, T, hipStream_t);
+BDSP_INST(float)
+BDSP_INST(double)
+#undef BDSP_INST
+
+} // namespace bdsp

@@ -1,0 +1,3 @@
+// f32 instantiation of the FFT kernels (split from f64 so the two compile in parallel)
+#define BDSP_FFT_T float
+#include "fft_impl.h"

@@ -1,0 +1,258 @@
+"""Host-side mirror of the reference's generic vector (GenDspVec<Vec<T>, T>) for the hot path.
+
+`DspVec` wraps a device-resident handle of libbasic_dsp_hip.so and exposes the reference's method
+names and argument meaning (vector crate traits ScaleOps/OffsetOps/ElementaryOps/ComplexOps/
+TimeToFrequencyDomainOperations/FrequencyToTimeDomainOperations/ConvolutionOps/InterpolationOps,
+SURVEY.md section 8a).  Error behaviour follows the C facade (interop/src/lib.rs:28-76): a method
+returns the facade's result code -- 0 ok, -1 vector poisoned, 1..14 = ErrorReason -- and raises
+BackendError only when the HIP backend itself fails.  Nothing is computed on the host.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import lib
+
+TIME, FREQ = 0, 1
+WINDOW_TRIANGULAR, WINDOW_HAMMING, WINDOW_BLACKMAN_HARRIS, WINDOW_RECTANGULAR, WINDOW_HANN = 0, 1, 2, 3, 4
+CONV_SINC, CONV_RAISED_COSINE = 0, 1
+PAD_END, PAD_SURROUND, PAD_CENTER = 0, 1, 2
+
+
+class DspVec:
+    """A real or complex, time- or frequency-domain vector living in HBM."""
+
+    def __init__(self, data=None, is_complex=False, domain=TIME, delta=1.0, dtype=np.float32,
+                 length=None, init=0.0, _handle=None, _sfx=None):
+        if _handle is not None:
+            self._h, self._sfx = _handle, _sfx
+            self.dtype = np.float32 if _sfx == "32" else np.float64
+            return
+        _lib.require_gpu()
+        if data is not None:
+            data = np.ascontiguousarray(data)
+            if data.dtype in (np.complex64, np.complex128):
+                is_complex = True
+                data = data.view(np.float32 if data.dtype == np.complex64 else np.float64)
+            dtype = data.dtype
+            length = data.size
+        self.dtype = np.dtype(dtype).type
+        self._sfx = "32" if self.dtype == np.float32 else "64"
+        h = self._fn("new")(int(bool(is_complex)), int(domain), init, int(length), delta)
+        if not h:
+            raise _lib.BackendError("new%s failed: %s" % (self._sfx, _lib.last_error()))
+        self._h = h
+        if data is not None and length:
+            self._call("overwrite_data", data.ctypes.data_as(C.c_void_p), int(length))
+
+    # ------------------------------------------------------------------ plumbing
+    def _fn(self, name):
+        return getattr(lib, name + self._sfx)
+
+    def _call(self, name, *args):
+        res = self._fn(name)(self._h, *args)
+        self._h = res.vector  # ownership moved in and comes back (facade convention)
+        return _lib.check(res.result_code, name + self._sfx)
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            try:
+                self._fn("delete_vector")(h)
+            except Exception:  # interpreter shutdown
+                pass
+            self._h = None
+
+    def clone(self):
+        h = self._fn("bdsp_hip_vec_clone")(self._h)
+        if not h:
+            raise _lib.BackendError("clone failed: %s" % _lib.last_error())
+        return DspVec(_handle=h, _sfx=self._sfx)
+
+    # ------------------------------------------------------------------ metadata
+    def __len__(self):
+        return self._fn("get_len")(self._h)
+
+    def len(self):
+        return len(self)
+
+    def points(self):
+        return self._fn("get_points")(self._h)
+
+    def delta(self):
+        return self._fn("get_delta")(self._h)
+
+    def is_complex(self):
+        return bool(self._fn("is_complex")(self._h))
+
+    def domain(self):
+        return self._fn("get_domain")(self._h)
+
+    def is_erroneous(self):
+        return len(self) == 0 and np.isnan(self.delta())
+
+    def device_ptr(self):
+        return self._fn("bdsp_hip_vec_device_ptr")(self._h)
+
+    def data(self):
+        """Download the valid part as a numpy array of scalars (interleaved if complex)."""
+        n = len(self)
+        p = self._fn("data")(self._h)
+        if not p:
+            raise _lib.BackendError("data%s failed: %s" % (self._sfx, _lib.last_error()))
+        ct = C.c_float if self._sfx == "32" else C.c_double
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(ct)), shape=(max(n, 1),))[:n].copy()
+
+    def datac(self):
+        d = self.data()
+        return d.view(np.complex64 if self._sfx == "32" else np.complex128)
+
+    def overwrite_data(self, data):
+        data = np.ascontiguousarray(data, dtype=self.dtype)
+        return self._call("overwrite_data", data.ctypes.data_as(C.c_void_p), data.size)
+
+    # ------------------------------------------------------------------ elementwise (a2, a15, a16)
+    def scale(self, factor):
+        if isinstance(factor, complex):
+            return self._call("complex_scale", factor.real, factor.imag)
+        return self._call("real_scale", factor)
+
+    def offset(self, value):
+        if isinstance(value, complex):
+            return self._call("complex_offset", value.real, value.imag)
+        return self._call("real_offset", value)
+
+    def add(self, other):
+        return self._call("add", other._h)
+
+    def sub(self, other):
+        return self._call("sub", other._h)
+
+    def mul(self, other):
+        return self._call("mul", other._h)
+
+    def div(self, other):
+        return self._call("div", other._h)
+
+    def conj(self):
+        return self._call("conj")
+
+    def multiply_complex_exponential(self, a, b):
+        return self._call("multiply_complex_exponential", a, b)
+
+    # ------------------------------------------------------------------ complex -> real (a8)
+    def magnitude(self):
+        return self._call("magnitude")
+
+    def magnitude_squared(self):
+        return self._call("magnitude_squared")
+
+    def to_real(self):
+        return self._call("to_real")
+
+    def to_imag(self):
+        return self._call("to_imag")
+
+    def phase(self):
+        return self._call("phase")
+
+    def to_complex(self):
+        return self._call("to_complex")
+
+    # ------------------------------------------------------------------ reorganisation (a6, a17)
+    def reverse(self):
+        return self._call("reverse")
+
+    def swap_halves(self):
+        return self._call("swap_halves")
+
+    def fft_shift(self):
+        return self._call("fft_shift")
+
+    def ifft_shift(self):
+        return self._call("ifft_shift")
+
+    def mirror(self):
+        return self._call("mirror")
+
+    def zero_pad(self, points, option=PAD_END):
+        return self._call("zero_pad", int(points), int(option))
+
+    def zero_interleave(self, factor):
+        return self._call("zero_interleave", int(factor))
+
+    # ------------------------------------------------------------------ windows (a7)
+    def apply_window(self, window):
+        return self._call("apply_window", int(window))
+
+    def unapply_window(self, window):
+        return self._call("unapply_window", int(window))
+
+    # ------------------------------------------------------------------ transforms (a3-a5)
+    def plain_fft(self):
+        return self._call("plain_fft")
+
+    def plain_ifft(self):
+        return self._call("plain_ifft")
+
+    def fft(self):
+        return self._call("fft")
+
+    def ifft(self):
+        return self._call("ifft")
+
+    def windowed_fft(self, window):
+        return self._call("windowed_fft", int(window))
+
+    def windowed_ifft(self, window):
+        return self._call("windowed_ifft", int(window))
+
+    # ------------------------------------------------------------------ convolution / interpolation
+    def convolve_signal(self, impulse_response):
+        return self._call("convolve_signal", impulse_response._h)
+
+    def interpolatef(self, function, interpolation_factor, delay, conv_len, rolloff=0.0):
+        return self._call("interpolatef", int(function), rolloff, interpolation_factor, delay,
+                          int(conv_len))
+
+
+# ---------------------------------------------------------------------- B1 helpers (host slices)
+def _sfx_of(a):
+    return "f32" if a.dtype == np.float32 else "f64"
+
+
+def gpu_fft(signal, inverse=False):
+    """GpuSupport::fft on a host slice (vector/src/gpu_support/mod.rs:35): in place, returns it."""
+    signal = np.ascontiguousarray(signal)
+    fn = getattr(lib, "bdsp_hip_fft_" + _sfx_of(signal))
+    _lib.check(fn(1, signal.ctypes.data_as(C.c_void_p), signal.size, int(inverse)), "fft")
+    return signal
+
+
+def gpu_convolve_vector(source, imp_resp, is_complex=True):
+    """GpuSupport::gpu_convolve_vector (mod.rs:24-29): returns (target, range) or (None, None)."""
+    source = np.ascontiguousarray(source)
+    imp = np.ascontiguousarray(imp_resp, dtype=source.dtype)
+    target = np.zeros_like(source)
+    rs, re = C.c_size_t(0), C.c_size_t(0)
+    fn = getattr(lib, "bdsp_hip_convolve_vector_" + _sfx_of(source))
+    code = fn(int(is_complex), source.ctypes.data_as(C.c_void_p), source.size,
+              target.ctypes.data_as(C.c_void_p), target.size, imp.ctypes.data_as(C.c_void_p),
+              imp.size, C.byref(rs), C.byref(re))
+    _lib.check(code, "gpu_convolve_vector")
+    if code == 0:
+        return None, None
+    return target, (rs.value, re.value)
+
+
+def gpu_overlap_discard(x_time, tmp, h_freq, imp_len, step_size):
+    """GpuSupport::overlap_discard (mod.rs:38-45); x_time and tmp are modified in place."""
+    fn = getattr(lib, "bdsp_hip_overlap_discard_" + _sfx_of(x_time))
+    x_freq = np.zeros_like(h_freq)
+    pos = fn(x_time.ctypes.data_as(C.c_void_p), x_time.size, tmp.ctypes.data_as(C.c_void_p),
+             tmp.size, x_freq.ctypes.data_as(C.c_void_p), x_freq.size,
+             h_freq.ctypes.data_as(C.c_void_p), h_freq.size, int(imp_len), int(step_size))
+    if pos == 0:
+        raise _lib.BackendError("overlap_discard failed: %s" % _lib.last_error())
+    return pos

@@ -1,0 +1,315 @@
+/*
+ * basic_dsp_hip.h -- C ABI of libbasic_dsp_hip.so, the MI355X (gfx950) backend for basic_dsp's
+ * time/frequency-domain vector operations.
+ *
+ * Three layers, all plain C (pointers + sizes, no C++/torch types):
+ *
+ *   B1  bdsp_hip_*_f32/_f64       the five functions of the reference's GPU plug-in trait
+ *                                 `GpuSupport<T>` (vector/src/gpu_support/mod.rs:18-46); HOST
+ *                                 pointers, synchronous, thread-safe.  This is what a Rust shim
+ *                                 `impl GpuSupport<T> for T` binds.
+ *   B2  new32, plain_fft32, ...   the subset of the reference's C facade
+ *                                 (interop/src/facade32.rs, facade64.rs) that covers the hot path,
+ *                                 with IDENTICAL names, argument order and result codes, but the
+ *                                 vector lives in HBM.  Handles are opaque.
+ *   B3  bdsp_hip_dev_*            the same kernels on caller-owned DEVICE pointers and a caller
+ *                                 stream (used by bench.py and the multi-GPU batch driver, which
+ *                                 hold memory in torch tensors and communicate through RCCL).
+ *
+ * All citations are relative to the reference tree (liebharc/basic_dsp v0.10.0).
+ * Conventions: complex data is interleaved [re0, im0, re1, im1, ...];
+ * every `len` counts SCALARS; `points` = len/2 for complex vectors.
+ */
+#ifndef BASIC_DSP_HIP_H
+#define BASIC_DSP_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------------------------------
+ * Result codes.  0 = ok; 1..14 = the reference's ErrorReason numbering
+ * (interop/src/lib.rs:125-142, translate_error); -1 = vector is poisoned
+ * (interop/src/lib.rs:145-151); <= -100 = backend failure (no reference counterpart: the OpenCL
+ * backend panics instead, vector/src/gpu_support/ocl/mod.rs:167,188,208).
+ * ---------------------------------------------------------------------------------------- */
+#define BDSP_OK 0
+#define BDSP_ERR_SAME_SIZE 1             /* InputMustHaveTheSameSize */
+#define BDSP_ERR_META_DATA 2             /* InputMetaDataMustAgree */
+#define BDSP_ERR_MUST_BE_COMPLEX 3       /* InputMustBeComplex */
+#define BDSP_ERR_MUST_BE_REAL 4          /* InputMustBeReal */
+#define BDSP_ERR_MUST_BE_TIME 5          /* InputMustBeInTimeDomain */
+#define BDSP_ERR_MUST_BE_FREQ 6          /* InputMustBeInFrequencyDomain */
+#define BDSP_ERR_ARG_LENGTH 7            /* InvalidArgumentLength */
+#define BDSP_ERR_CONJ_SYMMETRIC 8        /* InputMustBeConjSymmetric */
+#define BDSP_ERR_ODD_LENGTH 9            /* InputMustHaveAnOddLength */
+#define BDSP_ERR_FN_SYMMETRIC 10         /* ArgumentFunctionMustBeSymmetric */
+#define BDSP_ERR_COMBINED_ARGS 11        /* InvalidNumberOfArgumentsForCombinedOp */
+#define BDSP_ERR_NOT_EMPTY 12            /* InputMustNotBeEmpty */
+#define BDSP_ERR_EVEN_LENGTH 13          /* InputMustHaveAnEvenLength */
+#define BDSP_ERR_CANNOT_RESIZE 14        /* TypeCanNotResize */
+#define BDSP_ERR_POISONED (-1)
+#define BDSP_ERR_NO_DEVICE (-100)        /* no usable gfx950 device / HIP runtime failure */
+#define BDSP_ERR_HIP (-101)              /* a HIP call failed; see bdsp_hip_last_error() */
+#define BDSP_ERR_UNSUPPORTED (-102)      /* argument combination this backend does not implement */
+
+/* Human-readable text of the last backend failure on the calling thread ("" if none). */
+const char *bdsp_hip_last_error(void);
+/* Library version string, e.g. "basic_dsp_hip 0.1.0 (gfx950)". */
+const char *bdsp_hip_version(void);
+
+/* ==========================================================================================
+ * B1 -- GpuSupport<T> (vector/src/gpu_support/mod.rs:18-46).  HOST pointers.
+ * ======================================================================================== */
+
+/* fn has_gpu_support() -> bool            (gpu_support/mod.rs:21)
+ * 1 if a gfx950 device is usable (for _f64: always the same answer, MI355X has native fp64). */
+int bdsp_hip_has_gpu_support_f32(void);
+int bdsp_hip_has_gpu_support_f64(void);
+
+/* fn is_supported_fft_len(is_complex, len) -> bool      (gpu_support/mod.rs:32)
+ * `len` in scalars.  Like the OpenCL backend (ocl/mod.rs:277-299) real input is refused; unlike
+ * it, EVERY complex length >= 2 points is supported (powers of two natively, all other lengths
+ * through Bluestein on the same kernels), matching what rustfft accepts on the CPU path. */
+int bdsp_hip_is_supported_fft_len_f32(int is_complex, size_t len);
+int bdsp_hip_is_supported_fft_len_f64(int is_complex, size_t len);
+
+/* fn fft(is_complex, signal: &mut [T], direction)       (gpu_support/mod.rs:35)
+ * In place on `len` scalars (= len/2 complex points), UNNORMALISED in both directions
+ * (time_freq/mod.rs:47-58 contract).  inverse = 0 forward, 1 inverse.  Returns BDSP_OK or a
+ * negative backend code (the Rust shim panics on != 0, as the OpenCL impl does). */
+int bdsp_hip_fft_f32(int is_complex, float *signal, size_t len, int inverse);
+int bdsp_hip_fft_f64(int is_complex, double *signal, size_t len, int inverse);
+
+/* fn gpu_convolve_vector(is_complex, source, target, imp_resp) -> Option<Range<usize>>
+ *                                                        (gpu_support/mod.rs:24-29)
+ * Computes the reference's centred circular convolution (time_freq/mod.rs:455-473)
+ *     y[i] = sum_k x[(i + ceil(M/2) - 1 - k) mod N] * h[k]
+ * for EVERY output including the wrap-around head and tail (the OpenCL backend leaves those to
+ * the CPU and never fills the tail, convolution.rs:509-527).  Returns 1 and sets
+ * [*range_start, *range_end) = [0, src_len) for Some(range); returns 0 for None (declined:
+ * empty input or taps longer than the signal); negative on backend failure. */
+int bdsp_hip_convolve_vector_f32(int is_complex, const float *src, size_t src_len, float *dst,
+                                 size_t dst_len, const float *imp, size_t imp_len,
+                                 size_t *range_start, size_t *range_end);
+int bdsp_hip_convolve_vector_f64(int is_complex, const double *src, size_t src_len, double *dst,
+                                 size_t dst_len, const double *imp, size_t imp_len,
+                                 size_t *range_start, size_t *range_end);
+
+/* fn overlap_discard(x_time, tmp, x_freq, h_freq, imp_len, step_size) -> usize
+ *                                                        (gpu_support/mod.rs:38-45)
+ * All lengths in scalars (factor 2 against the caller's complex view, convolution.rs:401-412).
+ * fft_len = h_len.  Blocks start at scalar position 0 and advance by step_size while
+ * pos + fft_len < x_len; each block's valid part tmp[imp_len-2 .. fft_len] lands at
+ * x_time[pos + imp_len/2 ..]; the LAST block's full time-domain result is left in `tmp` and the
+ * final position is returned (ocl/mod.rs:426-520).  tmp[0 .. imp_len/2] (the caller's scalar
+ * head, convolution.rs:376-385) is copied to x_time[0 .. imp_len/2] first, as the OpenCL impl
+ * does.  The 1/fft_len scaling is applied here (h_freq arrives unscaled).  x_freq is scratch the
+ * reference passes along; it is not touched.  Returns 0 on backend failure (see last_error). */
+size_t bdsp_hip_overlap_discard_f32(float *x_time, size_t x_len, float *tmp, size_t tmp_len,
+                                    float *x_freq, size_t x_freq_len, const float *h_freq,
+                                    size_t h_len, size_t imp_len, size_t step_size);
+size_t bdsp_hip_overlap_discard_f64(double *x_time, size_t x_len, double *tmp, size_t tmp_len,
+                                    double *x_freq, size_t x_freq_len, const double *h_freq,
+                                    size_t h_len, size_t imp_len, size_t step_size);
+
+/* ==========================================================================================
+ * B2 -- device-resident vectors behind the reference's C facade names
+ *       (interop/src/facade32.rs; facade64.rs is generated from it by facade64_create.pl).
+ * Ownership follows the facade: operations take the handle BY VALUE (it moves in) and hand it
+ * back inside the result struct; borrowed operands are const pointers.
+ * ======================================================================================== */
+typedef struct VecBuf32 VecBuf32; /* InteropVec<f32>, interop/src/lib.rs:16-22 */
+typedef struct VecBuf64 VecBuf64;
+
+/* #[repr(C)] VectorInteropResult<T> { result_code: i32, vector: Box<T> }  (lib.rs:203-212) */
+typedef struct { int32_t result_code; VecBuf32 *vector; } VectorInteropResult32;
+typedef struct { int32_t result_code; VecBuf64 *vector; } VectorInteropResult64;
+
+/* domain: 0 = time, otherwise frequency (facade32.rs:24-28).  Window ids (lib.rs:153-164):
+ * 0 triangular, 1 Hamming(0.54), 2 Blackman-Harris, 3 rectangular; 4 = Hann (generalised
+ * Hamming alpha 0.5) is an ADDITION so windowed_fft(Hann) needs no host callback.
+ * Conv function ids (lib.rs:166-192): 0 sinc, otherwise raised cosine(rolloff).
+ * Padding option ids (lib.rs:194-200): 0 End, 1 Surround, otherwise Center. */
+
+VecBuf32 *new32(int32_t is_complex, int32_t domain, float init_value, size_t length,
+                float delta);                                  /* facade32.rs:22-41 */
+VecBuf32 *new_with_performance_options32(int32_t is_complex, int32_t domain, float init_value,
+                                         size_t length, float delta, size_t core_limit,
+                                         int early_temp_allocation); /* :43-70 (options ignored) */
+void delete_vector32(VecBuf32 *vector);                        /* facade32.rs:17-19 */
+VecBuf32 *clone32(VecBuf32 *vector); /* facade32.rs:687-692; consumes its argument like the reference (Box by value) */
+VecBuf32 *bdsp_hip_vec_clone32(const VecBuf32 *vector); /* non-consuming copy (addition) */
+float get_value32(const VecBuf32 *vector, size_t index);     /* facade32.rs:105-107 (one-element download) */
+size_t get_len32(const VecBuf32 *vector);                      /* facade32.rs:138-140 */
+size_t get_points32(const VecBuf32 *vector);                   /* facade32.rs:148-150 */
+float get_delta32(const VecBuf32 *vector);                     /* facade32.rs:153-155 */
+int32_t is_complex32(const VecBuf32 *vector);                  /* facade32.rs:115-121 */
+int32_t get_domain32(const VecBuf32 *vector);                  /* facade32.rs:130-135 */
+/* data32 (facade32.rs:158-160) returns a pointer into host memory in the reference.  Here the
+ * data lives in HBM: data32 downloads into a host mirror owned by the handle (valid until the
+ * next call on that handle) and returns it. */
+const float *data32(VecBuf32 *vector);
+/* overwrite_data32 (facade32.rs:827-846): uploads `len` scalars into the front of the vector.
+ * The reference rejects len >= vector.len() (strict `<`, :834); we accept len <= vector.len()
+ * and return code 7 (InvalidArgumentLength) beyond that. */
+VectorInteropResult32 overwrite_data32(VecBuf32 *vector, const float *data, size_t len);
+void set_len32(VecBuf32 *vector, size_t len);               /* facade32.rs:143-145 */
+
+VectorInteropResult32 real_offset32(VecBuf32 *vector, float value);          /* facade32.rs:363-365 */
+VectorInteropResult32 real_scale32(VecBuf32 *vector, float value);           /* facade32.rs:368-370 */
+VectorInteropResult32 complex_offset32(VecBuf32 *vector, float re, float im);/* facade32.rs:532-538 */
+VectorInteropResult32 complex_scale32(VecBuf32 *vector, float re, float im); /* facade32.rs:541-547 */
+VectorInteropResult32 add32(VecBuf32 *vector, const VecBuf32 *operand);      /* facade32.rs:173-175 */
+VectorInteropResult32 sub32(VecBuf32 *vector, const VecBuf32 *operand);      /* facade32.rs:178-180 */
+VectorInteropResult32 mul32(VecBuf32 *vector, const VecBuf32 *operand);      /* facade32.rs:188-190 */
+VectorInteropResult32 div32(VecBuf32 *vector, const VecBuf32 *operand);      /* facade32.rs:183-185 */
+VectorInteropResult32 conj32(VecBuf32 *vector);                              /* facade32.rs:579-581 */
+VectorInteropResult32 multiply_complex_exponential32(VecBuf32 *vector, float a, float b); /* facade32.rs:695-701 */
+VectorInteropResult32 magnitude32(VecBuf32 *vector);                         /* facade32.rs:559-561 */
+VectorInteropResult32 magnitude_squared32(VecBuf32 *vector);                 /* facade32.rs:574-576 */
+VectorInteropResult32 to_real32(VecBuf32 *vector);                           /* facade32.rs:584-586 */
+VectorInteropResult32 to_imag32(VecBuf32 *vector);                           /* facade32.rs:589-591 */
+VectorInteropResult32 phase32(VecBuf32 *vector);                             /* facade32.rs:662-664 */
+VectorInteropResult32 to_complex32(VecBuf32 *vector);                        /* facade32.rs:418-420 */
+VectorInteropResult32 reverse32(VecBuf32 *vector);                           /* facade32.rs:1142-1144 */
+VectorInteropResult32 swap_halves32(VecBuf32 *vector);                       /* facade32.rs:527-529 */
+VectorInteropResult32 zero_pad32(VecBuf32 *vector, size_t points, int32_t padding_option); /* facade32.rs:330-338 */
+VectorInteropResult32 zero_interleave32(VecBuf32 *vector, int32_t factor);   /* facade32.rs:340-345 */
+VectorInteropResult32 fft_shift32(VecBuf32 *vector);                         /* facade32.rs:963-965 */
+VectorInteropResult32 ifft_shift32(VecBuf32 *vector);                        /* facade32.rs:967-969 */
+VectorInteropResult32 mirror32(VecBuf32 *vector);                            /* facade32.rs:959-961 */
+VectorInteropResult32 apply_window32(VecBuf32 *vector, int32_t window);      /* facade32.rs:980-983 */
+VectorInteropResult32 unapply_window32(VecBuf32 *vector, int32_t window);    /* facade32.rs:987-994 */
+VectorInteropResult32 plain_fft32(VecBuf32 *vector);                         /* facade32.rs:672-674 */
+VectorInteropResult32 plain_ifft32(VecBuf32 *vector);                        /* facade32.rs:682-684 */
+VectorInteropResult32 fft32(VecBuf32 *vector);                               /* facade32.rs:934-936 */
+VectorInteropResult32 ifft32(VecBuf32 *vector);                              /* facade32.rs:944-946 */
+VectorInteropResult32 windowed_fft32(VecBuf32 *vector, int32_t window);      /* facade32.rs:997-1000 */
+VectorInteropResult32 windowed_ifft32(VecBuf32 *vector, int32_t window);     /* facade32.rs:1011-1014 */
+VectorInteropResult32 convolve_signal32(VecBuf32 *vector, const VecBuf32 *impulse_response); /* facade32.rs:1171-1176 */
+VectorInteropResult32 interpolatef32(VecBuf32 *vector, int32_t impulse_response, float rolloff,
+                                     float interpolation_factor, float delay, size_t conv_len); /* :1334-1348 */
+
+VecBuf64 *new64(int32_t is_complex, int32_t domain, double init_value, size_t length, double delta);
+VecBuf64 *new_with_performance_options64(int32_t is_complex, int32_t domain, double init_value,
+                                         size_t length, double delta, size_t core_limit,
+                                         int early_temp_allocation);
+void delete_vector64(VecBuf64 *vector);
+VecBuf64 *clone64(VecBuf64 *vector);
+VecBuf64 *bdsp_hip_vec_clone64(const VecBuf64 *vector);
+double get_value64(const VecBuf64 *vector, size_t index);
+size_t get_len64(const VecBuf64 *vector);
+size_t get_points64(const VecBuf64 *vector);
+double get_delta64(const VecBuf64 *vector);
+int32_t is_complex64(const VecBuf64 *vector);
+int32_t get_domain64(const VecBuf64 *vector);
+const double *data64(VecBuf64 *vector);
+VectorInteropResult64 overwrite_data64(VecBuf64 *vector, const double *data, size_t len);
+void set_len64(VecBuf64 *vector, size_t len);
+VectorInteropResult64 real_offset64(VecBuf64 *vector, double value);
+VectorInteropResult64 real_scale64(VecBuf64 *vector, double value);
+VectorInteropResult64 complex_offset64(VecBuf64 *vector, double re, double im);
+VectorInteropResult64 complex_scale64(VecBuf64 *vector, double re, double im);
+VectorInteropResult64 add64(VecBuf64 *vector, const VecBuf64 *operand);
+VectorInteropResult64 sub64(VecBuf64 *vector, const VecBuf64 *operand);
+VectorInteropResult64 mul64(VecBuf64 *vector, const VecBuf64 *operand);
+VectorInteropResult64 div64(VecBuf64 *vector, const VecBuf64 *operand);
+VectorInteropResult64 conj64(VecBuf64 *vector);
+VectorInteropResult64 multiply_complex_exponential64(VecBuf64 *vector, double a, double b);
+VectorInteropResult64 magnitude64(VecBuf64 *vector);
+VectorInteropResult64 magnitude_squared64(VecBuf64 *vector);
+VectorInteropResult64 to_real64(VecBuf64 *vector);
+VectorInteropResult64 to_imag64(VecBuf64 *vector);
+VectorInteropResult64 phase64(VecBuf64 *vector);
+VectorInteropResult64 to_complex64(VecBuf64 *vector);
+VectorInteropResult64 reverse64(VecBuf64 *vector);
+VectorInteropResult64 swap_halves64(VecBuf64 *vector);
+VectorInteropResult64 zero_pad64(VecBuf64 *vector, size_t points, int32_t padding_option);
+VectorInteropResult64 zero_interleave64(VecBuf64 *vector, int32_t factor);
+VectorInteropResult64 fft_shift64(VecBuf64 *vector);
+VectorInteropResult64 ifft_shift64(VecBuf64 *vector);
+VectorInteropResult64 mirror64(VecBuf64 *vector);
+VectorInteropResult64 apply_window64(VecBuf64 *vector, int32_t window);
+VectorInteropResult64 unapply_window64(VecBuf64 *vector, int32_t window);
+VectorInteropResult64 plain_fft64(VecBuf64 *vector);
+VectorInteropResult64 plain_ifft64(VecBuf64 *vector);
+VectorInteropResult64 fft64(VecBuf64 *vector);
+VectorInteropResult64 ifft64(VecBuf64 *vector);
+VectorInteropResult64 windowed_fft64(VecBuf64 *vector, int32_t window);
+VectorInteropResult64 windowed_ifft64(VecBuf64 *vector, int32_t window);
+VectorInteropResult64 convolve_signal64(VecBuf64 *vector, const VecBuf64 *impulse_response);
+VectorInteropResult64 interpolatef64(VecBuf64 *vector, int32_t impulse_response, double rolloff,
+                                     double interpolation_factor, double delay, size_t conv_len);
+
+/* Device pointer of the handle's live buffer (valid until the next mutating call); lets the
+ * batch driver feed RCCL without a host round trip.  No reference counterpart. */
+void *bdsp_hip_vec_device_ptr32(VecBuf32 *vector);
+void *bdsp_hip_vec_device_ptr64(VecBuf64 *vector);
+
+/* ==========================================================================================
+ * B3 -- kernels on caller-owned DEVICE memory.  `stream` is a hipStream_t passed as void*
+ * (NULL = the library's own stream).  Calls are asynchronous on that stream unless noted.
+ * `elem` = 0 for f32, 1 for f64.  Scratch: ops that are not in place ping-pong between `data`
+ * and `scratch` (same size); they return in *result_in_scratch whether the result ended in
+ * `scratch` (1) or `data` (0), mirroring the reference's Buffer::trade (support_std.rs:78-82).
+ * ======================================================================================== */
+
+/* Unnormalised complex FFT of `batch` contiguous vectors of `points` complex each.
+ * flags: BDSP_FFT_* bits. */
+#define BDSP_FFT_INVERSE 1u      /* exp(+...) instead of exp(-...) */
+#define BDSP_FFT_SHIFT_OUT 2u    /* fused fft_shift of the result (time_to_freq.rs:158-165) */
+#define BDSP_FFT_SHIFT_IN 4u     /* fused ifft_shift of the input (freq_to_time.rs:160-168) */
+#define BDSP_FFT_MAGNITUDE 8u    /* write |X| as `points` reals instead of complex (config C2) */
+int bdsp_hip_dev_fft(int elem, void *data, void *scratch, size_t points, size_t batch,
+                     unsigned flags, double in_scale, int window_id, double window_alpha,
+                     int *result_in_scratch, void *stream);
+
+/* Centred circular convolution (reference a9) of `batch` contiguous complex vectors of `points`
+ * points with ONE shared filter of `taps` complex taps (device pointer), by fused overlap-save.
+ * out must not alias in.  */
+int bdsp_hip_dev_convolve(int elem, const void *in, void *out, size_t points, size_t batch,
+                          const void *taps_dev, size_t taps, void *stream);
+
+/* The same convolution split in two, so a caller that reuses one filter (the batch driver, the
+ * benchmark) builds its spectrum once: prepare writes bdsp_hip_conv_spectrum_points() complex
+ * points (FFT of the zero-padded taps, pre-divided by the block length) to spectrum_dev;
+ * convolve_prepared is the single fused overlap-save launch (taps <= 1025). */
+size_t bdsp_hip_conv_spectrum_points(void);
+int bdsp_hip_dev_conv_prepare(int elem, const void *taps_dev, size_t taps, void *spectrum_dev,
+                              void *stream);
+int bdsp_hip_dev_convolve_prepared(int elem, const void *in, void *out, size_t points, size_t batch,
+                                   const void *spectrum_dev, size_t taps, void *stream);
+
+/* Elementwise x[i] = x[i]*scale + offset is NOT offered (the reference never fuses them and a
+ * fused multiply-add would round differently); separate entry points: */
+int bdsp_hip_dev_real_scale(int elem, void *data, size_t len, double factor, void *stream);
+int bdsp_hip_dev_real_offset(int elem, void *data, size_t len, int is_complex, double offset,
+                             void *stream);
+
+/* polyphase interpolatef (reference a13) on device memory; out holds
+ * bdsp_hip_interpolatef_new_len(...) scalars. */
+size_t bdsp_hip_interpolatef_new_len(int elem, size_t len, double factor);
+int bdsp_hip_dev_interpolatef(int elem, const void *in, void *out, size_t len, int is_complex,
+                              int function_id, double rolloff, double factor, double delay,
+                              size_t conv_len, double delta, void *stream);
+
+/* Blocks until everything queued on `stream` (NULL = library stream) has finished. */
+int bdsp_hip_synchronize(void *stream);
+/* Binds the calling thread's work to HIP device `ordinal` (one process per GPU: call once). */
+int bdsp_hip_set_device(int ordinal);
+
+/* Timing hooks for bench.py: HIP events recorded on `stream`; elapsed milliseconds between
+ * two recorded events.  (torch.cuda.Event only sees torch's current stream.) */
+void *bdsp_hip_event_create(void);
+int bdsp_hip_event_record(void *event, void *stream);
+int bdsp_hip_event_elapsed_ms(void *start, void *stop, float *ms);
+void bdsp_hip_event_destroy(void *event);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BASIC_DSP_HIP_H */

