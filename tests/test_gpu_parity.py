@@ -16,9 +16,15 @@ from basic_dsp_amd import DspVec  # noqa: E402
 from basic_dsp_amd import vector as V  # noqa: E402
 
 
+def _as_real(a):
+    a = np.asarray(a)
+    if np.iscomplexobj(a):
+        return a.astype(np.complex128).view(np.float64)
+    return a.astype(np.float64)
+
+
 def rel_l2(got, ref):
-    got = np.asarray(got, dtype=np.float64)
-    ref = np.asarray(ref, dtype=np.float64)
+    got, ref = _as_real(got), _as_real(ref)
     return np.linalg.norm(got - ref) / max(np.linalg.norm(ref), 1e-300)
 
 
@@ -106,7 +112,9 @@ def test_multiply_complex_exponential(dtype):
     v = DspVec(x, is_complex=True, delta=0.5)
     assert v.multiply_complex_exponential(0.02, 0.3) == 0
     k = np.arange(3000)
-    ref = x.astype(np.float64).view(np.complex128) * np.exp(1j * (0.02 * 0.5 * k + 0.3 * 0.5))
+    # a and b are multiplied by delta in T first (complex_ops.rs:83-84)
+    a, b = float(dtype(0.02) * dtype(0.5)), float(dtype(0.3) * dtype(0.5))
+    ref = x.astype(np.float64).view(np.complex128) * np.exp(1j * (a * k + b))
     assert rel_l2(v.data(), ref.view(np.float64)) < (2e-7 if dtype == np.float32 else 1e-14)
     # and it tracks the reference's running product to the reference's own accuracy
     refrun = orc.multiply_complex_exponential(x, 0.02, 0.3, 0.5)
