@@ -75,6 +75,20 @@ __device__ __forceinline__ void io_store(const FftIo<T>& io, size_t vec, size_t 
         reinterpret_cast<cpx<T>*>(io.out)[vec * io.out_stride + dst] = v;
 }
 
+// LDS stride (in elements) between the regions of adjacent columns / transforms of one workgroup.
+// Lanes that run along columns hit addresses c*stride + const: with the padded length alone the
+// stride is a multiple of 16 elements = a multiple of 32 banks, i.e. a 16-way conflict (measured:
+// 90 % of LDS cycles were conflict cycles).  stride = 16*k + max(1, 16/W) spreads the W columns of a
+// 16-lane group over all banks, and leaves room for the rows of a second thread-row when W < 16.
+__host__ __device__ constexpr int col_stride(int n)
+{
+    int nt = n / 16 > 0 ? n / 16 : 1;
+    int w = 256 / nt;
+    int padded = n + (n >> 4);
+    int base = (padded + 15) / 16 * 16;
+    return base + (w >= 16 ? 1 : 16 / w);
+}
+
 // ------------------------------------------------------------------------------ n <= 8
 template <typename T, int N, int DIR>
 __global__ __launch_bounds__(256) void k_fft_tiny(FftIo<T> io, size_t batch)
@@ -90,7 +104,11 @@ __global__ __launch_bounds__(256) void k_fft_tiny(FftIo<T> io, size_t batch)
 }
 
 // ------------------------------------------------------------------------------ 16 <= n <= 4096
-template <typename T, int N, int DIR>
+// GEN = false: plain complex in/out, registers <-> global directly.
+// GEN = true : any fused option (window, scale, shifts, real input, magnitude ...).  The option
+// code runs in a ROLLED loop that stages through LDS, so the register array stays statically
+// indexed and the option code is emitted once instead of 16 times per thread.
+template <typename T, int N, int DIR, bool GEN>
 __global__ __launch_bounds__(256) void k_fft_wg(FftIo<T> io, const cpx<T>* __restrict__ wtab,
                                                  size_t batch)
 {
@@ -105,13 +123,29 @@ __global__ __launch_bounds__(256) void k_fft_wg(FftIo<T> io, const cpx<T>* __res
     const int c = tid / NT, t = tid % NT;
     const size_t vec = (size_t)blockIdx.x * B + c;
     const bool active = vec < batch;
-    cpx<T>* l = lds + (size_t)c * F::LDS_ELEMS;
+    cpx<T>* l = lds + (size_t)c * col_stride(N);
     auto tw = [&](int m) { return wtab[m]; };
 
     cpx<T> v[16];
+    if constexpr (GEN) {
+#pragma unroll 1
+        for (int e = 0; e < 16; ++e) {
+            int idx = t + e * NT;
+            l[F::pad(idx)] = active ? io_load(io, vec, (size_t)idx) : cpx<T>{0, 0};
+        }
+        __syncthreads();
+        if constexpr (N >= 256) F::template gather<16>(v, t, l);
+        else {
 #pragma unroll
-    for (int r = 0; r < 16; ++r)
-        v[r] = active ? io_load(io, vec, (size_t)F::template in_index<16>(t, 0, r)) : cpx<T>{0, 0};
+            for (int r = 0; r < 16; ++r) v[r] = l[F::pad(F::template in_index<16>(t, 0, r))];
+        }
+        __syncthreads();
+    } else {
+        const cpx<T>* in = reinterpret_cast<const cpx<T>*>(io.in) + vec * io.in_stride;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            v[r] = active ? in[F::template in_index<16>(t, 0, r)] : cpx<T>{0, 0};
+    }
     F::template compute<16, 1, DIR>(v, t, tw);
     if constexpr (P::R2 > 1) {
         F::template scatter<16, 1>(v, t, l);
@@ -126,14 +160,29 @@ __global__ __launch_bounds__(256) void k_fft_wg(FftIo<T> io, const cpx<T>* __res
         F::template gather<P::R3>(v, t, l);
         F::template compute<P::R3, 16 * P::R2, DIR>(v, t, tw);
     }
-    if (!active) return;
     constexpr int RL = P::R3 > 1 ? P::R3 : (P::R2 > 1 ? P::R2 : 16);
     constexpr int NSL = N / RL;
+    if constexpr (GEN) {
+        __syncthreads();
 #pragma unroll
-    for (int b = 0; b < 16 / RL; ++b)
+        for (int b = 0; b < 16 / RL; ++b)
 #pragma unroll
-        for (int r = 0; r < RL; ++r)
-            io_store(io, vec, (size_t)F::template out_index<RL, NSL>(t, b, r), v[b * RL + r]);
+            for (int r = 0; r < RL; ++r) l[F::pad(F::template out_index<RL, NSL>(t, b, r))] = v[b * RL + r];
+        __syncthreads();
+        if (!active) return;
+#pragma unroll 1
+        for (int e = 0; e < 16; ++e) {
+            int idx = t + e * NT;
+            io_store(io, vec, (size_t)idx, l[F::pad(idx)]);
+        }
+    } else {
+        if (!active) return;
+        cpx<T>* out = reinterpret_cast<cpx<T>*>(io.out) + vec * io.out_stride;
+#pragma unroll
+        for (int b = 0; b < 16 / RL; ++b)
+#pragma unroll
+            for (int r = 0; r < RL; ++r) out[F::template out_index<RL, NSL>(t, b, r)] = v[b * RL + r];
+    }
 }
 
 // ------------------------------------------------------------------------------ n > 4096
@@ -170,15 +219,17 @@ __device__ __forceinline__ cpx<double> unit_root<double>(size_t e, size_t n)
 // ROWMAP selects how the LAST inner stage maps lanes: along rows (first global pass, where each
 // column's RP results are contiguous in memory) or along columns (later passes, where adjacent
 // columns are contiguous).
-template <typename T, int RP, int DIR, bool ROWMAP>
+// GEN: fused options on the vector's input (first pass = the ROWMAP instantiation) or output (last
+// pass = a !ROWMAP instantiation), staged through LDS by a rolled loop like k_fft_wg<GEN>.
+template <typename T, int RP, int DIR, bool ROWMAP, bool GEN>
 __global__ __launch_bounds__(256) void k_fft_pass(FftIo<T> io, const cpx<T>* __restrict__ src,
                                                    cpx<T>* __restrict__ dst,
                                                    const cpx<T>* __restrict__ wtab, size_t n,
-                                                   size_t nsg, size_t tiles_per_vec, int first,
-                                                   int last)
+                                                   size_t nsg, size_t tiles_per_vec, int last)
 {
     constexpr int NT = RP / 16;
     constexpr int W = 256 / NT;
+    constexpr int CS = col_stride(RP);
     using F = WgFft<T, RP, NT>;
     using P = Radix16Plan<RP>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -199,10 +250,19 @@ __global__ __launch_bounds__(256) void k_fft_pass(FftIo<T> io, const cpx<T>* __r
     const int c = tid % W, ti = tid / W;
     const size_t j = j0 + c;
     cpx<T> v[16];
+    if constexpr (GEN && ROWMAP) {
+#pragma unroll 1
+        for (int e = 0; e < 16; ++e) {
+            int row = ti + e * NT;
+            lds[(size_t)c * CS + F::pad(row)] = io_load(io, vec, j + (size_t)row * stride_in);
+        }
+        __syncthreads();
+        F::template gather<16>(v, ti, lds + (size_t)c * CS);
+        __syncthreads();
+    } else {
+        const cpx<T>* in = src + vec * n + j;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        size_t idx = j + (size_t)(ti + r * NT) * stride_in;
-        v[r] = first ? io_load(io, vec, idx) : src[vec * n + idx];
+        for (int r = 0; r < 16; ++r) v[r] = in[(size_t)(ti + r * NT) * stride_in];
     }
     if (nsg > 1) {
         // inter-pass twiddle w_n^{row*q}, q = k * n/(nsg*RP); row = ti + r*NT
@@ -228,11 +288,11 @@ __global__ __launch_bounds__(256) void k_fft_pass(FftIo<T> io, const cpx<T>* __r
 
     // ---- RP-point sub-FFT of every column
     F::template compute<16, 1, DIR>(v, ti, tw);
-    F::template scatter<16, 1>(v, ti, lds + (size_t)c * F::LDS_ELEMS);
+    F::template scatter<16, 1>(v, ti, lds + (size_t)c * CS);
     __syncthreads();
     const int c2 = ROWMAP ? tid / NT : tid % W;
     const int t2 = ROWMAP ? tid % NT : tid / W;
-    cpx<T>* l2 = lds + (size_t)c2 * F::LDS_ELEMS;
+    cpx<T>* l2 = lds + (size_t)c2 * CS;
     F::template gather<P::R2>(v, t2, l2);
     F::template compute<P::R2, 16, DIR>(v, t2, tw);
     if constexpr (P::R3 > 1) {
@@ -248,23 +308,44 @@ __global__ __launch_bounds__(256) void k_fft_pass(FftIo<T> io, const cpx<T>* __r
     constexpr int NSL = RP / RL;
     const size_t jj = j0 + c2;
     const size_t base = (jj / nsg) * nsg * RP + (jj % nsg);
+    if (GEN && !ROWMAP && last) {
+        __syncthreads();
 #pragma unroll
-    for (int b = 0; b < 16 / RL; ++b)
+        for (int b = 0; b < 16 / RL; ++b)
 #pragma unroll
-        for (int r = 0; r < RL; ++r) {
-            size_t idx = base + (size_t)F::template out_index<RL, NSL>(t2, b, r) * nsg;
-            if (last) io_store(io, vec, idx, v[b * RL + r]);
-            else dst[vec * n + idx] = v[b * RL + r];
+            for (int r = 0; r < RL; ++r)
+                l2[F::pad(F::template out_index<RL, NSL>(t2, b, r))] = v[b * RL + r];
+        __syncthreads();
+#pragma unroll 1
+        for (int e = 0; e < 16; ++e) {
+            int row = t2 + e * NT;
+            io_store(io, vec, base + (size_t)row * nsg, l2[F::pad(row)]);
         }
+    } else {
+        cpx<T>* out = dst + vec * n + base;
+#pragma unroll
+        for (int b = 0; b < 16 / RL; ++b)
+#pragma unroll
+            for (int r = 0; r < RL; ++r)
+                out[(size_t)F::template out_index<RL, NSL>(t2, b, r) * nsg] = v[b * RL + r];
+    }
 }
 
 // ------------------------------------------------------------------------------ launchers
+// plain complex in/out with the natural batch stride and no fused option?
+template <typename T>
+static bool io_is_generic(const FftIo<T>& io)
+{
+    return io.flags != 0 || io.window_id >= 0 || io.in_scale != (T)1 || io.in_stride != io.n ||
+           io.out_stride != io.n;
+}
+
 template <typename T>
 static size_t wg_lds_bytes(int n)
 {
     int nt = n / 16;
     int b = 256 / nt;
-    return (size_t)b * (n + (n >> 4)) * sizeof(cpx<T>);
+    return (size_t)b * col_stride(n) * sizeof(cpx<T>);
 }
 
 template <typename K>
@@ -284,13 +365,16 @@ static int launch_wg(const FftIo<T>& io, size_t batch, bool inverse, hipStream_t
     constexpr int B = 256 / (N / 16);
     size_t lds = wg_lds_bytes<T>(N);
     unsigned grid = (unsigned)((batch + B - 1) / B);
-    if (inverse) {
-        BDSP_TRY(set_lds(k_fft_wg<T, N, 1>, lds));
-        hipLaunchKernelGGL((k_fft_wg<T, N, 1>), dim3(grid), dim3(256), lds, s, io, wtab, batch);
-    } else {
-        BDSP_TRY(set_lds(k_fft_wg<T, N, -1>, lds));
-        hipLaunchKernelGGL((k_fft_wg<T, N, -1>), dim3(grid), dim3(256), lds, s, io, wtab, batch);
-    }
+    const bool gen = io_is_generic(io);
+#define BDSP_WG(DIRV, GENV)                                                                        \
+    do {                                                                                           \
+        BDSP_TRY(set_lds(k_fft_wg<T, N, DIRV, GENV>, lds));                                        \
+        hipLaunchKernelGGL((k_fft_wg<T, N, DIRV, GENV>), dim3(grid), dim3(256), lds, s, io, wtab,  \
+                           batch);                                                                 \
+    } while (0)
+    if (inverse) { if (gen) BDSP_WG(1, true); else BDSP_WG(1, false); }
+    else { if (gen) BDSP_WG(-1, true); else BDSP_WG(-1, false); }
+#undef BDSP_WG
     BDSP_LAUNCH_CHECK();
     return BDSP_OK;
 }
@@ -314,15 +398,23 @@ static int launch_pass(const FftIo<T>& io, const cpx<T>* src, cpx<T>* dst, size_
     size_t lds = wg_lds_bytes<T>(RP);
     size_t tiles = n / 4096;
     dim3 grid((unsigned)(tiles * batch));
-    const bool rowmap = nsg == 1;
-#define BDSP_PASS(DIRV, RM)                                                                        \
+    const bool rowmap = nsg == 1; // the first pass
+    const bool gen = io_is_generic(io) && (first || last);
+    if (first && !gen) src = reinterpret_cast<const cpx<T>*>(io.in);
+    if (last && !gen) dst = reinterpret_cast<cpx<T>*>(io.out);
+#define BDSP_PASS(DIRV, RM, GENV)                                                                  \
     do {                                                                                           \
-        BDSP_TRY(set_lds(k_fft_pass<T, RP, DIRV, RM>, lds));                                       \
-        hipLaunchKernelGGL((k_fft_pass<T, RP, DIRV, RM>), grid, dim3(256), lds, s, io, src, dst,   \
-                           wtab, n, nsg, tiles, (int)first, (int)last);                            \
+        BDSP_TRY(set_lds(k_fft_pass<T, RP, DIRV, RM, GENV>, lds));                                 \
+        hipLaunchKernelGGL((k_fft_pass<T, RP, DIRV, RM, GENV>), grid, dim3(256), lds, s, io, src,  \
+                           dst, wtab, n, nsg, tiles, (int)last);                                   \
     } while (0)
-    if (inverse) { if (rowmap) BDSP_PASS(1, true); else BDSP_PASS(1, false); }
-    else { if (rowmap) BDSP_PASS(-1, true); else BDSP_PASS(-1, false); }
+#define BDSP_PASS_D(DIRV)                                                                          \
+    do {                                                                                           \
+        if (rowmap) { if (gen) BDSP_PASS(DIRV, true, true); else BDSP_PASS(DIRV, true, false); }   \
+        else { if (gen) BDSP_PASS(DIRV, false, true); else BDSP_PASS(DIRV, false, false); }        \
+    } while (0)
+    if (inverse) BDSP_PASS_D(1); else BDSP_PASS_D(-1);
+#undef BDSP_PASS_D
 #undef BDSP_PASS
     BDSP_LAUNCH_CHECK();
     return BDSP_OK;

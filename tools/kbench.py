@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""Quick per-kernel timing on the GPU box: conv (prepared spectrum) and FFT at a given size."""
+import argparse, ctypes as C, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import basic_dsp_amd as bd
+lib = bd.lib
+ap = argparse.ArgumentParser()
+ap.add_argument("--points", type=int, default=1 << 24)
+ap.add_argument("--taps", type=int, default=1024)
+ap.add_argument("--batch", type=int, default=1)
+ap.add_argument("--iters", type=int, default=20)
+ap.add_argument("--elem", type=int, default=0)
+ap.add_argument("--what", default="conv,fft")
+a = ap.parse_args()
+n, m, b = a.points, a.taps, a.batch
+dt = torch.float32 if a.elem == 0 else torch.float64
+dev = torch.device("cuda", 0)
+xs = [torch.rand(2 * n * b, device=dev, dtype=dt) * 20 - 10 for _ in range(3)]
+taps = (torch.rand(2 * m, device=dev, dtype=dt) * 2 - 1) / m
+y = torch.empty(2 * n * b, device=dev, dtype=dt)
+spec = torch.empty(2 * lib.bdsp_hip_conv_spectrum_points(), device=dev, dtype=dt)
+sp = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+flag = C.c_int(0)
+def timeit(fn):
+    for i in range(3): fn(i)
+    torch.cuda.synchronize()
+    e0, e1 = lib.bdsp_hip_event_create(), lib.bdsp_hip_event_create()
+    lib.bdsp_hip_event_record(e0, sp)
+    for i in range(a.iters): fn(i)
+    lib.bdsp_hip_event_record(e1, sp)
+    ms = C.c_float(0); lib.bdsp_hip_event_elapsed_ms(e0, e1, C.byref(ms))
+    return ms.value / a.iters * 1e3
+esz = 8 if a.elem == 0 else 16
+if "conv" in a.what:
+    bd._lib.check(lib.bdsp_hip_dev_conv_prepare(a.elem, taps.data_ptr(), m, spec.data_ptr(), sp))
+    us = timeit(lambda i: bd._lib.check(lib.bdsp_hip_dev_convolve_prepared(a.elem, xs[i % 3].data_ptr(), y.data_ptr(), n, b, spec.data_ptr(), m, sp)))
+    print("conv  n=%d b=%d m=%d: %.1f us  %.1f Gsamples/s  %.0f GB/s algorithmic" % (n, b, m, us, n * b / us / 1e3, 2 * esz * n * b / us / 1e3))
+if "fft" in a.what:
+    us = timeit(lambda i: bd._lib.check(lib.bdsp_hip_dev_fft(a.elem, xs[i % 3].data_ptr(), y.data_ptr(), n, b, 0, 1.0, -1, 0.0, C.byref(flag), sp)))
+    print("fft   n=%d b=%d: %.1f us  %.1f Gsamples/s  %.0f GB/s algorithmic" % (n, b, us, n * b / us / 1e3, 2 * esz * n * b / us / 1e3))
+if "prep" in a.what:
+    us = timeit(lambda i: bd._lib.check(lib.bdsp_hip_dev_conv_prepare(a.elem, taps.data_ptr(), m, spec.data_ptr(), sp)))
+    print("prep  m=%d: %.1f us" % (m, us))
