@@ -26,7 +26,17 @@ size_t conv_fft_len(size_t) { return CONV_L; }
 
 // Grid: x = persistent workgroups walking the blocks of one vector with a grid stride,
 //       y = vector of the batch.  All per-vector indices are 32-bit (points < 2^31).
-template <typename T, bool REGTW>
+//
+// Software pipeline (measured on MI355X: without it the load, FFT, xH, IFFT and store phases of all
+// resident workgroups run in lockstep and their times simply add up, 100 us; phase ablation:
+// x loads 23 us, spectrum loads 22 us, stores 20 us, LDS 12 us, butterflies 18-33 us):
+//   * the input of block b+G is requested before block b is transformed (one block of prefetch
+//     registers), so HBM latency hides under the butterflies;
+//   * FAST (f32): the filter spectrum H (16 values per thread) and the stage-3 twiddles stay in
+//     registers for the whole persistent loop, the stage-2 twiddles (16 distinct rows) in a 2 KB
+//     LDS table; the kernel is built for 2 workgroups per CU (256 VGPRs) because occupancy beyond
+//     that bought nothing once the phases overlap inside one workgroup.
+template <typename T, bool FAST>
 __global__ __launch_bounds__(256, 2) void k_overlap_save(
     const cpx<T>* __restrict__ x, cpx<T>* __restrict__ y, const cpx<T>* __restrict__ hs,
     const cpx<T>* __restrict__ wtab, unsigned n, int m_taps, long long in_off, long long out_off,
@@ -37,37 +47,36 @@ __global__ __launch_bounds__(256, 2) void k_overlap_save(
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     cpx<T>* lds = reinterpret_cast<cpx<T>*>(smem_raw);
     const int t = threadIdx.x;
+    const unsigned ut = (unsigned)t;
     const int ov = m_taps - 1;
     const unsigned V = (unsigned)(L - ov);
     auto tw = [&](int mm) { return wtab[mm]; };
 
-    cpx<T> tw2[REGTW ? 15 : 1], tw3[REGTW ? 15 : 1];
-    if constexpr (REGTW) {
-        F::template load_twiddles<16, 16>(tw2, t, tw);
+    cpx<T> tw3[FAST ? 15 : 1], hreg[FAST ? 16 : 1];
+    cpx<T>* tw2l = lds + F::LDS_ELEMS;
+    if constexpr (FAST) {
         F::template load_twiddles<16, 256>(tw3, t, tw);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) hreg[r] = hs[ut + 256u * r];
+        if (t < 240) {
+            int k = t / 15, r = t % 15 + 1;
+            tw2l[k * 17 + r - 1] = wtab[r * k * 16];
+        }
+        __syncthreads();
     }
+    const cpx<T>* tw2p = tw2l + (t & 15) * 17;
     const size_t vec = blockIdx.y;
     const cpx<T>* __restrict__ xv = x + vec * (size_t)n;
     cpx<T>* __restrict__ yv = y + vec * (size_t)(store_all ? (unsigned)L : n);
 
-    for (unsigned b = blockIdx.x; b < blocks_per_vec; b += gridDim.x) {
-        // Keep the spectrum (and, without register twiddles, the twiddle table) out of loop-invariant
-        // code motion: hoisted they would pin 32..150 VGPRs for the whole persistent loop.
-        const cpx<T>* hp = hs + t;
-        const cpx<T>* wt = wtab;
-        asm volatile("" : "+v"(hp));
-        if constexpr (!REGTW) asm volatile("" : "+s"(wt));
-        auto twl = [&](int mm) { return wt[mm]; };
-        // first input index of the block, reduced into [0, n) once (uniform -> scalar registers)
+    // block b reads x[(b*V + in_off + i) mod n], i = t + 256 r.  Global addressing is
+    // uniform 64-bit base (scalar registers) + small unsigned lane index.
+    auto load_block = [&](unsigned b, cpx<T> (&d)[16]) {
         long long base = (long long)b * V + in_off;
-        cpx<T> v[16];
-        // Global addressing is  uniform 64-bit base (scalar registers) + small unsigned lane index,
-        // so no per-register 64-bit addresses are kept alive across the loop.
-        const unsigned ut = (unsigned)t;
         if (base >= 0 && base + L <= (long long)n) {
             const cpx<T>* xb = xv + base;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) v[r] = xb[ut + 256u * r];
+            for (int r = 0; r < 16; ++r) d[r] = xb[ut + 256u * r];
         } else {
             long long sb = base % (long long)n;
             if (sb < 0) sb += n;
@@ -77,13 +86,37 @@ __global__ __launch_bounds__(256, 2) void k_overlap_save(
                 for (int r = 0; r < 16; ++r) {
                     unsigned i = idx + 256u * r;
                     if (i >= n) i -= n;
-                    v[r] = xv[i];
+                    d[r] = xv[i];
                 }
             } else {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) v[r] = xv[(idx + 256u * r) % n];
+                for (int r = 0; r < 16; ++r) d[r] = xv[(idx + 256u * r) % n];
             }
         }
+    };
+
+    // Workgroup w runs on XCD w % 8 (observed dispatch order; only speed depends on it).  Blocks
+    // that are adjacent in the signal share M-1 input samples, so give each XCD a contiguous run
+    // of blocks per sweep: the overlap is then served by that XCD's L2 instead of HBM.
+    unsigned wl = blockIdx.x;
+    if ((gridDim.x & 7) == 0) wl = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+
+    cpx<T> nx[16];
+    if (wl < blocks_per_vec) load_block(wl, nx);
+    for (unsigned b = wl; b < blocks_per_vec; b += gridDim.x) {
+        cpx<T> v[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = nx[r];
+        if (b + gridDim.x < blocks_per_vec) load_block(b + gridDim.x, nx); // prefetch
+
+        const cpx<T>* hp = hs + t;
+        const cpx<T>* wt = wtab;
+        if constexpr (!FAST) {
+            // keep the spectrum / twiddle loads inside the loop (hoisted they would pin > 150 VGPRs)
+            asm volatile("" : "+v"(hp));
+            asm volatile("" : "+s"(wt));
+        }
+        auto twl = [&](int mm) { return wt[mm]; };
 
         // ---- forward FFT_L
         F::template compute<16, 1, -1>(v, t, twl);
@@ -91,18 +124,18 @@ __global__ __launch_bounds__(256, 2) void k_overlap_save(
         F::template scatter<16, 1>(v, t, lds);
         __syncthreads();
         F::template gather<16>(v, t, lds);
-        if constexpr (REGTW) F::template compute_pre<16, 16, -1>(v, tw2);
+        if constexpr (FAST) F::template compute_pre<16, 16, -1>(v, tw2p);
         else F::template compute<16, 16, -1>(v, t, twl);
         __syncthreads();
         F::template scatter<16, 16>(v, t, lds);
         __syncthreads();
         F::template gather<16>(v, t, lds);
-        if constexpr (REGTW) F::template compute_pre<16, 256, -1>(v, tw3);
+        if constexpr (FAST) F::template compute_pre<16, 256, -1>(v, tw3);
         else F::template compute<16, 256, -1>(v, t, twl);
 
         // ---- spectrum product (hs already carries the 1/L of the inverse transform)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) v[r] = cmul(v[r], hp[256 * r]);
+        for (int r = 0; r < 16; ++r) v[r] = cmul(v[r], FAST ? hreg[r] : hp[256 * r]);
 
         // ---- inverse FFT_L
         F::template compute<16, 1, 1>(v, t, twl);
@@ -110,13 +143,13 @@ __global__ __launch_bounds__(256, 2) void k_overlap_save(
         F::template scatter<16, 1>(v, t, lds);
         __syncthreads();
         F::template gather<16>(v, t, lds);
-        if constexpr (REGTW) F::template compute_pre<16, 16, 1>(v, tw2);
+        if constexpr (FAST) F::template compute_pre<16, 16, 1>(v, tw2p);
         else F::template compute<16, 16, 1>(v, t, twl);
         __syncthreads();
         F::template scatter<16, 16>(v, t, lds);
         __syncthreads();
         F::template gather<16>(v, t, lds);
-        if constexpr (REGTW) F::template compute_pre<16, 256, 1>(v, tw3);
+        if constexpr (FAST) F::template compute_pre<16, 256, 1>(v, tw3);
         else F::template compute<16, 256, 1>(v, t, twl);
 
         // ---- store: z[n'] for n' >= M-1 is output b*V + out_off + (n' - (M-1))
@@ -173,7 +206,7 @@ __global__ __launch_bounds__(256) void k_conv_direct(const T* __restrict__ x, T*
 }
 
 template <typename T>
-static size_t conv_lds_bytes() { return (size_t)(CONV_L + (CONV_L >> 4)) * sizeof(cpx<T>); }
+static size_t conv_lds_bytes() { return (size_t)(CONV_L + (CONV_L >> 4) + 16 * 17) * sizeof(cpx<T>); }
 
 // Filter spectrum for the block kernel: hs[0..L) = FFT_L(zero-padded taps) / L in natural order
 // (the 1/L of the unnormalised inverse transform is folded in here).  Exactly one of
@@ -221,14 +254,14 @@ int conv_run_blocks(const T* in, T* out, size_t points, size_t batch, const T* h
     const long long V = L - (long long)(taps - 1);
     long long per_vec = nblocks_limit ? (long long)nblocks_limit : ((long long)points + V - 1) / V;
     size_t lds = conv_lds_bytes<T>();
-    constexpr bool REGTW = sizeof(T) == 4;
-    auto kern = k_overlap_save<T, REGTW>;
+    constexpr bool FAST = sizeof(T) == 4;
+    auto kern = k_overlap_save<T, FAST>;
     if (lds > 64 * 1024)
         BDSP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     // persistent-ish grid: enough workgroups to fill every CU at the occupancy LDS/VGPRs allow,
     // each walking blocks with a grid stride so the register-resident twiddles are loaded once
-    int per_cu = 2; // register budget of the current build: 2 workgroups (8 waves) per CU
+    int per_cu = 2; // the kernel is built for 2 workgroups (8 waves) per CU
     long long want = (long long)num_cus() * per_cu;
     long long gx = (want + (long long)batch - 1) / (long long)batch;
     if (gx > per_vec) gx = per_vec;
