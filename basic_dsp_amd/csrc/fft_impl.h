@@ -16,6 +16,9 @@
 // Window, 1/N scale, fft_shift / ifft_shift and magnitude are fused into the first / last pass
 // (FftIo), so fft()/windowed_fft()/ifft() never take an extra trip through HBM
 // (reference: time_to_freq.rs:158-175, freq_to_time.rs:160-177 run them as separate passes).
+#include <cstdio>
+#include <cstdlib>
+
 #include "bdsp_internal.h"
 #include "dsp_funcs.h"
 
@@ -80,10 +83,10 @@ __device__ __forceinline__ void io_store(const FftIo<T>& io, size_t vec, size_t 
 // stride is a multiple of 16 elements = a multiple of 32 banks, i.e. a 16-way conflict (measured:
 // 90 % of LDS cycles were conflict cycles).  stride = 16*k + max(1, 16/W) spreads the W columns of a
 // 16-lane group over all banks, and leaves room for the rows of a second thread-row when W < 16.
-__host__ __device__ constexpr int col_stride(int n)
+__host__ __device__ constexpr int col_stride(int n, int w = 0)
 {
     int nt = n / 16 > 0 ? n / 16 : 1;
-    int w = 256 / nt;
+    if (w == 0) w = 256 / nt;
     int padded = n + (n >> 4);
     int base = (padded + 15) / 16 * 16;
     return base + (w >= 16 ? 1 : 16 / w);
@@ -221,15 +224,14 @@ __device__ __forceinline__ cpx<double> unit_root<double>(size_t e, size_t n)
 // columns are contiguous).
 // GEN: fused options on the vector's input (first pass = the ROWMAP instantiation) or output (last
 // pass = a !ROWMAP instantiation), staged through LDS by a rolled loop like k_fft_wg<GEN>.
-template <typename T, int RP, int DIR, bool ROWMAP, bool GEN>
-__global__ __launch_bounds__(256) void k_fft_pass(FftIo<T> io, const cpx<T>* __restrict__ src,
+template <typename T, int RP, int W, int DIR, bool ROWMAP, bool GEN>
+__global__ __launch_bounds__(W * (RP / 16)) void k_fft_pass(FftIo<T> io, const cpx<T>* __restrict__ src,
                                                    cpx<T>* __restrict__ dst,
                                                    const cpx<T>* __restrict__ wtab, size_t n,
                                                    size_t nsg, size_t tiles_per_vec, int last)
 {
     constexpr int NT = RP / 16;
-    constexpr int W = 256 / NT;
-    constexpr int CS = col_stride(RP);
+    constexpr int CS = col_stride(RP, W);
     using F = WgFft<T, RP, NT>;
     using P = Radix16Plan<RP>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -389,14 +391,15 @@ static int launch_tiny(const FftIo<T>& io, size_t batch, bool inverse, hipStream
     return BDSP_OK;
 }
 
-template <typename T, int RP>
+template <typename T, int RP, int W>
 static int launch_pass(const FftIo<T>& io, const cpx<T>* src, cpx<T>* dst, size_t n, size_t nsg,
                        size_t batch, bool inverse, bool first, bool last, hipStream_t s)
 {
     const cpx<T>* wtab;
     BDSP_TRY(twiddle_table<T>(RP, &wtab));
-    size_t lds = wg_lds_bytes<T>(RP);
-    size_t tiles = n / 4096;
+    constexpr int THREADS = W * (RP / 16);
+    size_t lds = (size_t)W * col_stride(RP, W) * sizeof(cpx<T>);
+    size_t tiles = (n / RP) / W;
     dim3 grid((unsigned)(tiles * batch));
     const bool rowmap = nsg == 1; // the first pass
     const bool gen = io_is_generic(io) && (first || last);
@@ -404,9 +407,9 @@ static int launch_pass(const FftIo<T>& io, const cpx<T>* src, cpx<T>* dst, size_
     if (last && !gen) dst = reinterpret_cast<cpx<T>*>(io.out);
 #define BDSP_PASS(DIRV, RM, GENV)                                                                  \
     do {                                                                                           \
-        BDSP_TRY(set_lds(k_fft_pass<T, RP, DIRV, RM, GENV>, lds));                                 \
-        hipLaunchKernelGGL((k_fft_pass<T, RP, DIRV, RM, GENV>), grid, dim3(256), lds, s, io, src,  \
-                           dst, wtab, n, nsg, tiles, (int)last);                                   \
+        BDSP_TRY(set_lds(k_fft_pass<T, RP, W, DIRV, RM, GENV>, lds));                              \
+        hipLaunchKernelGGL((k_fft_pass<T, RP, W, DIRV, RM, GENV>), grid, dim3(THREADS), lds, s,    \
+                           io, src, dst, wtab, n, nsg, tiles, (int)last);                          \
     } while (0)
 #define BDSP_PASS_D(DIRV)                                                                          \
     do {                                                                                           \
@@ -420,32 +423,54 @@ static int launch_pass(const FftIo<T>& io, const cpx<T>* src, cpx<T>* dst, size_
     return BDSP_OK;
 }
 
+// (super-radix, tile width) pairs that are instantiated.  Default tile: W = 4096/RP columns
+// (256 threads); the wider variants trade LDS for longer contiguous global segments.
 template <typename T>
-static int launch_pass_rp(int rp, const FftIo<T>& io, const cpx<T>* src, cpx<T>* dst, size_t n,
-                          size_t nsg, size_t batch, bool inverse, bool first, bool last,
+static int launch_pass_rp(int rp, int w, const FftIo<T>& io, const cpx<T>* src, cpx<T>* dst,
+                          size_t n, size_t nsg, size_t batch, bool inverse, bool first, bool last,
                           hipStream_t s)
 {
-    switch (rp) {
-    case 64: return launch_pass<T, 64>(io, src, dst, n, nsg, batch, inverse, first, last, s);
-    case 128: return launch_pass<T, 128>(io, src, dst, n, nsg, batch, inverse, first, last, s);
-    case 256: return launch_pass<T, 256>(io, src, dst, n, nsg, batch, inverse, first, last, s);
-    case 512: return launch_pass<T, 512>(io, src, dst, n, nsg, batch, inverse, first, last, s);
-    case 1024: return launch_pass<T, 1024>(io, src, dst, n, nsg, batch, inverse, first, last, s);
-    default: set_last_error("unsupported super-radix"); return BDSP_ERR_UNSUPPORTED;
-    }
+#define BDSP_CASE(RPV, WV)                                                                         \
+    if (rp == RPV && w == WV)                                                                      \
+        return launch_pass<T, RPV, WV>(io, src, dst, n, nsg, batch, inverse, first, last, s);
+    BDSP_CASE(64, 64) BDSP_CASE(128, 32) BDSP_CASE(256, 16) BDSP_CASE(512, 8) BDSP_CASE(1024, 4)
+    BDSP_CASE(1024, 8) BDSP_CASE(2048, 2) BDSP_CASE(2048, 4) BDSP_CASE(4096, 2) BDSP_CASE(4096, 4)
+#undef BDSP_CASE
+    set_last_error("unsupported super-radix / tile width");
+    return BDSP_ERR_UNSUPPORTED;
 }
 
 // Super-radix plan for n = 2^bits > 4096: 2 passes up to 2^20, 3 passes up to 2^30, bits split as
 // evenly as possible, largest first (the first pass is the one whose stores are always long
 // contiguous runs, so it can afford the narrowest tile).
-static int plan_passes(size_t n, int rp[3])
+static int plan_passes(size_t n, int rp[3], int w[3])
 {
     int bits = 0;
     while ((size_t(1) << bits) < n) ++bits;
-    int passes = bits <= 20 ? 2 : 3;
     if (bits > 30) return 0;
+    // experiment hook: BDSP_FFT_PLAN="4096x2,4096x2" (radix x tile width per pass)
+    if (const char* e = getenv("BDSP_FFT_PLAN")) {
+        int k = 0;
+        size_t prod = 1;
+        while (*e && k < 3) {
+            int r = 0, ww = 0;
+            if (sscanf(e, "%dx%d", &r, &ww) != 2) break;
+            rp[k] = r; w[k] = ww; prod *= (size_t)r; ++k;
+            while (*e && *e != ',') ++e;
+            if (*e == ',') ++e;
+        }
+        if (k >= 2 && prod == n) return k;
+    }
+    int passes = bits <= 20 ? 2 : 3;
     int base = bits / passes, extra = bits % passes;
-    for (int i = 0; i < passes; ++i) rp[i] = 1 << (base + (i < extra ? 1 : 0));
+    for (int i = 0; i < passes; ++i) {
+        rp[i] = 1 << (base + (i < extra ? 1 : 0));
+        w[i] = 4096 / rp[i];
+        // 1024-point columns: 8-wide tiles (64-byte segments, 512 threads) measured 14 % faster than
+        // 4-wide ones on 64 x 2^20 points; 2-pass plans for 2^24 (4096x2 / 4096x4 tiles) measured
+        // 30-70 % SLOWER than three fully coalesced 256-point passes, so 3 passes stay.
+        if (rp[i] == 1024) w[i] = 8;
+    }
     return passes;
 }
 
@@ -479,8 +504,8 @@ int fft_pow2(const FftIo<T>& io, T* scratch_a, T* scratch_b, size_t batch, bool 
     case 4096: return launch_wg<T, 4096>(io, batch, inverse, s);
     default: break;
     }
-    int rp[3];
-    int passes = plan_passes(n, rp);
+    int rp[3], w[3];
+    int passes = plan_passes(n, rp, w);
     if (passes == 0) { set_last_error("FFT length above 2^30 points"); return BDSP_ERR_UNSUPPORTED; }
     if (!scratch_a || (passes == 3 && !scratch_b)) {
         set_last_error("fft_pow2: scratch missing");
@@ -489,14 +514,14 @@ int fft_pow2(const FftIo<T>& io, T* scratch_a, T* scratch_b, size_t batch, bool 
     cpx<T>* sa = reinterpret_cast<cpx<T>*>(scratch_a);
     cpx<T>* sb = reinterpret_cast<cpx<T>*>(scratch_b);
     size_t nsg = 1;
-    BDSP_TRY(launch_pass_rp<T>(rp[0], io, nullptr, sa, n, nsg, batch, inverse, true, false, s));
+    BDSP_TRY(launch_pass_rp<T>(rp[0], w[0], io, nullptr, sa, n, nsg, batch, inverse, true, false, s));
     nsg *= rp[0];
     if (passes == 2) {
-        BDSP_TRY(launch_pass_rp<T>(rp[1], io, sa, nullptr, n, nsg, batch, inverse, false, true, s));
+        BDSP_TRY(launch_pass_rp<T>(rp[1], w[1], io, sa, nullptr, n, nsg, batch, inverse, false, true, s));
     } else {
-        BDSP_TRY(launch_pass_rp<T>(rp[1], io, sa, sb, n, nsg, batch, inverse, false, false, s));
+        BDSP_TRY(launch_pass_rp<T>(rp[1], w[1], io, sa, sb, n, nsg, batch, inverse, false, false, s));
         nsg *= rp[1];
-        BDSP_TRY(launch_pass_rp<T>(rp[2], io, sb, nullptr, n, nsg, batch, inverse, false, true, s));
+        BDSP_TRY(launch_pass_rp<T>(rp[2], w[2], io, sb, nullptr, n, nsg, batch, inverse, false, true, s));
     }
     return BDSP_OK;
 }
