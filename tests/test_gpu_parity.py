@@ -398,3 +398,42 @@ def test_interpolatef_both_paths(cplx, dtype):
     assert v.interpolatef(0, 2.0, 1.0, 6) == 0
     ref, _ = orc.interpolatef(t, True, 0, 0.0, 2.0, 1.0, 6)
     np.testing.assert_allclose(v.data(), ref, atol=1e-5)
+
+
+# ------------------------------------------------------------------ batch (config C5, one GPU)
+def test_batch_shard_on_gpu_matches_oracle():
+    import torch
+    from basic_dsp_amd.batch import process_shard_gpu
+    nvec, points, m = 5, 1 << 14, 200
+    host = np.stack([orc.fill_uniform(2 * points, 201511212 + v, -10, 10, np.float32) for v in range(nvec)])
+    h = orc.fill_uniform(2 * m, 201601172, -1, 1, np.float32) / np.float32(m)
+    out = process_shard_gpu(torch.from_numpy(host).cuda(), torch.from_numpy(h).cuda(), points)
+    torch.cuda.synchronize()
+    out = out.cpu().numpy()
+    for v in range(nvec):
+        y = orc.convolve_direct(host[v].astype(np.float64), h.astype(np.float64), True)
+        assert rel_l2(out[v], orc.fft(y)) < 2e-6, v
+
+
+def test_b3_device_pointer_api():
+    """bdsp_hip_dev_* on torch-owned memory and torch's stream (what bench.py uses)."""
+    import ctypes as C
+    import torch
+    lib = bd.lib
+    n = 1 << 16
+    x = orc.fill_uniform(2 * n, 77, -10, 10, np.float32)
+    d = torch.from_numpy(x).cuda()
+    s = torch.empty_like(d)
+    sp = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    flag = C.c_int(0)
+    assert lib.bdsp_hip_dev_fft(0, d.data_ptr(), s.data_ptr(), n, 1, bd._lib.FFT_SHIFT_OUT | bd._lib.FFT_MAGNITUDE,
+                                1.0, -1, 0.0, C.byref(flag), sp) == 0
+    torch.cuda.synchronize()
+    got = (s if flag.value else d).cpu().numpy()[:n]
+    ref = orc.magnitude(orc.swap_halves(orc.fft(x.astype(np.float64)), True, True))
+    assert rel_l2(got, ref) < 1e-6
+    d = torch.from_numpy(x).cuda()
+    assert lib.bdsp_hip_dev_real_scale(0, d.data_ptr(), 2 * n, 2.5, sp) == 0
+    assert lib.bdsp_hip_dev_real_offset(0, d.data_ptr(), 2 * n, 0, -1.25, sp) == 0
+    torch.cuda.synchronize()
+    assert np.array_equal(d.cpu().numpy(), orc.real_offset(orc.real_scale(x, 2.5), -1.25))
