@@ -22,7 +22,30 @@ class VectorInteropResult64(C.Structure):
     _fields_ = [("result_code", C.c_int32), ("vector", C.c_void_p)]
 
 
+def _preload_shared_hip_runtime():
+    """One process must hold ONE copy of the HIP runtime.  PyTorch-ROCm wheels bundle their own
+    libamdhip64.so (file name without version, soname libamdhip64.so.7); if this library pulls in
+    /opt/rocm's copy first and torch is imported later, torch loads a second runtime and whichever
+    initialises second reports "no ROCm-capable device".  Opening torch's copy by path first makes
+    both our NEEDED (matched by soname) and torch's own lookup (matched by file) resolve to it,
+    whatever the import order.  Without torch installed the system runtime is used."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def _load():
+    _preload_shared_hip_runtime()
     if not os.path.exists(LIB_PATH):
         raise BackendError(
             "libbasic_dsp_hip.so is not built (expected %s); run `python -c 'import "

@@ -63,6 +63,7 @@ struct FftIo {
     T in_scale;        // applied to every input element (1 = none)
     int window_id;     // -1 none; else reference window id (4 = Hann)
     T window_alpha;
+    size_t in_valid;   // 0 = all n points; else points >= in_valid read as zero (fused End zero-padding)
 };
 constexpr unsigned FFT_IN_REAL = 1u << 8;        // input is a real vector (zero imaginary parts)
 constexpr unsigned FFT_WINDOW_OUT_DIV = 1u << 9; // divide OUTPUT by the window (windowed_ifft)
@@ -92,6 +93,7 @@ template <typename T>
 int conv_run_blocks(const T* in, T* out, size_t points, size_t batch, const T* hs, size_t taps,
                     long long in_off, long long out_off, size_t nblocks_limit, T* last_block_out,
                     hipStream_t s);
+// the spectrum handed to conv_run_blocks is UNSCALED; the kernel multiplies by 1/L while it loads it
 template <typename T> int mul_bcast(T* z, const T* h, size_t l, size_t nb, T scale, hipStream_t s);
 template <typename T>
 int scatter_valid(const T* z, T* x, size_t l, size_t skip, size_t step, size_t dst_off, size_t nb,

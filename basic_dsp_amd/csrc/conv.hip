@@ -50,6 +50,7 @@ __global__ __launch_bounds__(256, 2) void k_overlap_save(
     const unsigned ut = (unsigned)t;
     const int ov = m_taps - 1;
     const unsigned V = (unsigned)(L - ov);
+    const T hscale = (T)1 / (T)L; // the inverse transform below is unnormalised
     auto tw = [&](int mm) { return wtab[mm]; };
 
     cpx<T> tw3[FAST ? 15 : 1], hreg[FAST ? 16 : 1];
@@ -57,7 +58,10 @@ __global__ __launch_bounds__(256, 2) void k_overlap_save(
     if constexpr (FAST) {
         F::template load_twiddles<16, 256>(tw3, t, tw);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) hreg[r] = hs[ut + 256u * r];
+        for (int r = 0; r < 16; ++r) {
+            cpx<T> hv = hs[ut + 256u * r];
+            hreg[r] = cpx<T>{hv.x * hscale, hv.y * hscale};
+        }
         if (t < 240) {
             int k = t / 15, r = t % 15 + 1;
             tw2l[k * 17 + r - 1] = wtab[r * k * 16];
@@ -133,9 +137,15 @@ __global__ __launch_bounds__(256, 2) void k_overlap_save(
         if constexpr (FAST) F::template compute_pre<16, 256, -1>(v, tw3);
         else F::template compute<16, 256, -1>(v, t, twl);
 
-        // ---- spectrum product (hs already carries the 1/L of the inverse transform)
+        // ---- spectrum product
 #pragma unroll
-        for (int r = 0; r < 16; ++r) v[r] = cmul(v[r], FAST ? hreg[r] : hp[256 * r]);
+        for (int r = 0; r < 16; ++r) {
+            if constexpr (FAST) v[r] = cmul(v[r], hreg[r]);
+            else {
+                cpx<T> hv = hp[256 * r];
+                v[r] = cmul(v[r], cpx<T>{hv.x * hscale, hv.y * hscale});
+            }
+        }
 
         // ---- inverse FFT_L
         F::template compute<16, 1, 1>(v, t, twl);
@@ -208,8 +218,8 @@ __global__ __launch_bounds__(256) void k_conv_direct(const T* __restrict__ x, T*
 template <typename T>
 static size_t conv_lds_bytes() { return (size_t)(CONV_L + (CONV_L >> 4) + 16 * 17) * sizeof(cpx<T>); }
 
-// Filter spectrum for the block kernel: hs[0..L) = FFT_L(zero-padded taps) / L in natural order
-// (the 1/L of the unnormalised inverse transform is folded in here).  Exactly one of
+// Filter spectrum for the block kernel: hs[0..L) = FFT_L(zero-padded taps) in natural order,
+// UNSCALED (the block kernel folds the 1/L of its unnormalised inverse transform into the load).  Exactly one of
 // (taps_dev, h_freq_dev) is used: `taps` complex time-domain taps, or an UNSCALED length-L
 // spectrum handed in by GpuSupport::overlap_discard.
 template <typename T>
@@ -218,15 +228,14 @@ int conv_prepare_spectrum(const T* taps_dev, size_t taps, const T* h_freq_dev, T
     constexpr int L = CONV_L;
     if (h_freq_dev) {
         BDSP_HIP_TRY(hipMemcpyAsync(hs, h_freq_dev, sizeof(cpx<T>) * L, hipMemcpyDeviceToDevice, s));
-        return ew_real_scale<T>(hs, 2 * (size_t)L, (T)1 / (T)L, s);
+        return BDSP_OK;
     }
     if (taps == 0 || taps > (size_t)L) return BDSP_ERR_ARG_LENGTH;
-    BDSP_HIP_TRY(hipMemsetAsync(hs, 0, sizeof(cpx<T>) * L, s));
-    BDSP_HIP_TRY(hipMemcpyAsync(hs, taps_dev, sizeof(cpx<T>) * taps, hipMemcpyDeviceToDevice, s));
+    // one launch: the taps are zero-padded while they are loaded (in_valid), plain I/O path
     FftIo<T> io{};
     io.n = L; io.in_stride = L; io.out_stride = L; io.flags = 0; io.window_id = -1;
-    io.window_alpha = 0; io.in_scale = (T)1 / (T)L;
-    io.in = hs; io.out = hs;
+    io.window_alpha = 0; io.in_scale = (T)1; io.in_valid = taps;
+    io.in = taps_dev; io.out = hs;
     return fft_pow2<T>(io, nullptr, nullptr, 1, false, s);
 }
 

@@ -39,6 +39,7 @@ __device__ __forceinline__ cpx<T> io_load(const FftIo<T>& io, size_t vec, size_t
         if (src >= io.n) src -= io.n;
     }
     cpx<T> v;
+    if (io.in_valid && src >= io.in_valid) return cpx<T>{0, 0};
     if (io.flags & FFT_IN_REAL) {
         v.x = reinterpret_cast<const T*>(io.in)[vec * io.in_stride + src];
         v.y = (T)0;
@@ -131,7 +132,7 @@ __global__ __launch_bounds__(256) void k_fft_wg(FftIo<T> io, const cpx<T>* __res
 
     cpx<T> v[16];
     if constexpr (GEN) {
-#pragma unroll 1
+#pragma unroll 2
         for (int e = 0; e < 16; ++e) {
             int idx = t + e * NT;
             l[F::pad(idx)] = active ? io_load(io, vec, (size_t)idx) : cpx<T>{0, 0};
@@ -145,9 +146,12 @@ __global__ __launch_bounds__(256) void k_fft_wg(FftIo<T> io, const cpx<T>* __res
         __syncthreads();
     } else {
         const cpx<T>* in = reinterpret_cast<const cpx<T>*>(io.in) + vec * io.in_stride;
+        const int nvalid = io.in_valid ? (int)io.in_valid : N;
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-            v[r] = active ? in[F::template in_index<16>(t, 0, r)] : cpx<T>{0, 0};
+        for (int r = 0; r < 16; ++r) {
+            const int idx = F::template in_index<16>(t, 0, r);
+            v[r] = (active && idx < nvalid) ? in[idx] : cpx<T>{0, 0};
+        }
     }
     F::template compute<16, 1, DIR>(v, t, tw);
     if constexpr (P::R2 > 1) {
@@ -339,7 +343,7 @@ template <typename T>
 static bool io_is_generic(const FftIo<T>& io)
 {
     return io.flags != 0 || io.window_id >= 0 || io.in_scale != (T)1 || io.in_stride != io.n ||
-           io.out_stride != io.n;
+           io.out_stride != io.n || (io.in_valid != 0 && io.n > 4096);
 }
 
 template <typename T>
