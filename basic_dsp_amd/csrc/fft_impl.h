@@ -338,13 +338,24 @@ __global__ __launch_bounds__(W * (RP / 16)) void k_fft_pass(FftIo<T> io, const c
 }
 
 // ------------------------------------------------------------------------------ launchers
-// plain complex in/out with the natural batch stride and no fused option?
+// plain complex in/out with the natural batch stride and no fused option?  The input side and the
+// output side are judged separately so that e.g. fft->magnitude pays the staged path only in its
+// last pass.
 template <typename T>
-static bool io_is_generic(const FftIo<T>& io)
+static bool io_in_generic(const FftIo<T>& io)
 {
-    return io.flags != 0 || io.window_id >= 0 || io.in_scale != (T)1 || io.in_stride != io.n ||
-           io.out_stride != io.n || (io.in_valid != 0 && io.n > 4096);
+    return (io.flags & (BDSP_FFT_SHIFT_IN | FFT_IN_REAL)) != 0 ||
+           (io.window_id >= 0 && !(io.flags & FFT_WINDOW_OUT_DIV)) || io.in_scale != (T)1 ||
+           io.in_stride != io.n || (io.in_valid != 0 && io.n > 4096);
 }
+template <typename T>
+static bool io_out_generic(const FftIo<T>& io)
+{
+    return (io.flags & (BDSP_FFT_SHIFT_OUT | BDSP_FFT_MAGNITUDE | FFT_OUT_REAL | FFT_WINDOW_OUT_DIV)) != 0 ||
+           io.out_stride != io.n;
+}
+template <typename T>
+static bool io_is_generic(const FftIo<T>& io) { return io_in_generic(io) || io_out_generic(io); }
 
 template <typename T>
 static size_t wg_lds_bytes(int n)
@@ -406,7 +417,7 @@ static int launch_pass(const FftIo<T>& io, const cpx<T>* src, cpx<T>* dst, size_
     size_t tiles = (n / RP) / W;
     dim3 grid((unsigned)(tiles * batch));
     const bool rowmap = nsg == 1; // the first pass
-    const bool gen = io_is_generic(io) && (first || last);
+    const bool gen = (first && io_in_generic(io)) || (last && io_out_generic(io));
     if (first && !gen) src = reinterpret_cast<const cpx<T>*>(io.in);
     if (last && !gen) dst = reinterpret_cast<cpx<T>*>(io.out);
 #define BDSP_PASS(DIRV, RM, GENV)                                                                  \

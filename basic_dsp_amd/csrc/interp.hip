@@ -50,7 +50,8 @@ __global__ void k_interp_taps(T* __restrict__ taps, int fid, T rolloff, int conv
 template <typename T, bool CPLX>
 __global__ __launch_bounds__(256) void k_interp_table(const T* __restrict__ x, T* __restrict__ y,
                                                        const T* __restrict__ taps, long long points,
-                                                       long long new_points, int conv_len, int factor)
+                                                       long long new_points, int conv_len, int factor,
+                                                       long long skip_lo, long long skip_hi)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T* lt = reinterpret_cast<T*>(smem_raw);
@@ -58,8 +59,11 @@ __global__ __launch_bounds__(256) void k_interp_table(const T* __restrict__ x, T
     for (int k = threadIdx.x; k < ntaps * factor; k += blockDim.x) lt[k] = taps[k];
     __syncthreads();
     const long long scalar_len = (long long)ntaps * factor;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < new_points;
-         i += (long long)gridDim.x * blockDim.x) {
+    // outputs in [skip_lo, skip_hi) belong to the blocked inner kernel: walk only the two edge runs
+    const long long nskip = skip_hi > skip_lo ? skip_hi - skip_lo : 0;
+    for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < new_points - nskip;
+         g += (long long)gridDim.x * blockDim.x) {
+        const long long i = (nskip && g >= skip_lo) ? g + nskip : g;
         T sr = 0, si = 0;
         const bool edge = i < scalar_len || i + scalar_len >= new_points || new_points < 2 * scalar_len;
         if (edge) {
@@ -90,6 +94,71 @@ __global__ __launch_bounds__(256) void k_interp_table(const T* __restrict__ x, T
         if (CPLX) { y[2 * i] = sr; y[2 * i + 1] = si; }
         else y[i] = sr;
     }
+}
+
+// Inner region of the integer-factor ("simd") path, register/LDS blocked: a thread owns one input
+// position q and produces the FACTOR outputs i = FACTOR*q + s.  With c = ceil(i/f) the reference sums
+//   s = 0 :  sum_m x[q + L - 1 - m] * taps_0[m]          s > 0 :  sum_m x[q + L - m] * taps_{f-s}[m]
+// (interpolation.rs:249-273), lowest address first.  Walking n = q-L-1 .. q+L once, x[n] feeds output
+// s = 0 with tap m = q+L-1-n and outputs s > 0 with tap m = q+L-n, so each input sample is read from
+// LDS once for FACTOR outputs (the one-output-per-thread kernel re-reads it FACTOR times through L1
+// and measured 14 % of the HBM roofline on config C4).  Results cross threads through LDS so the
+// stores are contiguous.  The workgroup covers q in [q0, q0+256) of the inner region
+// [q_lo, q_hi) = positions whose FACTOR outputs are all inner outputs.
+template <typename T, bool CPLX, int FACTOR>
+__global__ __launch_bounds__(256) void k_interp_inner(const T* __restrict__ x, T* __restrict__ y,
+                                                      const T* __restrict__ taps, long long q_lo,
+                                                      long long q_hi, int conv_len, long long points)
+{
+    constexpr int E = CPLX ? 2 : 1;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int ntaps = 2 * conv_len + 1;
+    T* lt = reinterpret_cast<T*>(smem_raw);                 // [FACTOR][ntaps]
+    T* lx = lt + ((FACTOR * ntaps + 1) & ~1);               // [256 + 2L + 2][E]
+    T* lo = lx + (256 + 2 * conv_len + 2) * E;              // [256 * FACTOR][E] output staging
+    const int t = threadIdx.x;
+    const long long q0 = q_lo + (long long)blockIdx.x * 256;
+    for (int k = t; k < ntaps * FACTOR; k += 256) lt[k] = taps[k];
+    // x[q0 - L - 1 .. q0 + 255 + L]  (always in range: the inner region starts (2L+1) positions in)
+    const int span = 256 + 2 * conv_len + 2;
+    const long long xbase = q0 - conv_len - 1;
+    for (int k = t; k < span * E; k += 256) {
+        long long g = xbase * E + k;
+        lx[k] = g < points * E ? x[g] : (T)0; // the last workgroup's tile may overhang the vector
+    }
+    __syncthreads();
+    T ar[FACTOR], ai[FACTOR];
+#pragma unroll
+    for (int s = 0; s < FACTOR; ++s) { ar[s] = 0; ai[s] = 0; }
+    // local index of x[n] in lx: n - xbase = (q - q0) + (n - q) + L + 1 = t + j, j = 0 .. 2L+1
+    for (int j = 0; j <= 2 * conv_len + 1; ++j) {
+        T xr = lx[(t + j) * E], xi = CPLX ? lx[(t + j) * E + 1] : (T)0;
+        // n = q - L - 1 + j.  s = 0: m = q+L-1-n = 2L - j (valid for j <= 2L)
+        if (j <= 2 * conv_len) {
+            T w = lt[2 * conv_len - j];
+            ar[0] = ar[0] + xr * w;
+            if (CPLX) ai[0] = ai[0] + xi * w;
+        }
+        // s > 0: m = q+L-n = 2L + 1 - j (valid for j >= 1), tap vector f - s
+        if (j >= 1) {
+#pragma unroll
+            for (int s = 1; s < FACTOR; ++s) {
+                T w = lt[(FACTOR - s) * ntaps + 2 * conv_len + 1 - j];
+                ar[s] = ar[s] + xr * w;
+                if (CPLX) ai[s] = ai[s] + xi * w;
+            }
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < FACTOR; ++s) {
+        lo[(t * FACTOR + s) * E] = ar[s];
+        if (CPLX) lo[(t * FACTOR + s) * E + 1] = ai[s];
+    }
+    __syncthreads();
+    long long nq = q_hi - q0;
+    if (nq > 256) nq = 256;
+    const long long out0 = q0 * FACTOR * E, nout = nq * FACTOR * E;
+    for (long long k = t; k < nout; k += 256) y[out0 + k] = lo[k];
 }
 
 template <typename T, bool CPLX>
@@ -149,12 +218,40 @@ int interpolatef_dev(const T* in, T* out, size_t len, bool is_complex, int fid, 
         BDSP_LAUNCH_CHECK();
         size_t lds = sizeof(T) * (size_t)ntaps * f;
         if (lds > 60 * 1024) { set_last_error("interpolatef: tap table exceeds LDS"); return BDSP_ERR_UNSUPPORTED; }
+        // edges (and everything, for factors without a blocked instantiation) by the generic kernel;
+        // the inner region is then overwritten by the blocked kernel where one exists
+        const long long scalar_len = (long long)ntaps * f;
+        long long q_lo = (scalar_len + f - 1) / f;                   // first q with f*q >= scalar_len
+        long long q_hi = ((long long)new_points - scalar_len) / f;   // f*q + f - 1 < new_points - scalar_len
+        const bool blocked = (f == 2 || f == 3 || f == 4 || f == 8) && q_hi > q_lo &&
+                             (long long)new_points >= 2 * scalar_len;
+        long long edge_points = blocked ? 0 : (long long)new_points;
         if (is_complex)
             hipLaunchKernelGGL((k_interp_table<T, true>), dim3((unsigned)blocks), dim3(256), lds, s, in, out,
-                               tb.as<T>(), (long long)points, (long long)new_points, (int)conv_len, f);
+                               tb.as<T>(), (long long)points, (long long)new_points, (int)conv_len, f,
+                               blocked ? q_lo * f : -1LL, blocked ? q_hi * f : -1LL);
         else
             hipLaunchKernelGGL((k_interp_table<T, false>), dim3((unsigned)blocks), dim3(256), lds, s, in, out,
-                               tb.as<T>(), (long long)points, (long long)new_points, (int)conv_len, f);
+                               tb.as<T>(), (long long)points, (long long)new_points, (int)conv_len, f,
+                               blocked ? q_lo * f : -1LL, blocked ? q_hi * f : -1LL);
+        (void)edge_points;
+        if (blocked) {
+            BDSP_LAUNCH_CHECK();
+            const int e = is_complex ? 2 : 1;
+            size_t lds2 = sizeof(T) * (((size_t)f * ntaps + 1) / 2 * 2 + (256 + 2 * conv_len + 2) * e + 256 * (size_t)f * e);
+            unsigned g = (unsigned)((q_hi - q_lo + 255) / 256);
+#define BDSP_INNER(FV)                                                                             \
+    do {                                                                                           \
+        if (is_complex)                                                                            \
+            hipLaunchKernelGGL((k_interp_inner<T, true, FV>), dim3(g), dim3(256), lds2, s, in, out, \
+                               tb.as<T>(), q_lo, q_hi, (int)conv_len, (long long)points);          \
+        else                                                                                       \
+            hipLaunchKernelGGL((k_interp_inner<T, false, FV>), dim3(g), dim3(256), lds2, s, in, out, \
+                               tb.as<T>(), q_lo, q_hi, (int)conv_len, (long long)points);          \
+    } while (0)
+            if (f == 2) BDSP_INNER(2); else if (f == 3) BDSP_INNER(3); else if (f == 4) BDSP_INNER(4); else BDSP_INNER(8);
+#undef BDSP_INNER
+        }
     } else {
         if (is_complex)
             hipLaunchKernelGGL((k_interp_scalar<T, true>), dim3((unsigned)blocks), dim3(256), 0, s, in, out,

@@ -1,0 +1,80 @@
+#!/usr/bin/env python3
+"""Times every BASELINE.json config on one MI355X through the B3 device API (data resident in HBM)
+and prints one JSON line per config with its algorithmic-bytes roofline fraction.
+Run on the GPU box: python tools/bench_configs.py"""
+import ctypes as C, json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import basic_dsp_amd as bd
+from basic_dsp_amd._lib import FFT_SHIFT_OUT, FFT_MAGNITUDE
+lib = bd.lib
+dev = torch.device("cuda", 0)
+sp = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+flag = C.c_int(0)
+PEAK = 8000.0
+
+def timeit(fn, iters=20):
+    for i in range(3): fn(i)
+    torch.cuda.synchronize()
+    e0, e1 = lib.bdsp_hip_event_create(), lib.bdsp_hip_event_create()
+    lib.bdsp_hip_event_record(e0, sp)
+    for i in range(iters): fn(i)
+    lib.bdsp_hip_event_record(e1, sp)
+    ms = C.c_float(0); lib.bdsp_hip_event_elapsed_ms(e0, e1, C.byref(ms))
+    return ms.value / iters * 1e3
+
+def report(name, us, units, bytes_per_unit, unit_name):
+    gbs = units * bytes_per_unit / us / 1e3
+    print(json.dumps({"config": name, "us": round(us, 2), "M%s_per_s" % unit_name: round(units / us, 1),
+                      "algorithmic_GBs": round(gbs, 1), "roofline_frac": round(gbs / PEAK, 4)}))
+
+def rnd(n, dt, k=3):
+    return [torch.rand(n, device=dev, dtype=dt) * 20 - 10 for _ in range(k)]
+
+x = rnd(65536, torch.float32, 1)[0]
+us = timeit(lambda i: (lib.bdsp_hip_dev_real_scale(0, x.data_ptr(), 65536, 2.5, sp), lib.bdsp_hip_dev_real_offset(0, x.data_ptr(), 65536, 0, -1.25, sp)))
+report("C1 real f32 65536: scale+offset (2 launches, launch-bound)", us, 65536, 16, "samples")
+n = 1 << 26
+xb = rnd(n, torch.float32, 2)
+us = timeit(lambda i: lib.bdsp_hip_dev_real_scale(0, xb[i % 2].data_ptr(), n, 1.0001, sp))
+report("C1' real f32 64M: scale (bandwidth regime)", us, n, 8, "samples")
+del xb
+
+n = 1 << 20
+xs = rnd(2 * n, torch.float32); sc = torch.empty(2 * n, device=dev, dtype=torch.float32)
+us = timeit(lambda i: lib.bdsp_hip_dev_fft(0, xs[i % 3].data_ptr(), sc.data_ptr(), n, 1, FFT_MAGNITUDE, 1.0, -1, 0.0, C.byref(flag), sp))
+report("C2 complex f32 1M: plain_fft->magnitude fused (2 passes, latency-bound)", us, n, 12, "points")
+b = 64
+xs = rnd(2 * n * b, torch.float32, 2); sc = torch.empty(2 * n * b, device=dev, dtype=torch.float32)
+us = timeit(lambda i: lib.bdsp_hip_dev_fft(0, xs[i % 2].data_ptr(), sc.data_ptr(), n, b, FFT_MAGNITUDE, 1.0, -1, 0.0, C.byref(flag), sp), 10)
+report("C2x64 64 x complex f32 1M: plain_fft->magnitude fused", us, n * b, 12, "points")
+del xs, sc
+
+n, m = 1 << 24, 1024
+xs = rnd(2 * n, torch.float32); y = torch.empty(2 * n, device=dev, dtype=torch.float32)
+taps = (torch.rand(2 * m, device=dev) * 2 - 1) / m
+spec = torch.empty(2 * lib.bdsp_hip_conv_spectrum_points(), device=dev, dtype=torch.float32)
+lib.bdsp_hip_dev_conv_prepare(0, taps.data_ptr(), m, spec.data_ptr(), sp)
+us = timeit(lambda i: lib.bdsp_hip_dev_convolve_prepared(0, xs[i % 3].data_ptr(), y.data_ptr(), n, 1, spec.data_ptr(), m, sp))
+report("C3 complex f32 16M (*) 1024 taps: fused overlap-save", us, n, 16, "samples")
+us = timeit(lambda i: lib.bdsp_hip_dev_fft(0, xs[i % 3].data_ptr(), y.data_ptr(), n, 1, 0, 1.0, -1, 0.0, C.byref(flag), sp))
+report("FFT complex f32 16M: plain_fft (3 passes)", us, n, 16, "points")
+del xs, y
+
+n = 1 << 22
+xs = rnd(2 * n, torch.float64); sc = torch.empty(2 * n, device=dev, dtype=torch.float64)
+us = timeit(lambda i: lib.bdsp_hip_dev_fft(1, xs[i % 3].data_ptr(), sc.data_ptr(), n, 1, FFT_SHIFT_OUT, 1.0, 4, 0.5, C.byref(flag), sp))
+report("C4a complex f64 4M: windowed_fft(Hann) fused window+fft+shift", us, n, 32, "points")
+out = torch.empty(8 * n, device=dev, dtype=torch.float64)
+us = timeit(lambda i: lib.bdsp_hip_dev_interpolatef(1, xs[i % 3].data_ptr(), out.data_ptr(), 2 * n, 1, 1, 0.35, 4.0, 0.0, 12, 1.0, sp), 10)
+report("C4b complex f64 4M: interpolatef(RC 0.35, x4, conv_len 12)", us, n, 80, "input_points")
+del xs, sc, out
+
+n, b = 1 << 20, 64
+xs = rnd(2 * n * b, torch.float32, 2); y = torch.empty(2 * n * b, device=dev, dtype=torch.float32)
+def c5(i):
+    lib.bdsp_hip_dev_conv_prepare(0, taps.data_ptr(), m, spec.data_ptr(), sp)
+    lib.bdsp_hip_dev_convolve_prepared(0, xs[i % 2].data_ptr(), y.data_ptr(), n, b, spec.data_ptr(), m, sp)
+    lib.bdsp_hip_dev_fft(0, y.data_ptr(), xs[i % 2].data_ptr(), n, b, 0, 1.0, -1, 0.0, C.byref(flag), sp)
+us = timeit(c5, 10)
+report("C5/GPU 64 x complex f32 1M: convolve_signal -> fft (compute only)", us, n * b, 32, "samples")
