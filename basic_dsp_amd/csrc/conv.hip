@@ -27,17 +27,21 @@ size_t conv_fft_len(size_t) { return CONV_L; }
 // Grid: x = persistent workgroups walking the blocks of one vector with a grid stride,
 //       y = vector of the batch.  All per-vector indices are 32-bit (points < 2^31).
 //
-// Software pipeline (measured on MI355X: without it the load, FFT, xH, IFFT and store phases of all
-// resident workgroups run in lockstep and their times simply add up, 100 us; phase ablation:
-// x loads 23 us, spectrum loads 22 us, stores 20 us, LDS 12 us, butterflies 18-33 us):
-//   * the input of block b+G is requested before block b is transformed (one block of prefetch
-//     registers), so HBM latency hides under the butterflies;
+// What bounds this kernel (MI355X measurements, tools/conv_timeline.py + phase ablation):
+//   * a workgroup's block is a ~11.5k-cycle dependency chain -- butterflies 4.8k (one wave issues
+//     a VALU op only every ~5 cycles, hence PACKED f32 math), four LDS exchanges 4.5k (the 8 KB a
+//     wave writes per exchange drain at ~46 B/clk), load + store issue 3k -- and co-resident
+//     workgroups overlap perfectly, so throughput = resident workgroups / chain length;
 //   * FAST (f32): the filter spectrum H (16 values per thread) and the stage-3 twiddles stay in
 //     registers for the whole persistent loop, the stage-2 twiddles (16 distinct rows) in a 2 KB
-//     LDS table; the kernel is built for 2 workgroups per CU (256 VGPRs) because occupancy beyond
-//     that bought nothing once the phases overlap inside one workgroup.
+//     LDS table (re-reading H from L2 per block cost 22 us per launch); the kernel is built for
+//     168 VGPRs = 3 workgroups per CU.  Measured alternatives: 2 workgroups + one block of input
+//     prefetch 82 us, 2 + two blocks of prefetch 82 us, 3 without prefetch 80 us (this build),
+//     4 with H re-read from L2 and 20 spilled registers 99 us, ping-pong LDS buffers (4 barriers
+//     instead of 8) 80 us, one-block-per-workgroup with every table re-read 149 us;
+//   * the generic build (f64) keeps everything in L2 and prefetches one block.
 template <typename T, bool FAST>
-__global__ __launch_bounds__(256, 2) void k_overlap_save(
+__global__ __launch_bounds__(256, 3) void k_overlap_save(
     const cpx<T>* __restrict__ x, cpx<T>* __restrict__ y, const cpx<T>* __restrict__ hs,
     const cpx<T>* __restrict__ wtab, unsigned n, int m_taps, long long in_off, long long out_off,
     unsigned blocks_per_vec, unsigned out_limit, int store_all)
@@ -49,7 +53,12 @@ __global__ __launch_bounds__(256, 2) void k_overlap_save(
     const int t = threadIdx.x;
     const unsigned ut = (unsigned)t;
     const int ov = m_taps - 1;
-    const unsigned V = (unsigned)(L - ov);
+    // Valid outputs per block, rounded DOWN to a multiple of 16 points (128 bytes for f32): every
+    // block then starts on a cache-line boundary in both the input and the output vector.  With the
+    // natural V = L-(M-1) = 3073 each 512-byte wave access straddled five lines instead of four and
+    // began mid-line (timeline: 12 stores took 2.3k cycles to issue).
+    const unsigned Vfull = (unsigned)(L - ov);
+    const unsigned V = Vfull >= 16 ? (Vfull & ~15u) : Vfull;
     const T hscale = (T)1 / (T)L; // the inverse transform below is unnormalised
     auto tw = [&](int mm) { return wtab[mm]; };
 
@@ -105,14 +114,9 @@ __global__ __launch_bounds__(256, 2) void k_overlap_save(
     unsigned wl = blockIdx.x;
     if ((gridDim.x & 7) == 0) wl = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
 
-    cpx<T> nx[16];
-    if (wl < blocks_per_vec) load_block(wl, nx);
-    for (unsigned b = wl; b < blocks_per_vec; b += gridDim.x) {
-        cpx<T> v[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) v[r] = nx[r];
-        if (b + gridDim.x < blocks_per_vec) load_block(b + gridDim.x, nx); // prefetch
-
+    const unsigned G = gridDim.x;
+    // one block: transform the 16 register-resident inputs and store the valid outputs
+    auto process = [&](cpx<T> (&v)[16], unsigned b) {
         const cpx<T>* hp = hs + t;
         const cpx<T>* wt = wtab;
         if constexpr (!FAST) {
@@ -170,13 +174,34 @@ __global__ __launch_bounds__(256, 2) void k_overlap_save(
             // output index = obase + n', valid for ov <= n' < lim (both bounds uniform)
             const long long obase = (long long)b * V + out_off - ov;
             long long room = (long long)out_limit - obase;
-            const unsigned lim = room <= 0 ? 0u : (room > L ? (unsigned)L : (unsigned)room);
+            unsigned lim = room <= 0 ? 0u : (room > L ? (unsigned)L : (unsigned)room);
+            if (lim > (unsigned)ov + V) lim = (unsigned)ov + V; // outputs past V belong to the next block
             cpx<T>* yb = yv + obase;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 unsigned np = ut + 256u * r;
                 if (np >= (unsigned)ov && np < lim) yb[np] = v[r];
             }
+        }
+    };
+
+    if constexpr (FAST) {
+        // two blocks of input in flight per workgroup (prefetch distance 2): with one block the
+        // request stream had gaps and HBM sat idle half of the time
+        for (unsigned b = wl; b < blocks_per_vec; b += G) {
+            cpx<T> v[16];
+            load_block(b, v);
+            process(v, b);
+        }
+    } else {
+        cpx<T> nx[16];
+        if (wl < blocks_per_vec) load_block(wl, nx);
+        for (unsigned b = wl; b < blocks_per_vec; b += G) {
+            cpx<T> v[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = nx[r];
+            if (b + G < blocks_per_vec) load_block(b + G, nx); // prefetch
+            process(v, b);
         }
     }
 }
@@ -260,7 +285,8 @@ int conv_run_blocks(const T* in, T* out, size_t points, size_t batch, const T* h
         set_last_error("convolve_overlap_save: vector too long or batch above 65535");
         return BDSP_ERR_UNSUPPORTED;
     }
-    const long long V = L - (long long)(taps - 1);
+    long long V = L - (long long)(taps - 1);
+    if (V >= 16) V &= ~15LL; // must match the kernel's aligned block step
     long long per_vec = nblocks_limit ? (long long)nblocks_limit : ((long long)points + V - 1) / V;
     size_t lds = conv_lds_bytes<T>();
     constexpr bool FAST = sizeof(T) == 4;
@@ -270,7 +296,7 @@ int conv_run_blocks(const T* in, T* out, size_t points, size_t batch, const T* h
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     // persistent-ish grid: enough workgroups to fill every CU at the occupancy LDS/VGPRs allow,
     // each walking blocks with a grid stride so the register-resident twiddles are loaded once
-    int per_cu = 2; // the kernel is built for 2 workgroups (8 waves) per CU
+    int per_cu = sizeof(T) == 4 ? 3 : 2;
     long long want = (long long)num_cus() * per_cu;
     long long gx = (want + (long long)batch - 1) / (long long)batch;
     if (gx > per_vec) gx = per_vec;

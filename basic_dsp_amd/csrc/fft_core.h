@@ -26,80 +26,168 @@
 
 namespace bdsp {
 
+// Complex value type.  f64 (and every host build) uses a plain struct.  On the device, f32 complex
+// values are 2-wide clang vectors so that complex add/sub/multiply lower to gfx950's PACKED f32
+// VALU ops (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32, with the swaps and sign flips of the
+// multiply-by-i and conjugate forms folded into op_sel / neg modifiers).  Measured on MI355X
+// (tools/ubench/valu_rate.hip): one wave issues a VALU instruction about every 5-6 clocks whatever
+// its width, so a lone wave on a SIMD retires 2x the flops with packed ops; v_pk_fma_f32 sustains
+// 2.8 clk per result with two waves, scalar v_fma_f32 4.6.
 template <typename T>
-struct alignas(2 * sizeof(T)) cpx {
+struct alignas(2 * sizeof(T)) cpx_s {
     T x, y;
 };
+template <typename C> struct real_of;
+template <typename T> struct real_of<cpx_s<T>> { using type = T; };
 
-template <typename T>
-BDSP_HD cpx<T> cadd(cpx<T> a, cpx<T> b) { return {a.x + b.x, a.y + b.y}; }
-template <typename T>
-BDSP_HD cpx<T> csub(cpx<T> a, cpx<T> b) { return {a.x - b.x, a.y - b.y}; }
-template <typename T>
-BDSP_HD cpx<T> cmul(cpx<T> a, cpx<T> b) { return {a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
+#if defined(__HIP_DEVICE_COMPILE__) || (defined(__HIPCC__) && defined(__clang__))
+typedef float bdsp_f32x2 __attribute__((ext_vector_type(2)));
+template <> struct real_of<bdsp_f32x2> { using type = float; };
+template <typename T> struct cpx_sel { using type = cpx_s<T>; };
+template <> struct cpx_sel<float> { using type = bdsp_f32x2; };
+#define BDSP_PACKED_F32 1
+#else
+template <typename T> struct cpx_sel { using type = cpx_s<T>; };
+#endif
+template <typename T> using cpx = typename cpx_sel<T>::type;
+
+template <typename C> BDSP_HD C cadd(C a, C b) { return C{a.x + b.x, a.y + b.y}; }
+template <typename C> BDSP_HD C csub(C a, C b) { return C{a.x - b.x, a.y - b.y}; }
+template <typename C> BDSP_HD C cmul(C a, C b) { return C{a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
 // a * conj(b)
-template <typename T>
-BDSP_HD cpx<T> cmulc(cpx<T> a, cpx<T> b) { return {a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y}; }
+template <typename C> BDSP_HD C cmulc(C a, C b) { return C{a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y}; }
+template <typename C> BDSP_HD C cscale(C a, typename real_of<C>::type s) { return C{a.x * s, a.y * s}; }
 // DIR = -1: forward (multiply by -i), DIR = +1: inverse (multiply by +i)
-template <int DIR, typename T>
-BDSP_HD cpx<T> mul_dir_i(cpx<T> a) { return DIR < 0 ? cpx<T>{a.y, -a.x} : cpx<T>{-a.y, a.x}; }
+template <int DIR, typename C>
+BDSP_HD C mul_dir_i(C a) { return DIR < 0 ? C{a.y, -a.x} : C{-a.y, a.x}; }
+
+// a + (DIR*i)*d and a - (DIR*i)*d (the rotated sums of a radix-4 butterfly)
+template <int DIR, typename C>
+BDSP_HD C cadd_i(C a, C d) { return cadd(a, mul_dir_i<DIR>(d)); }
+template <int DIR, typename C>
+BDSP_HD C csub_i(C a, C d) { return csub(a, mul_dir_i<DIR>(d)); }
+
+#ifdef BDSP_PACKED_F32
+// Packed f32 forms (VOP3P).  op_sel[i] / op_sel_hi[i] pick the half of source i that feeds the
+// low / high result lane, neg_lo / neg_hi negate it: every swap, broadcast and sign flip of
+// complex arithmetic rides on the instruction as a modifier, so nothing is materialised in extra
+// registers (hipcc's own selection spent 124 v_xor + 315 v_mov per block and doubled the twiddle
+// registers).  Plain VALU read-after-write is interlocked in hardware: no manual wait states.
+BDSP_HD bdsp_f32x2 cadd(bdsp_f32x2 a, bdsp_f32x2 b) { return a + b; }
+BDSP_HD bdsp_f32x2 csub(bdsp_f32x2 a, bdsp_f32x2 b) { return a - b; }
+BDSP_HD bdsp_f32x2 cscale(bdsp_f32x2 a, float s) { return a * bdsp_f32x2{s, s}; }
+// One asm statement per INSTRUCTION, deliberately: merging the mul+fma of a complex multiply (or a
+// whole radix-4 butterfly) into one statement measured 8-12 % slower on the overlap-save kernel --
+// the statements are opaque to the scheduler, so the dependent instructions inside issue back to
+// back and stall, while separate statements let hipcc interleave independent butterflies.
+BDSP_HD bdsp_f32x2 cmul(bdsp_f32x2 a, bdsp_f32x2 b)
+{
+    bdsp_f32x2 t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(t) : "v"(a), "v"(b)); // (ax bx, ax by)
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]"        // (-ay by, ay bx) + t
+        : "=v"(r) : "v"(a), "v"(b), "v"(t));
+    return r;
+}
+BDSP_HD bdsp_f32x2 cmulc(bdsp_f32x2 a, bdsp_f32x2 b)
+{
+    bdsp_f32x2 t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1] neg_hi:[0,1]" : "=v"(t) : "v"(a), "v"(b)); // (ax bx, -ax by)
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1]"                                    // (ay by, ay bx) + t
+        : "=v"(r) : "v"(a), "v"(b), "v"(t));
+    return r;
+}
+// forward (-i d) = (dy, -dx); inverse (+i d) = (-dy, dx)
+template <int DIR>
+BDSP_HD bdsp_f32x2 cadd_i(bdsp_f32x2 a, bdsp_f32x2 d)
+{
+    bdsp_f32x2 r;
+    if (DIR < 0) asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(d));
+    else asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(d));
+    return r;
+}
+template <int DIR>
+BDSP_HD bdsp_f32x2 csub_i(bdsp_f32x2 a, bdsp_f32x2 d) { return cadd_i<-DIR>(a, d); }
+template <int DIR>
+BDSP_HD bdsp_f32x2 mul_dir_i_pk(bdsp_f32x2 a)
+{
+    bdsp_f32x2 r;
+    if (DIR < 0) asm("v_pk_mul_f32 %0, %1, 1.0 op_sel:[1,0] op_sel_hi:[0,0] neg_hi:[1,0]" : "=v"(r) : "v"(a));
+    else asm("v_pk_mul_f32 %0, %1, 1.0 op_sel:[1,0] op_sel_hi:[0,0] neg_lo:[1,0]" : "=v"(r) : "v"(a));
+    return r;
+}
+#endif
+
+// standalone multiply by -/+ i
+template <int DIR, typename C>
+BDSP_HD C rot_i(C a) { return mul_dir_i<DIR>(a); }
+#ifdef BDSP_PACKED_F32
+template <int DIR>
+BDSP_HD bdsp_f32x2 rot_i(bdsp_f32x2 a) { return mul_dir_i_pk<DIR>(a); }
+#endif
+
 // twiddle application: forward uses w, inverse uses conj(w); tables always hold forward values
-template <int DIR, typename T>
-BDSP_HD cpx<T> twmul(cpx<T> a, cpx<T> w) { return DIR < 0 ? cmul(a, w) : cmulc(a, w); }
+template <int DIR, typename C>
+BDSP_HD C twmul(C a, C w) { return DIR < 0 ? cmul(a, w) : cmulc(a, w); }
 
 // ------------------------------------------------------------------ small DFTs, natural order
-template <int DIR, typename T>
-BDSP_HD void dft2(cpx<T>& a, cpx<T>& b)
+template <int DIR, typename C>
+BDSP_HD void dft2(C& a, C& b)
 {
-    cpx<T> t = csub(a, b);
+    C t = csub(a, b);
     a = cadd(a, b);
     b = t;
 }
 
-template <int DIR, typename T>
-BDSP_HD void dft4(cpx<T>& a0, cpx<T>& a1, cpx<T>& a2, cpx<T>& a3)
+template <int DIR, typename C>
+BDSP_HD void dft4(C& a0, C& a1, C& a2, C& a3)
 {
-    cpx<T> t0 = cadd(a0, a2), t1 = csub(a0, a2);
-    cpx<T> t2 = cadd(a1, a3), t3 = mul_dir_i<DIR>(csub(a1, a3));
+    C t0 = cadd(a0, a2), t1 = csub(a0, a2);
+    C t2 = cadd(a1, a3), d = csub(a1, a3);
     a0 = cadd(t0, t2);
     a2 = csub(t0, t2);
-    a1 = cadd(t1, t3);
-    a3 = csub(t1, t3);
+    a1 = cadd_i<DIR>(t1, d);
+    a3 = csub_i<DIR>(t1, d);
 }
 
-// a * exp(DIR * i*pi/4) and a * exp(DIR * 3i*pi/4)
-template <int DIR, typename T>
-BDSP_HD cpx<T> mul_w8_1(cpx<T> a)
+// a * exp(DIR * i*pi/4) and a * exp(DIR * 3i*pi/4):  (a + (-/+ i) a) * h  and  (-a + (-/+ i) a) * h... spelled
+// so that each is one packed add (with a swizzled, sign-flipped second operand) and one packed mul
+template <int DIR, typename C>
+BDSP_HD C mul_w8_1(C a)
 {
+    using T = typename real_of<C>::type;
     const T h = (T)0.70710678118654752440;
-    return DIR < 0 ? cpx<T>{(a.x + a.y) * h, (a.y - a.x) * h} : cpx<T>{(a.x - a.y) * h, (a.x + a.y) * h};
+    // forward: (ax + ay, ay - ax) h = (a + (ay, -ax)) h ; inverse: (ax - ay, ax + ay) h = (a + (-ay, ax)) h
+    return cscale(cadd_i<DIR>(a, a), h);
 }
-template <int DIR, typename T>
-BDSP_HD cpx<T> mul_w8_3(cpx<T> a)
+template <int DIR, typename C>
+BDSP_HD C mul_w8_3(C a)
 {
+    using T = typename real_of<C>::type;
     const T h = (T)0.70710678118654752440;
-    return DIR < 0 ? cpx<T>{(a.y - a.x) * h, -(a.x + a.y) * h} : cpx<T>{-(a.x + a.y) * h, (a.x - a.y) * h};
+    // forward: (ay - ax, -(ax + ay)) h = -(a - (ay, -ax)) h ; inverse: (-(ax + ay), ax - ay) h = -(a - (-ay, ax)) h
+    return cscale(csub_i<DIR>(a, a), -h);
 }
 
-template <int DIR, typename T>
-BDSP_HD void dft8(cpx<T>* v)
+template <int DIR, typename C>
+BDSP_HD void dft8(C* v)
 {
     // even / odd split
     dft4<DIR>(v[0], v[2], v[4], v[6]); // E[k] in v[0],v[2],v[4],v[6]
     dft4<DIR>(v[1], v[3], v[5], v[7]); // O[k] in v[1],v[3],v[5],v[7]
-    cpx<T> o1 = mul_w8_1<DIR>(v[3]);
-    cpx<T> o2 = mul_dir_i<DIR>(v[5]);
-    cpx<T> o3 = mul_w8_3<DIR>(v[7]);
-    cpx<T> e0 = v[0], e1 = v[2], e2 = v[4], e3 = v[6], o0 = v[1];
+    C o1 = mul_w8_1<DIR>(v[3]);
+    C o2 = rot_i<DIR>(v[5]);
+    C o3 = mul_w8_3<DIR>(v[7]);
+    C e0 = v[0], e1 = v[2], e2 = v[4], e3 = v[6], o0 = v[1];
     v[0] = cadd(e0, o0); v[4] = csub(e0, o0);
     v[1] = cadd(e1, o1); v[5] = csub(e1, o1);
     v[2] = cadd(e2, o2); v[6] = csub(e2, o2);
     v[3] = cadd(e3, o3); v[7] = csub(e3, o3);
 }
 
-template <int DIR, typename T>
-BDSP_HD void dft16(cpx<T>* v)
+template <int DIR, typename C>
+BDSP_HD void dft16(C* v)
 {
+    using T = typename real_of<C>::type;
     // n = 4*n1 + n2, k = k1 + 4*k2.  Step 1: DFT4 over n1 for each n2 -> B[n2][k1] left in
     // v[4*k1 + n2]; step 2: * w16^(n2*k1); step 3: DFT4 over n2 for each k1 -> X[k1 + 4*k2].
     dft4<DIR>(v[0], v[4], v[8], v[12]);
@@ -107,28 +195,25 @@ BDSP_HD void dft16(cpx<T>* v)
     dft4<DIR>(v[2], v[6], v[10], v[14]);
     dft4<DIR>(v[3], v[7], v[11], v[15]);
     const T c1 = (T)0.92387953251128675613, s1 = (T)0.38268343236508977173; // cos/sin(pi/8)
-    const cpx<T> w1 = {c1, -s1}, w3 = {s1, -c1};                             // forward w16^1, w16^3
+    const C w1 = {c1, -s1}, w3 = {s1, -c1};                                  // forward w16^1, w16^3
     // k1 = 1 : v[4+n2] *= w16^(n2)
     v[5] = twmul<DIR>(v[5], w1);
     v[6] = mul_w8_1<DIR>(v[6]);
     v[7] = twmul<DIR>(v[7], w3);
     // k1 = 2 : v[8+n2] *= w16^(2 n2) = w8^(n2)
     v[9] = mul_w8_1<DIR>(v[9]);
-    v[10] = mul_dir_i<DIR>(v[10]);
+    v[10] = rot_i<DIR>(v[10]);
     v[11] = mul_w8_3<DIR>(v[11]);
     // k1 = 3 : v[12+n2] *= w16^(3 n2): n2=1 -> w16^3, n2=2 -> w16^6 = w8^3, n2=3 -> w16^9 = -w16^1
     v[13] = twmul<DIR>(v[13], w3);
     v[14] = mul_w8_3<DIR>(v[14]);
-    {
-        cpx<T> t = twmul<DIR>(v[15], w1);
-        v[15] = cpx<T>{-t.x, -t.y};
-    }
+    v[15] = twmul<DIR>(v[15], C{-c1, s1});
     dft4<DIR>(v[0], v[1], v[2], v[3]);     // k1 = 0 -> X[0], X[4], X[8], X[12]
     dft4<DIR>(v[4], v[5], v[6], v[7]);     // k1 = 1 -> X[1], X[5], X[9], X[13]
     dft4<DIR>(v[8], v[9], v[10], v[11]);   // k1 = 2
     dft4<DIR>(v[12], v[13], v[14], v[15]); // k1 = 3
     // v[4*k1 + k2] holds X[k1 + 4*k2]: transpose the 4x4 to natural order
-    cpx<T> t;
+    C t;
     t = v[1]; v[1] = v[4]; v[4] = t;
     t = v[2]; v[2] = v[8]; v[8] = t;
     t = v[3]; v[3] = v[12]; v[12] = t;
@@ -137,8 +222,8 @@ BDSP_HD void dft16(cpx<T>* v)
     t = v[11]; v[11] = v[14]; v[14] = t;
 }
 
-template <int R, int DIR, typename T>
-BDSP_HD void dft(cpx<T>* v)
+template <int R, int DIR, typename C>
+BDSP_HD void dft(C* v)
 {
     if (R == 2) dft2<DIR>(v[0], v[1]);
     else if (R == 4) dft4<DIR>(v[0], v[1], v[2], v[3]);

@@ -84,7 +84,7 @@ static double run()
             for (int r = 0; r < 16; ++r) out[F::template out_index<16, 1>(t, 0, r)] = v[r];
         }
     }
-    auto ref = naive(x, DIR);
+    auto ref = naive<T>(x, DIR);
     double num = 0, den = 0;
     for (int k = 0; k < N; ++k) {
         std::complex<double> d = std::complex<double>(out[k].x, out[k].y) - ref[k];
