@@ -74,6 +74,22 @@ def cpu_baseline(points, taps, sample_points):
     }
 
 
+def pmc_traffic(kernel_prefix):
+    """HBM bytes per launch of a kernel as measured by rocprofv3 PMC passes (FETCH_SIZE and
+    WRITE_SIZE in separate runs, gfx950 read-size correction applied) -- collected with
+    tools/pmc.sh on this same command and committed as profiles/r01_hbm_traffic.json; the live run
+    cannot collect counters itself.  None if the profile is missing."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")) as f:
+            k = json.load(f)["kernels"]
+        for name, v in k.items():
+            if name.startswith(kernel_prefix):
+                return v["hbm_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        pass
+    return None
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -187,7 +203,7 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": pmc_traffic("k_overlap_save<float") if (n, m) == (POINTS, TAPS) else None,
                 "algorithmic_bytes_per_launch": algo_bytes,
                 "avg_launch_ms": conv_avg,
                 "dominant": bool(dominant_conv),
