@@ -108,6 +108,15 @@ for _s, _t, _R in (("32", _F, VectorInteropResult32), ("64", _D, VectorInteropRe
         _proto(_n + _s, _R, _P, C.c_int32)
     _proto("zero_pad" + _s, _R, _P, _SZ, C.c_int32)
     _proto("interpolatef" + _s, _R, _P, C.c_int32, _t, _t, _t, _SZ)
+    _proto("interpolatei" + _s, _R, _P, C.c_int32, _t, C.c_int32)
+    _proto("interpolate" + _s, _R, _P, C.c_int32, _t, _SZ, _t)
+    _proto("interpft" + _s, _R, _P, _SZ)
+    _proto("decimatei" + _s, _R, _P, C.c_uint32, C.c_uint32)
+    _proto("multiply_frequency_response" + _s, _R, _P, C.c_int32, _t, _t)
+    for _n in ("plain_sfft", "sfft", "plain_sifft", "sifft"):
+        _proto(_n + _s, _R, _P)
+    for _n in ("windowed_sfft", "windowed_sifft"):
+        _proto(_n + _s, _R, _P, C.c_int32)
 
 _proto("bdsp_hip_dev_fft", _I, _I, _P, _P, _SZ, _SZ, _U, _D, _I, _D, C.POINTER(_I), _P)
 _proto("bdsp_hip_dev_convolve", _I, _I, _P, _P, _SZ, _SZ, _P, _SZ, _P)

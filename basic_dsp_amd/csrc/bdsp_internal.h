@@ -110,6 +110,8 @@ template <typename T> int ew_mul_cexp(T* x, size_t len, T a, T b, hipStream_t s)
 template <typename T> int ew_complex_to_real(const T* x, T* out, size_t len, int kind, hipStream_t s);
 template <typename T> int ew_window(T* x, size_t len, bool is_complex, int id, T alpha, bool unapply, hipStream_t s);
 template <typename T> int ew_fill(T* x, size_t len, T value, hipStream_t s);
+template <typename T> int ew_freq_response(T* x, size_t len, bool is_complex, int fid, T rolloff, T ratio, bool shifted, hipStream_t s);
+template <typename T> int ew_linear_phase(T* x, size_t len, T delay, hipStream_t s);
 
 // reorg.hip
 template <typename T> int rg_rotate(const T* in, T* out, size_t points, size_t elem, size_t shift, hipStream_t s);
@@ -117,6 +119,7 @@ template <typename T> int rg_reverse(const T* in, T* out, size_t points, size_t 
 template <typename T> int rg_zero_pad(const T* in, T* out, size_t len_before, bool is_complex, size_t points, int option, hipStream_t s);
 template <typename T> int rg_zero_interleave(const T* in, T* out, size_t len, size_t elem, size_t factor, hipStream_t s);
 template <typename T> int rg_mirror(const T* in, T* out, size_t len, hipStream_t s);
+template <typename T> int rg_decimate(const T* in, T* out, size_t out_points, size_t elem, size_t factor, size_t delay, hipStream_t s);
 
 // interp.hip
 template <typename T>

@@ -588,6 +588,161 @@ int op_window(DevVec<T>* v, int window, bool unapply)
     return ew_window<T>(v->data, v->valid_len, v->complex_, wid, alpha, unapply, lib_stream());
 }
 
+
+// ---- FFT-domain interpolation family, composed from the fused kernels -----------
+// interpolatei (interpolation.rs:484-532): zero_interleave -> plain_fft -> x frequency response on the
+// fft-shifted axis (scaled by the factor) -> plain_ifft -> scale(1/points) [-> real parts]
+template <typename T>
+int op_interpolatei(DevVec<T>* v, int fid, T rolloff, int factor)
+{
+    if (factor <= 1) return BDSP_OK;
+    hipStream_t s = lib_stream();
+    const bool was_complex = v->complex_;
+    const size_t points = v->points(), np = points * (size_t)factor;
+    if (points == 0) return BDSP_OK;
+    BDSP_TRY(v->reserve(2 * np));
+    // real input: interleave with 2*factor-1 zeros = complex with zero imaginary parts
+    BDSP_HIP_TRY(hipMemsetAsync(v->buf, 0, sizeof(T) * 2 * np, s));
+    BDSP_TRY(rg_zero_interleave<T>(v->data, v->buf, v->valid_len, was_complex ? 2 : 1,
+                                   was_complex ? (size_t)factor : 2 * (size_t)factor, s));
+    v->trade();
+    bool in_b = false;
+    BDSP_TRY(fft_two_buffers<T>(v->data, v->buf, np, 1, false, 0, (T)1, -1, (T)0, &in_b, s));
+    if (in_b) v->trade();
+    BDSP_TRY(ew_freq_response<T>(v->data, 2 * np, true, fid, rolloff, (T)factor, true, s));
+    // plain_ifft then scale(1/points): the scale rides on the inverse transform's input
+    BDSP_TRY(fft_two_buffers<T>(v->data, v->buf, np, 1, true, 0, (T)1 / (T)np, -1, (T)0, &in_b, s));
+    if (in_b) v->trade();
+    if (was_complex) {
+        v->valid_len = 2 * np;
+    } else {
+        BDSP_TRY(ew_complex_to_real<T>(v->data, v->buf, 2 * np, 2, s));
+        v->trade();
+        v->valid_len = np;
+    }
+    return BDSP_OK; // the reference does not touch delta here (interpolation.rs:484-532)
+}
+
+// interpolate / interpft (interpolation.rs:534-605).  fid < 0 = no frequency response.
+template <typename T>
+int op_interpolate(DevVec<T>* v, int fid, T rolloff, size_t dest_points, T delay)
+{
+    hipStream_t s = lib_stream();
+    const bool was_complex = v->complex_;
+    const size_t points = v->points();
+    if (points == 0 || dest_points == 0) return BDSP_ERR_ARG_LENGTH;
+    const T delta_t = v->delta;
+    const T factorf = (T)dest_points / (T)points;
+    const size_t maxp = points > dest_points ? points : dest_points;
+    BDSP_TRY(v->reserve(2 * maxp));
+    if (!was_complex) {
+        BDSP_TRY(rg_zero_interleave<T>(v->data, v->buf, points, 1, 2, s));
+        v->trade();
+    }
+    bool in_b = false;
+    BDSP_TRY(fft_two_buffers<T>(v->data, v->buf, points, 1, false, 0, (T)1, -1, (T)0, &in_b, s));
+    if (in_b) v->trade();
+    if (delay != (T)0) BDSP_TRY(ew_linear_phase<T>(v->data, 2 * points, delay / delta_t, s));
+    if (dest_points > points) {
+        BDSP_TRY(rg_zero_pad<T>(v->data, v->buf, 2 * points, true, dest_points, 2, s));
+        v->trade();
+        if (fid < 0) BDSP_TRY(ew_real_scale<T>(v->data, 2 * dest_points, factorf, s));
+        else BDSP_TRY(ew_freq_response<T>(v->data, 2 * dest_points, true, fid, rolloff, factorf, true, s));
+    } else if (dest_points < points) {
+        // interpolate_downsample (:362-376): keep the first pos and the last neg bins
+        const size_t neg = dest_points / 2, pos = dest_points - neg;
+        BDSP_HIP_TRY(hipMemcpyAsync(v->buf, v->data, sizeof(T) * 2 * pos, hipMemcpyDeviceToDevice, s));
+        BDSP_HIP_TRY(hipMemcpyAsync(v->buf + 2 * pos, v->data + 2 * (points - neg), sizeof(T) * 2 * neg,
+                                    hipMemcpyDeviceToDevice, s));
+        v->trade();
+        BDSP_TRY(ew_real_scale<T>(v->data, 2 * dest_points, (T)(2 * dest_points) / (T)(2 * points), s));
+    }
+    BDSP_TRY(fft_two_buffers<T>(v->data, v->buf, dest_points, 1, true, 0, (T)1 / (T)dest_points, -1, (T)0, &in_b, s));
+    if (in_b) v->trade();
+    v->delta = delta_t / factorf;
+    if (was_complex) {
+        v->valid_len = 2 * dest_points;
+    } else {
+        BDSP_TRY(ew_complex_to_real<T>(v->data, v->buf, 2 * dest_points, 2, s));
+        v->trade();
+        v->valid_len = dest_points;
+    }
+    return BDSP_OK;
+}
+
+template <typename T>
+int op_decimatei(DevVec<T>* v, unsigned factor, unsigned delay)
+{
+    if (factor == 0) return BDSP_ERR_ARG_LENGTH;
+    const size_t elem = v->complex_ ? 2 : 1, points = v->points();
+    const size_t outp = delay < points ? (points - delay + factor - 1) / factor : 0;
+    if (outp) {
+        BDSP_TRY(rg_decimate<T>(v->data, v->buf, outp, elem, factor, delay, lib_stream()));
+        v->trade();
+    }
+    v->valid_len = outp * elem;
+    return BDSP_OK;
+}
+
+template <typename T>
+int op_multiply_frequency_response(DevVec<T>* v, int fid, T rolloff, T ratio)
+{
+    if (!v->freq) { v->poison(); return BDSP_OK; } // convolution.rs:590-593
+    return ew_freq_response<T>(v->data, v->valid_len, v->complex_, fid, rolloff, ratio, false, lib_stream());
+}
+
+// Symmetric real FFT family (time_to_freq.rs:188-298, freq_to_time.rs:180-248): a real vector of odd
+// length -> the non-redundant half spectrum (points/2 + 1 bins), and back.
+template <typename T>
+int op_sfft(DevVec<T>* v, bool shift, int window)
+{
+    if (v->freq || v->complex_) { v->poison(); v->complex_ = true; v->freq = true; return BDSP_ERR_MUST_BE_TIME; }
+    const size_t points = v->valid_len;
+    if (points % 2 == 0) { v->poison(); v->complex_ = true; v->freq = true; return BDSP_ERR_ODD_LENGTH; }
+    BDSP_TRY(op_fft<T>(v, false, shift, window));
+    if (!shift) v->valid_len = 2 * (points / 2 + 1); // unmirror! (time_to_freq.rs:178-186)
+    else {
+        // fft() is shifted: the non-negative frequencies are the LAST points/2+1 bins; the reference
+        // truncates the shifted vector to its first points/2+1 bins (unmirror! after fft_shift), i.e.
+        // it keeps the negative half plus DC -- we do the same
+        v->valid_len = 2 * (points / 2 + 1);
+    }
+    return BDSP_OK;
+}
+
+template <typename T>
+int op_sifft(DevVec<T>* v, bool shift, int window)
+{
+    if (!v->freq || !v->complex_) { v->poison(); v->complex_ = true; v->freq = true; return BDSP_ERR_MUST_BE_FREQ; }
+    hipStream_t s = lib_stream();
+    if (v->points() > 0) {
+        // The first bin must be real (freq_to_time.rs:203-211 tests |im| > 1e-10).  A spectrum that
+        // was COMPUTED (e.g. by plain_sfft through Bluestein) carries rounding noise of a few
+        // eps * |X| there, so the absolute test is paired with a relative one against the first bins.
+        T h[4] = {0, 0, 0, 0};
+        size_t nh = v->valid_len < 4 ? v->valid_len : 4;
+        BDSP_HIP_TRY(hipMemcpyAsync(h, v->data, sizeof(T) * nh, hipMemcpyDeviceToHost, s));
+        BDSP_HIP_TRY(hipStreamSynchronize(s));
+        double im0 = std::fabs((double)h[1]);
+        double scale = std::fabs((double)h[0]) + std::fabs((double)h[2]) + std::fabs((double)h[3]);
+        if (im0 > 1e-10 && im0 > 1e-3 * scale) {
+            v->poison(); v->complex_ = true; v->freq = true;
+            return BDSP_ERR_CONJ_SYMMETRIC;
+        }
+    }
+    if (shift) {
+        // sifft: scale(1/points) and ifft_shift BEFORE mirroring (freq_to_time.rs:226-236)
+        const size_t p = v->points();
+        if (p) BDSP_TRY(ew_real_scale<T>(v->data, v->valid_len, (T)1 / (T)p, s));
+        BDSP_TRY(op_swap<T>(v, false));
+    }
+    BDSP_TRY(op_mirror<T>(v));
+    BDSP_TRY(op_fft<T>(v, true, false, -1));
+    BDSP_TRY(op_complex_to_real<T>(v, 2));
+    if (shift && window >= 0) BDSP_TRY(op_window<T>(v, window, true));
+    return BDSP_OK;
+}
+
 template <typename T>
 const T* vec_download(DevVec<T>* v)
 {
@@ -741,7 +896,23 @@ size_t bdsp_hip_overlap_discard_f64(double* x_time, size_t x_len, double* tmp, s
     RES convolve_signal##SFX(VB* vector, const VB* impulse_response)                                        \
     { DevVec<T>* v = H<T>(vector); return finish<T>(v, op_convolve_signal<T>(v, H<T>(impulse_response))); } \
     RES interpolatef##SFX(VB* vector, int32_t impulse_response, T rolloff, T interpolation_factor, T delay, size_t conv_len) \
-    { DevVec<T>* v = H<T>(vector); return finish<T>(v, op_interpolatef<T>(v, impulse_response == 0 ? 0 : 1, rolloff, interpolation_factor, delay, conv_len)); }
+    { DevVec<T>* v = H<T>(vector); return finish<T>(v, op_interpolatef<T>(v, impulse_response == 0 ? 0 : 1, rolloff, interpolation_factor, delay, conv_len)); } \
+    RES interpolatei##SFX(VB* vector, int32_t frequency_response, T rolloff, int32_t interpolation_factor)  \
+    { DevVec<T>* v = H<T>(vector); return finish<T>(v, op_interpolatei<T>(v, frequency_response == 0 ? 0 : 1, rolloff, interpolation_factor)); } \
+    RES interpolate##SFX(VB* vector, int32_t frequency_response, T rolloff, size_t dest_points, T delay)    \
+    { DevVec<T>* v = H<T>(vector); return finish<T>(v, op_interpolate<T>(v, frequency_response == 0 ? 0 : 1, rolloff, dest_points, delay)); } \
+    RES interpft##SFX(VB* vector, size_t dest_points)                                                       \
+    { DevVec<T>* v = H<T>(vector); return finish<T>(v, op_interpolate<T>(v, -1, (T)0, dest_points, (T)0)); } \
+    RES decimatei##SFX(VB* vector, uint32_t decimation_factor, uint32_t delay)                              \
+    { DevVec<T>* v = H<T>(vector); return finish<T>(v, op_decimatei<T>(v, decimation_factor, delay)); }     \
+    RES multiply_frequency_response##SFX(VB* vector, int32_t frequency_response, T rolloff, T ratio)        \
+    { DevVec<T>* v = H<T>(vector); return finish<T>(v, op_multiply_frequency_response<T>(v, frequency_response == 0 ? 0 : 1, rolloff, ratio)); } \
+    RES plain_sfft##SFX(VB* vector) { DevVec<T>* v = H<T>(vector); return finish<T>(v, op_sfft<T>(v, false, -1)); } \
+    RES sfft##SFX(VB* vector) { DevVec<T>* v = H<T>(vector); return finish<T>(v, op_sfft<T>(v, true, -1)); } \
+    RES windowed_sfft##SFX(VB* vector, int32_t window) { DevVec<T>* v = H<T>(vector); return finish<T>(v, op_sfft<T>(v, true, window < 0 ? 3 : window)); } \
+    RES plain_sifft##SFX(VB* vector) { DevVec<T>* v = H<T>(vector); return finish<T>(v, op_sifft<T>(v, false, -1)); } \
+    RES sifft##SFX(VB* vector) { DevVec<T>* v = H<T>(vector); return finish<T>(v, op_sifft<T>(v, true, -1)); } \
+    RES windowed_sifft##SFX(VB* vector, int32_t window) { DevVec<T>* v = H<T>(vector); return finish<T>(v, op_sifft<T>(v, true, window < 0 ? 3 : window)); }
 
 BDSP_FACADE(32, float, VecBuf32, VectorInteropResult32)
 BDSP_FACADE(64, double, VecBuf64, VectorInteropResult64)

@@ -71,4 +71,26 @@ __device__ __forceinline__ T conv_time_value(int id, T rolloff, T x)
     return dev_sin(pi_x) * dev_cos(pi_x * rolloff) / pi_x / (one - (arg * arg));
 }
 
+// frequency-domain forms (conv_types.rs:434-449, 498-505) and the axis mapping of a spectrum in
+// fft-shifted or natural order (time_freq/mod.rs:67-77)
+template <typename T>
+__device__ __forceinline__ T conv_freq_value(int id, T rolloff, T x)
+{
+    const T one = (T)1, two = (T)2, pi = (T)3.14159265358979323846;
+    T ax = dev_abs(x);
+    if (id == 0) return ax <= one ? one : (T)0;
+    if (ax <= (one - rolloff)) return one;
+    if (((one - rolloff) < ax) && (ax <= (one + rolloff)))
+        return one / two * (one + dev_cos(pi / rolloff * (ax - (one - rolloff)) / two));
+    return (T)0;
+}
+
+template <typename T>
+__device__ __forceinline__ T fft_swap_x(bool is_fft_shifted, T x_value, T x_max)
+{
+    if (!is_fft_shifted) return x_value / x_max;
+    if (x_value <= (T)0) return (T)1 + x_value / x_max;
+    return -(x_max - x_value + (T)1) / x_max;
+}
+
 } // namespace bdsp

@@ -157,6 +157,45 @@ template <typename T> struct OpWindow {
         }
     }
 };
+// multiply_function_priv, symmetric functions (time_freq/mod.rs:655-721): element i takes the value
+// of the function on the negative half of the axis, j = -|i - center|.
+template <typename T> struct OpFreqResp {
+    struct Params { int id; T rolloff; T ratio; size_t points; int is_complex; int shifted; };
+    static __device__ __forceinline__ void apply(T* e, int n, size_t i0, Params p)
+    {
+        const size_t offset = p.points % 2;
+        const T maxv = (T)(p.points - offset) / (T)2;
+        const int step = p.is_complex ? 2 : 1;
+        for (int i = 0; i + step - 1 < n; i += step) {
+            T j = -maxv + (T)((i0 + i) / step);
+            if (j > (T)0) j = -j;
+            T arg = p.ratio * conv_freq_value<T>(p.id, p.rolloff, fft_swap_x<T>(p.shifted != 0, j, maxv) * p.ratio);
+            if (p.is_complex) {
+                T re = e[i], im = e[i + 1];
+                e[i] = re * arg - im * (T)0;
+                e[i + 1] = re * (T)0 + im * arg;
+            } else e[i] = e[i] * arg;
+        }
+    }
+};
+// apply_linear_phase (interpolation.rs:319-339): bins below pos_points get phase_inc*k, the rest
+// phase_inc*(k - points); every element evaluates its own phase (the reference runs two running
+// products, compared with tolerance).
+template <typename T> struct OpLinearPhase {
+    struct Params { double phase_inc; size_t points; size_t pos_points; };
+    static __device__ __forceinline__ void apply(T* e, int n, size_t i0, Params p)
+    {
+        for (int i = 0; i + 1 < n; i += 2) {
+            size_t k = (i0 + i) / 2;
+            double kk = k < p.pos_points ? (double)k : (double)k - (double)p.points;
+            double s, c;
+            sincos(p.phase_inc * kk, &s, &c);
+            T wr = (T)c, wi = (T)s, zr = e[i], zi = e[i + 1];
+            e[i] = zr * wr - zi * wi;
+            e[i + 1] = zr * wi + zi * wr;
+        }
+    }
+};
 template <typename T> struct OpFill {
     struct Params { T v; };
     static __device__ __forceinline__ void apply(T* e, int n, size_t, Params p)
@@ -188,6 +227,18 @@ template <typename T> int ew_window(T* x, size_t len, bool is_complex, int id, T
 }
 template <typename T> int ew_fill(T* x, size_t len, T value, hipStream_t s)
 { return launch_map<T, OpFill<T>>(x, len, {value}, s); }
+template <typename T> int ew_freq_response(T* x, size_t len, bool is_complex, int fid, T rolloff, T ratio, bool shifted, hipStream_t s)
+{
+    size_t points = is_complex ? len / 2 : len;
+    return launch_map<T, OpFreqResp<T>>(x, len, {fid, rolloff, ratio, points, (int)is_complex, (int)shifted}, s);
+}
+template <typename T> int ew_linear_phase(T* x, size_t len, T delay, hipStream_t s)
+{
+    // phase_inc = 2*pi*delay/points computed in T like the reference, then widened
+    size_t points = len / 2, pos = points / 2;
+    T phase_inc = (T)2 * (T)3.14159265358979323846 * delay / (T)points;
+    return launch_map<T, OpLinearPhase<T>>(x, len, {(double)phase_inc, points, pos}, s);
+}
 
 // ---- binary vector (.) vector, in place on x (elementary.rs:540-589) ------------------------------
 template <typename T, int OP, bool CPLX>
@@ -304,7 +355,9 @@ template <typename T> int ew_complex_to_real(const T* x, T* out, size_t len, int
     template int ew_mul_cexp<T>(T*, size_t, T, T, hipStream_t);                                    \
     template int ew_complex_to_real<T>(const T*, T*, size_t, int, hipStream_t);                    \
     template int ew_window<T>(T*, size_t, bool, int, T, bool, hipStream_t);                        \
-    template int ew_fill<T>(T*, size_t, T, hipStream_t);
+    template int ew_fill<T>(T*, size_t, T, hipStream_t);                                            \
+    template int ew_freq_response<T>(T*, size_t, bool, int, T, T, bool, hipStream_t);              \
+    template int ew_linear_phase<T>(T*, size_t, T, hipStream_t);
 BDSP_INST(float)
 BDSP_INST(double)
 #undef BDSP_INST

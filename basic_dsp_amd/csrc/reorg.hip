@@ -87,6 +87,25 @@ __global__ __launch_bounds__(256) void k_mirror(const cpx<T>* __restrict__ in, c
     }
 }
 
+// decimatei (interpolation.rs:607-633): out[j] = in[delay + j*factor]
+template <typename T>
+__global__ __launch_bounds__(256) void k_decimate(const T* __restrict__ in, T* __restrict__ out, size_t out_points,
+                                                   size_t elem, size_t factor, size_t delay)
+{
+    size_t total = out_points * elem;
+    for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (size_t)gridDim.x * blockDim.x) {
+        size_t j = g / elem, e = g % elem;
+        out[g] = in[(delay + j * factor) * elem + e];
+    }
+}
+template <typename T> int rg_decimate(const T* in, T* out, size_t out_points, size_t elem, size_t factor, size_t delay, hipStream_t s)
+{
+    if (out_points == 0) return BDSP_OK;
+    hipLaunchKernelGGL((k_decimate<T>), dim3(rg_grid(out_points * elem)), dim3(256), 0, s, in, out, out_points, elem, factor, delay);
+    BDSP_LAUNCH_CHECK();
+    return BDSP_OK;
+}
+
 template <typename T> int rg_rotate(const T* in, T* out, size_t points, size_t elem, size_t shift, hipStream_t s)
 {
     if (points == 0) return BDSP_OK;
@@ -142,7 +161,8 @@ template <typename T> int rg_mirror(const T* in, T* out, size_t len, hipStream_t
     template int rg_reverse<T>(const T*, T*, size_t, size_t, hipStream_t);                         \
     template int rg_zero_pad<T>(const T*, T*, size_t, bool, size_t, int, hipStream_t);             \
     template int rg_zero_interleave<T>(const T*, T*, size_t, size_t, size_t, hipStream_t);         \
-    template int rg_mirror<T>(const T*, T*, size_t, hipStream_t);
+    template int rg_mirror<T>(const T*, T*, size_t, hipStream_t);                                  \
+    template int rg_decimate<T>(const T*, T*, size_t, size_t, size_t, size_t, hipStream_t);
 BDSP_INST(float)
 BDSP_INST(double)
 #undef BDSP_INST

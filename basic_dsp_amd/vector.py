@@ -212,6 +212,41 @@ class DspVec:
     def convolve_signal(self, impulse_response):
         return self._call("convolve_signal", impulse_response._h)
 
+    def interpolatei(self, function, interpolation_factor, rolloff=0.0):
+        return self._call("interpolatei", int(function), rolloff, int(interpolation_factor))
+
+    def interpolate(self, function, dest_points, delay=0.0, rolloff=0.0):
+        if function is None:
+            return self._call("interpft", int(dest_points))
+        return self._call("interpolate", int(function), rolloff, int(dest_points), delay)
+
+    def interpft(self, dest_points):
+        return self._call("interpft", int(dest_points))
+
+    def decimatei(self, decimation_factor, delay):
+        return self._call("decimatei", int(decimation_factor), int(delay))
+
+    def multiply_frequency_response(self, function, ratio, rolloff=0.0):
+        return self._call("multiply_frequency_response", int(function), rolloff, ratio)
+
+    def plain_sfft(self):
+        return self._call("plain_sfft")
+
+    def sfft(self):
+        return self._call("sfft")
+
+    def windowed_sfft(self, window):
+        return self._call("windowed_sfft", int(window))
+
+    def plain_sifft(self):
+        return self._call("plain_sifft")
+
+    def sifft(self):
+        return self._call("sifft")
+
+    def windowed_sifft(self, window):
+        return self._call("windowed_sifft", int(window))
+
     def interpolatef(self, function, interpolation_factor, delay, conv_len, rolloff=0.0):
         return self._call("interpolatef", int(function), rolloff, interpolation_factor, delay,
                           int(conv_len))

@@ -194,6 +194,22 @@ VectorInteropResult32 convolve_signal32(VecBuf32 *vector, const VecBuf32 *impuls
 VectorInteropResult32 interpolatef32(VecBuf32 *vector, int32_t impulse_response, float rolloff,
                                      float interpolation_factor, float delay, size_t conv_len); /* :1334-1348 */
 
+/* FFT-domain interpolation family and the symmetric (real, odd-length) transforms */
+VectorInteropResult32 interpolatei32(VecBuf32 *vector, int32_t frequency_response, float rolloff,
+                                     int32_t interpolation_factor);            /* facade32.rs:1426-1434 */
+VectorInteropResult32 interpolate32(VecBuf32 *vector, int32_t frequency_response, float rolloff,
+                                    size_t dest_points, float delay);          /* facade32.rs:1378-1387 */
+VectorInteropResult32 interpft32(VecBuf32 *vector, size_t dest_points);        /* facade32.rs:1390-1395 */
+VectorInteropResult32 decimatei32(VecBuf32 *vector, uint32_t decimation_factor, uint32_t delay); /* facade32.rs:1147-1153 */
+VectorInteropResult32 multiply_frequency_response32(VecBuf32 *vector, int32_t frequency_response,
+                                                    float rolloff, float ratio); /* facade32.rs:1293-1301 */
+VectorInteropResult32 plain_sfft32(VecBuf32 *vector);                          /* facade32.rs:677-679 */
+VectorInteropResult32 sfft32(VecBuf32 *vector);                                /* facade32.rs:939-941 */
+VectorInteropResult32 windowed_sfft32(VecBuf32 *vector, int32_t window);       /* facade32.rs:1004-1007 */
+VectorInteropResult32 plain_sifft32(VecBuf32 *vector);                         /* facade32.rs:949-951 */
+VectorInteropResult32 sifft32(VecBuf32 *vector);                               /* facade32.rs:954-956 */
+VectorInteropResult32 windowed_sifft32(VecBuf32 *vector, int32_t window);      /* facade32.rs:1018-1024 */
+
 VecBuf64 *new64(int32_t is_complex, int32_t domain, double init_value, size_t length, double delta);
 VecBuf64 *new_with_performance_options64(int32_t is_complex, int32_t domain, double init_value,
                                          size_t length, double delta, size_t core_limit,
@@ -244,6 +260,21 @@ VectorInteropResult64 windowed_ifft64(VecBuf64 *vector, int32_t window);
 VectorInteropResult64 convolve_signal64(VecBuf64 *vector, const VecBuf64 *impulse_response);
 VectorInteropResult64 interpolatef64(VecBuf64 *vector, int32_t impulse_response, double rolloff,
                                      double interpolation_factor, double delay, size_t conv_len);
+
+VectorInteropResult64 interpolatei64(VecBuf64 *vector, int32_t frequency_response, double rolloff,
+                                     int32_t interpolation_factor);
+VectorInteropResult64 interpolate64(VecBuf64 *vector, int32_t frequency_response, double rolloff,
+                                    size_t dest_points, double delay);
+VectorInteropResult64 interpft64(VecBuf64 *vector, size_t dest_points);
+VectorInteropResult64 decimatei64(VecBuf64 *vector, uint32_t decimation_factor, uint32_t delay);
+VectorInteropResult64 multiply_frequency_response64(VecBuf64 *vector, int32_t frequency_response,
+                                                    double rolloff, double ratio);
+VectorInteropResult64 plain_sfft64(VecBuf64 *vector);
+VectorInteropResult64 sfft64(VecBuf64 *vector);
+VectorInteropResult64 windowed_sfft64(VecBuf64 *vector, int32_t window);
+VectorInteropResult64 plain_sifft64(VecBuf64 *vector);
+VectorInteropResult64 sifft64(VecBuf64 *vector);
+VectorInteropResult64 windowed_sifft64(VecBuf64 *vector, int32_t window);
 
 /* Device pointer of the handle's live buffer (valid until the next mutating call); lets the
  * batch driver feed RCCL without a host round trip.  No reference counterpart. */

@@ -771,3 +771,120 @@ void SFX(orc_interpolatef)(const REAL *x, size_t len, int is_complex, int fid, R
         SFX(interp_scalar)(out, new_len / elem, x, points, elem, fid, rolloff, factor, delay,
                            conv_len);
 }
+
+/* ------------------------------------------------------------------------------------------
+ * a14: FFT-domain interpolation family (time_freq/interpolation.rs:319-376, 484-633) and
+ * multiply_function_priv (time_freq/mod.rs:612-723), fft_swap_x (mod.rs:67-77).
+ * ---------------------------------------------------------------------------------------- */
+static REAL SFX(fft_swap_x)(int is_fft_shifted, REAL x_value, REAL x_max)
+{
+    if (!is_fft_shifted) return x_value / x_max;
+    if (x_value <= (REAL)0) return (REAL)1 + x_value / x_max;
+    return -(x_max - x_value + (REAL)1) / x_max;
+}
+
+/* multiply_function_priv for a SYMMETRIC function (all built-in responses are): the function is
+ * evaluated on the negative half of the axis, j = -center + i, and the same value multiplies the
+ * mirrored element (mod.rs:655-721) => element i uses j = -|i - center|,
+ * center = max = (points - points%2)/2.  value *= ratio * f(fft_swap_x(j, max) * ratio). */
+void SFX(orc_multiply_frequency_response)(REAL *x, size_t len, int is_complex, int fid, REAL rolloff,
+                                          REAL ratio, int is_fft_shifted)
+{
+    size_t elem = is_complex ? 2 : 1, points = len / elem;
+    size_t offset = points % 2;
+    REAL maxv = (REAL)(points - offset) / (REAL)2;
+    for (size_t i = 0; i < points; ++i) {
+        REAL j = -maxv + (REAL)i;
+        if (j > (REAL)0) j = -j; /* mirrored element reuses the value of its negative-axis partner */
+        REAL f = SFX(orc_conv_freq)(fid, rolloff, SFX(fft_swap_x)(is_fft_shifted, j, maxv) * ratio);
+        REAL arg = ratio * f;
+        if (is_complex) {
+            /* Complex * Complex::new(arg, 0) */
+            REAL re = x[2 * i], im = x[2 * i + 1];
+            x[2 * i] = re * arg - im * (REAL)0;
+            x[2 * i + 1] = re * (REAL)0 + im * arg;
+        } else {
+            x[i] = x[i] * arg;
+        }
+    }
+}
+
+/* apply_linear_phase (interpolation.rs:319-339): two running-product complex exponentials */
+static void SFX(apply_linear_phase)(REAL *x, size_t len, REAL delay)
+{
+    const REAL pi = (REAL)M_PI, two = (REAL)2;
+    size_t points = len / 2, pos_points = points / 2, neg_points = points - pos_points;
+    REAL phase_inc = two * pi * delay / (REAL)points;
+    REAL start = -(REAL)neg_points * phase_inc;
+    SFX(orc_multiply_complex_exponential)(x + 2 * pos_points, len - 2 * pos_points, phase_inc, start, (REAL)1);
+    SFX(orc_multiply_complex_exponential)(x, 2 * pos_points, phase_inc, (REAL)0, (REAL)1);
+}
+
+/* interpolatei (interpolation.rs:484-532).  out holds len*factor scalars.  Returns 0 or 10. */
+int SFX(orc_interpolatei)(const REAL *x, size_t len, int is_complex, int fid, REAL rolloff,
+                          unsigned factor, REAL *out)
+{
+    if (factor <= 1) { memcpy(out, x, len * sizeof(REAL)); return 0; }
+    size_t points = is_complex ? len / 2 : len;
+    size_t np = points * factor;
+    REAL *c = (REAL *)calloc(2 * np, sizeof(REAL));
+    for (size_t i = 0; i < points; ++i) {
+        c[2 * i * factor] = is_complex ? x[2 * i] : x[i];
+        c[2 * i * factor + 1] = is_complex ? x[2 * i + 1] : (REAL)0;
+    }
+    SFX(orc_fft)(c, np, 0);
+    SFX(orc_multiply_frequency_response)(c, 2 * np, 1, fid, rolloff, (REAL)factor, 1);
+    SFX(orc_fft)(c, np, 1);
+    SFX(orc_real_scale)(c, 2 * np, (REAL)1 / (REAL)np);
+    if (is_complex) memcpy(out, c, 2 * np * sizeof(REAL));
+    else for (size_t i = 0; i < np; ++i) out[i] = c[2 * i];
+    free(c);
+    return 0;
+}
+
+/* interpolate / interpft (interpolation.rs:534-605).  fid < 0: no frequency response (interpft).
+ * out holds dest_points*(is_complex?2:1) scalars; *delta_out = delta / (dest_points/points). */
+int SFX(orc_interpolate)(const REAL *x, size_t len, int is_complex, int fid, REAL rolloff,
+                         size_t dest_points, REAL delay, REAL delta, REAL *out, REAL *delta_out)
+{
+    size_t points = is_complex ? len / 2 : len;
+    size_t dest_len = is_complex ? 2 * dest_points : dest_points;
+    REAL factorf = (REAL)dest_points / (REAL)points;
+    size_t maxp = points > dest_points ? points : dest_points;
+    REAL *c = (REAL *)calloc(2 * maxp, sizeof(REAL));
+    for (size_t i = 0; i < points; ++i) {
+        c[2 * i] = is_complex ? x[2 * i] : x[i];
+        c[2 * i + 1] = is_complex ? x[2 * i + 1] : (REAL)0;
+    }
+    SFX(orc_fft)(c, points, 0);
+    if (delay != (REAL)0) SFX(apply_linear_phase)(c, 2 * points, delay / delta);
+    if (dest_len > len) {
+        REAL *p = (REAL *)malloc(2 * dest_points * sizeof(REAL));
+        SFX(orc_zero_pad)(c, 2 * points, 1, dest_points, 2, 0, p);
+        memcpy(c, p, 2 * dest_points * sizeof(REAL));
+        free(p);
+        if (fid < 0) SFX(orc_real_scale)(c, 2 * dest_points, factorf);
+        else SFX(orc_multiply_frequency_response)(c, 2 * dest_points, 1, fid, rolloff, factorf, 1);
+    } else if (dest_len < len) {
+        /* interpolate_downsample (:362-376) */
+        size_t orig_len = 2 * points, neg_points = dest_points / 2, pos_points = dest_points - neg_points;
+        memmove(c + 2 * pos_points, c + orig_len - 2 * neg_points, 2 * neg_points * sizeof(REAL));
+        SFX(orc_real_scale)(c, 2 * dest_points, (REAL)(2 * dest_points) / (REAL)orig_len);
+    }
+    SFX(orc_fft)(c, dest_points, 1);
+    SFX(orc_real_scale)(c, 2 * dest_points, (REAL)1 / (REAL)dest_points);
+    if (delta_out) *delta_out = delta / factorf;
+    if (is_complex) memcpy(out, c, 2 * dest_points * sizeof(REAL));
+    else for (size_t i = 0; i < dest_points; ++i) out[i] = c[2 * i];
+    free(c);
+    return 0;
+}
+
+/* decimatei (interpolation.rs:607-633): out[j] = in[delay + j*factor]; returns new len (scalars) */
+size_t SFX(orc_decimatei)(const REAL *x, size_t len, int is_complex, unsigned factor, unsigned delay, REAL *out)
+{
+    size_t elem = is_complex ? 2 : 1, points = len / elem, j = 0;
+    for (size_t i = delay; i < points; i += factor, ++j)
+        for (size_t e = 0; e < elem; ++e) out[j * elem + e] = x[i * elem + e];
+    return j * elem;
+}

@@ -243,3 +243,33 @@ def next_power_of_two(v):
     fn = lib.orc_next_power_of_two_f32
     fn.argtypes = [C.c_size_t]; fn.restype = C.c_size_t
     return fn(v)
+
+
+def multiply_frequency_response(x, is_complex, fid, rolloff, ratio, is_fft_shifted=False):
+    y = np.array(x, copy=True); fn = _fn("orc_multiply_frequency_response", y.dtype); r = _real(y.dtype)
+    fn.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, r, r, C.c_int]; fn.restype = None
+    fn(_p(y), y.size, int(is_complex), fid, rolloff, ratio, int(is_fft_shifted)); return y
+
+
+def interpolatei(x, is_complex, fid, rolloff, factor):
+    x = np.ascontiguousarray(x); out = np.zeros(x.size * max(factor, 1), dtype=x.dtype)
+    fn = _fn("orc_interpolatei", x.dtype); r = _real(x.dtype)
+    fn.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, r, C.c_uint, C.c_void_p]; fn.restype = C.c_int
+    code = fn(_p(x), x.size, int(is_complex), fid, rolloff, factor, _p(out)); return code, out
+
+
+def interpolate(x, is_complex, fid, rolloff, dest_points, delay=0.0, delta=1.0):
+    """fid < 0: no frequency response (interpft). returns (code, out, new_delta)"""
+    x = np.ascontiguousarray(x); e = 2 if is_complex else 1
+    out = np.zeros(dest_points * e, dtype=x.dtype); r = _real(x.dtype); nd = r(0)
+    fn = _fn("orc_interpolate", x.dtype)
+    fn.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, r, C.c_size_t, r, r, C.c_void_p, C.POINTER(r)]
+    fn.restype = C.c_int
+    code = fn(_p(x), x.size, int(is_complex), fid, rolloff, dest_points, delay, delta, _p(out), C.byref(nd))
+    return code, out, nd.value
+
+
+def decimatei(x, is_complex, factor, delay):
+    x = np.ascontiguousarray(x); out = np.zeros_like(x); fn = _fn("orc_decimatei", x.dtype)
+    fn.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_uint, C.c_uint, C.c_void_p]; fn.restype = C.c_size_t
+    n = fn(_p(x), x.size, int(is_complex), factor, delay, _p(out)); return out[:n]

@@ -437,3 +437,75 @@ def test_b3_device_pointer_api():
     assert lib.bdsp_hip_dev_real_offset(0, d.data_ptr(), 2 * n, 0, -1.25, sp) == 0
     torch.cuda.synchronize()
     assert np.array_equal(d.cpu().numpy(), orc.real_offset(orc.real_scale(x, 2.5), -1.25))
+
+
+# ------------------------------------------------------------------ FFT-domain interpolation family (a14)
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_interpolatei_interpolate_decimatei(dtype):
+    tol = 5e-6 if dtype == np.float32 else 1e-11
+    for cplx in (True, False):
+        e = 2 if cplx else 1
+        for points, factor in ((6, 2), (1024, 4), (1000, 3)):
+            x = orc.fill_uniform(points * e, 31 + points, -10, 10, dtype)
+            for fid, ro in ((0, 0.0), (1, 0.4)):
+                v = DspVec(x, is_complex=cplx)
+                assert v.interpolatei(fid, factor, ro) == 0
+                code, ref = orc.interpolatei(x.astype(np.float64), cplx, fid, ro, factor)
+                assert len(v) == ref.size and v.is_complex() == cplx
+                assert rel_l2(v.data(), ref) < tol, (cplx, points, factor, fid)
+        for points, dest, delay in ((6, 12, 0.0), (7, 14, 0.0), (6, 13, 0.0), (13, 6, 0.0), (4096, 8192, 0.0),
+                                    (1000, 1500, 0.0), (2048, 1024, 0.0), (6, 12, 1.0), (512, 2048, 0.3)):
+            x = orc.fill_uniform(points * e, 77 + points, -10, 10, dtype)
+            v = DspVec(x, is_complex=cplx, delta=0.5)
+            assert v.interpolate(V.CONV_SINC, dest, delay) == 0
+            code, ref, nd = orc.interpolate(x.astype(np.float64), cplx, 0, 0.0, dest, delay, 0.5)
+            assert len(v) == ref.size
+            assert rel_l2(v.data(), ref) < (2e-5 if dtype == np.float32 else 1e-10), (cplx, points, dest, delay)
+            assert v.delta() == pytest.approx(nd, rel=1e-6)
+            v = DspVec(x, is_complex=cplx)
+            assert v.interpft(dest) == 0
+            code, ref, _ = orc.interpolate(x.astype(np.float64), cplx, -1, 0.0, dest, 0.0, 1.0)
+            assert rel_l2(v.data(), ref) < (2e-5 if dtype == np.float32 else 1e-10)
+        x = orc.fill_uniform(1001 * e, 5, -10, 10, dtype)
+        for factor, delay in ((2, 1), (3, 0), (7, 5), (2000, 3)):
+            v = DspVec(x, is_complex=cplx)
+            assert v.decimatei(factor, delay) == 0
+            assert np.array_equal(v.data(), orc.decimatei(x, cplx, factor, delay))
+
+
+def test_multiply_frequency_response_gpu():
+    x = np.ones(10, np.float32)
+    v = DspVec(x, is_complex=True, domain=V.FREQ)
+    assert v.multiply_frequency_response(V.CONV_RAISED_COSINE, 2.0, 1.0) == 0
+    np.testing.assert_allclose(v.data(), [0, 0, 1, 1, 2, 2, 1, 1, 0, 0], atol=1e-4)  # convolution.rs:633-639
+    for cplx, n in ((True, 1001), (False, 4096)):
+        e = 2 if cplx else 1
+        x = orc.fill_uniform(n * e, 3, -1, 1, np.float64)
+        v = DspVec(x, is_complex=cplx, domain=V.FREQ)
+        assert v.multiply_frequency_response(V.CONV_RAISED_COSINE, 1.7, 0.35) == 0
+        np.testing.assert_allclose(v.data(), orc.multiply_frequency_response(x, cplx, 1, 0.35, 1.7, False), atol=1e-12)
+    t = DspVec(np.ones(8, np.float32), is_complex=True, domain=V.TIME)
+    assert t.multiply_frequency_response(0, 1.0) == -1  # must be in frequency domain (convolution.rs:590-593)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_symmetric_fft_family(dtype):
+    # tests/real_test.rs:582-605: mirror(plain_sfft(x)) == plain_fft(to_complex(x)); plain_sifft inverts it
+    n = 1001
+    x = orc.fill_uniform(n, 201511210, -10, 10, dtype)
+    tol = 1e-6 if dtype == np.float32 else 1e-12
+    v = DspVec(x)
+    assert v.plain_sfft() == 0 and v.is_complex() and v.domain() == V.FREQ and v.points() == n // 2 + 1
+    full = np.fft.fft(x.astype(np.float64))
+    assert rel_l2(v.datac(), full[:n // 2 + 1]) < 2 * tol
+    assert v.mirror() == 0 and v.points() == n
+    assert rel_l2(v.datac(), full) < 2 * tol
+    v = DspVec(x)
+    assert v.plain_sfft() == 0 and v.plain_sifft() == 0
+    assert not v.is_complex() and len(v) == n
+    assert rel_l2(v.data().astype(np.float64) / n, x) < 4 * tol
+    assert DspVec(x[:1000]).plain_sfft() == 9                       # InputMustHaveAnOddLength
+    assert DspVec(np.zeros(10, dtype), is_complex=True).plain_sfft() == 5   # must be real time data
+    assert DspVec(np.zeros(10, dtype), is_complex=True).plain_sifft() == 6  # must be frequency domain
+    bad = DspVec(np.array([1.0, 0.5, 2.0, 0.0], dtype), is_complex=True, domain=V.FREQ)
+    assert bad.plain_sifft() == 8                                            # first bin must be real

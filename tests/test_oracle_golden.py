@@ -357,3 +357,49 @@ def test_interpolatef_new_len_is_even():
     # interpolation.rs:406-410
     assert orc.interpolatef_new_len(12, 13.0 / 6.0) == 26
     assert orc.interpolatef_new_len(10, 1.5) == 16  # round(15) = 15 -> made even
+
+
+# ---------------------------------------------------------------- FFT-domain interpolation family (a14)
+def test_multiply_frequency_response_kats():
+    # convolution.rs:633-648: ones * raised-cosine(1.0) frequency response, ratio 2
+    for name, n in (("convolve_complex_freq_and_freq32", 10), ("convolve_complex_freq_and_freq_even32", 12)):
+        got = orc.multiply_frequency_response(np.ones(n, np.float32), True, 1, 1.0, 2.0, False)
+        np.testing.assert_allclose(got, kat(name, -1), atol=1e-4)
+
+
+def test_interpolatei_kats():
+    # interpolation.rs:654-678 (sinc) and :726-750 (raised cosine 0.4): 6 complex points, impulse in re of point 3
+    t = np.zeros(12, np.float32)
+    t[6] = 1.0
+    for name, fid, ro in (("interpolatei_sinc_test", 0, 0.0), ("interpolatei_rc_test", 1, 0.4)):
+        code, out = orc.interpolatei(t, True, fid, ro, 2)
+        assert code == 0
+        np.testing.assert_allclose(orc.magnitude(out), kat(name), atol=1e-4)
+
+
+def test_interpolate_kats():
+    # interpolation.rs:681-723: interpolate(Some(sinc), 2*len, 0) == Octave interpft
+    t = np.zeros(12, np.float32)
+    t[6] = 1.0
+    code, out, nd = orc.interpolate(t, True, 0, 0.0, 12)
+    assert code == 0 and nd == pytest.approx(0.5)
+    np.testing.assert_allclose(orc.complex_to_real(out, 2), kat("interpolate_sinc_even_test"), atol=1e-4)
+    code, out, _ = orc.interpolate(_impulse(7), True, 0, 0.0, 14)
+    np.testing.assert_allclose(orc.complex_to_real(out, 2), kat("interpolate_sinc_odd_test"), atol=1e-4)
+    # :834-865 fractional 6 -> 13 points (tol 0.1)
+    code, out, _ = orc.interpolate(_impulse(6), True, 0, 0.0, 13)
+    np.testing.assert_allclose(orc.complex_to_real(out, 2), kat("interpolate_by_fractional_sinc_test"), atol=0.1)
+    # :922-948 delayed by one sample (tol 0.1)
+    fir = kat("interpolate_delayed_sinc_test", 0).astype(np.float32)
+    code, out, _ = orc.interpolate(to_complex(fir), True, 0, 0.0, 12, delay=1.0)
+    np.testing.assert_allclose(orc.magnitude(out), kat("interpolate_delayed_sinc_test", 1), atol=0.1)
+    # :972-1007 downsampling 13 -> 6 points == Octave interpft(time, 6), tol 1e-4
+    fir = kat("decimate_with_interpolate_test", 0).astype(np.float32)
+    code, out, _ = orc.interpolate(to_complex(fir), True, 0, 0.0, 6)
+    np.testing.assert_allclose(orc.magnitude(out), kat("decimate_with_interpolate_test", 1), atol=1e-4)
+
+
+def test_decimatei_kat():
+    # interpolation.rs:963-969
+    got = orc.decimatei(kat("decimatei_test", 0), True, 2, 1)
+    assert np.array_equal(got, kat("decimatei_test", 1))

@@ -48,7 +48,7 @@ SOURCES = [
         "interpolatei_rc_test", "interpolatef_by_integer_sinc_even_test",
         "interpolatef_by_integer_sinc_odd_test", "interpolatef_by_fractional_sinc_test",
         "interpolate_by_fractional_sinc_test", "interpolatef_delayed_sinc_test",
-        "interpolate_delayed_sinc_test", "decimatei_test"]),
+        "interpolate_delayed_sinc_test", "decimatei_test", "decimate_with_interpolate_test"]),
 ]
 
 NUM = r"[-+]?(?:\d+\.\d*|\.\d+|\d+)(?:[eE][-+]?\d+)?"
