@@ -117,6 +117,31 @@ for _s, _t, _R in (("32", _F, VectorInteropResult32), ("64", _D, VectorInteropRe
         _proto(_n + _s, _R, _P)
     for _n in ("windowed_sfft", "windowed_sifft"):
         _proto(_n + _s, _R, _P, C.c_int32)
+    _proto("new_with_detailed_performance_options" + _s, _P, C.c_int32, C.c_int32, _t, _SZ, _t,
+           _SZ, _SZ, _SZ, _SZ, _SZ)
+    _proto("set_value" + _s, None, _P, _SZ, _t)
+    _proto("get_allocated_len" + _s, _SZ, _P)
+    _proto("complex_data" + _s, _P, _P)
+    _proto("complex_divide" + _s, _R, _P, _t, _t)
+    for _n in ("add_vector", "sub_vector", "mul_vector", "div_vector", "add_smaller_vector",
+               "sub_smaller_vector", "mul_smaller_vector", "div_smaller_vector", "correlate"):
+        _proto(_n + _s, _R, _P, _P)
+    for _n in ("prepare_argument", "prepare_argument_padded"):
+        _proto(_n + _s, _R, _P)
+    _proto("convolve" + _s, _R, _P, C.c_int32, _t, _t, _SZ)
+    for _n in ("interpolate_lin", "interpolate_hermite"):
+        _proto(_n + _s, _R, _P, _t, _t)
+    # callback variants: the callbacks run on the host (sampled into a table), see the header
+    _proto("convolve_real" + _s, _R, _P, _P, _P, C.c_bool, _t, _SZ)
+    _proto("multiply_frequency_response_real" + _s, _R, _P, _P, _P, C.c_bool, _t)
+    for _n in ("apply_custom_window", "unapply_custom_window", "windowed_custom_fft",
+               "windowed_custom_sfft", "windowed_custom_ifft", "windowed_custom_sifft"):
+        _proto(_n + _s, _R, _P, _P, _P, C.c_bool)
+
+WINDOW_FN32 = C.CFUNCTYPE(_F, _P, _SZ, _SZ)
+WINDOW_FN64 = C.CFUNCTYPE(_D, _P, _SZ, _SZ)
+REAL_FN32 = C.CFUNCTYPE(_F, _P, _F)
+REAL_FN64 = C.CFUNCTYPE(_D, _P, _D)
 
 _proto("bdsp_hip_dev_fft", _I, _I, _P, _P, _SZ, _SZ, _U, _D, _I, _D, C.POINTER(_I), _P)
 _proto("bdsp_hip_dev_convolve", _I, _I, _P, _P, _SZ, _SZ, _P, _SZ, _P)

@@ -105,6 +105,8 @@ template <typename T> int ew_real_offset(T* x, size_t len, bool is_complex, T f,
 template <typename T> int ew_complex_scale(T* x, size_t len, T re, T im, hipStream_t s);
 template <typename T> int ew_complex_offset(T* x, size_t len, T re, T im, hipStream_t s);
 template <typename T> int ew_binary(T* x, const T* y, size_t len, bool is_complex, int op, hipStream_t s);
+template <typename T> int ew_binary_smaller(T* x, const T* y, size_t len, size_t ylen, bool is_complex, int op, hipStream_t s);
+template <typename T> int ew_point_table(T* x, size_t len, bool is_complex, const T* table, bool divide, hipStream_t s);
 template <typename T> int ew_conj(T* x, size_t len, hipStream_t s);
 template <typename T> int ew_mul_cexp(T* x, size_t len, T a, T b, hipStream_t s);
 template <typename T> int ew_complex_to_real(const T* x, T* out, size_t len, int kind, hipStream_t s);
@@ -126,6 +128,10 @@ template <typename T>
 int interpolatef_dev(const T* in, T* out, size_t len, bool is_complex, int fid, T rolloff, T factor,
                      T delay, size_t conv_len, T delta, hipStream_t s);
 template <typename T> size_t interpolatef_new_len(size_t len, T factor);
+template <typename T> int conv_function_taps(T* taps, size_t conv_len, int fid, T rolloff, T ratio, int stride, bool reversed, hipStream_t s);
+template <typename T> int conv_function_direct(const T* in, T* out, size_t points, bool is_complex, const T* taps, size_t conv_len, hipStream_t s);
+template <typename T> size_t interpolate_real_len(size_t len, T factor);
+template <typename T> int interpolate_real_dev(const T* in, T* out, size_t len, T factor, T delay, bool hermite, hipStream_t s);
 
 // window value shared by fft.hip and elementwise.hip (device) -- defined inline in window.h
 } // namespace bdsp

@@ -743,6 +743,189 @@ int op_sifft(DevVec<T>* v, bool shift, int window)
     return BDSP_OK;
 }
 
+// convolve(function, ratio, len) in the time domain (convolution.rs:136-192 -> convolve_function_priv,
+// time_freq/mod.rs:174-213): y[i] = sum_{m=-L}^{L} x[(i+m) mod N] * f(-m*ratio).  The 2L+1 weights are
+// tabulated once; when the table fits the vector it is the tap vector of the centred convolution and the
+// fused overlap-save kernel does the work.  host_taps (window order, 2L+1 values) replaces the built-in
+// functions for the callback variants (convolve_real32).  The reference's alternative branch for long
+// vectors (:148-172) builds its tap vector with 1/ratio instead of ratio and fills every other tap of a
+// real vector only; the convolve_function_priv semantics are the documented ones and are used throughout.
+template <typename T>
+int op_convolve_function(DevVec<T>* v, int fid, T rolloff, T ratio, size_t conv_len, const T* host_taps)
+{
+    if (v->freq) { v->poison(); return BDSP_OK; } // assert_time! (convolution.rs:95-102)
+    const size_t points = v->points();
+    if (points == 0) return BDSP_OK;
+    hipStream_t s = lib_stream();
+    if (conv_len > points) conv_len = points; // mod.rs:197
+    const size_t ntaps = 2 * conv_len + 1;
+    const bool as_taps = ntaps <= points;
+    const int stride = (as_taps && v->complex_) ? 2 : 1;
+    WsBlock tb;
+    BDSP_TRY(tb.alloc(sizeof(T) * ntaps * stride, s));
+    if (host_taps) {
+        std::vector<T> h(ntaps * stride, (T)0);
+        for (size_t k = 0; k < ntaps; ++k) h[(as_taps ? ntaps - 1 - k : k) * stride] = host_taps[k];
+        BDSP_HIP_TRY(hipMemcpyAsync(tb.p, h.data(), sizeof(T) * h.size(), hipMemcpyHostToDevice, s));
+        BDSP_HIP_TRY(hipStreamSynchronize(s));
+    } else {
+        BDSP_TRY(conv_function_taps<T>(tb.as<T>(), conv_len, fid, rolloff, ratio, stride, as_taps, s));
+    }
+    if (!as_taps) BDSP_TRY(conv_function_direct<T>(v->data, v->buf, points, v->complex_, tb.as<T>(), conv_len, s));
+    else if (v->complex_) BDSP_TRY(conv_complex_dev<T>(v->data, v->buf, points, 1, tb.as<T>(), ntaps, s));
+    else BDSP_TRY(conv_real_dev<T>(v->data, v->buf, points, tb.as<T>(), ntaps, s));
+    v->trade();
+    return BDSP_OK;
+}
+
+// Cross correlation (correlation.rs:96-160)
+template <typename T>
+int op_prepare_argument(DevVec<T>* v, bool padded)
+{
+    if (padded) {
+        const size_t points = v->points();
+        // zero_pad_b(2*points-1, Surround).expect(..): the reference PANICS for points <= 1; code 7 here
+        if (points <= 1) return BDSP_ERR_ARG_LENGTH;
+        BDSP_TRY(op_zero_pad<T>(v, 2 * points - 1, 1));
+    }
+    BDSP_TRY(op_fft<T>(v, false, false, -1));
+    if (v->erroneous()) return BDSP_OK;
+    return ew_conj<T>(v->data, v->valid_len, lib_stream());
+}
+
+template <typename T>
+int op_correlate(DevVec<T>* v, const DevVec<T>* other)
+{
+    // both failures report InputMustBeInTimeDomain (correlation.rs:134-146)
+    if (v->freq || !v->complex_ || !other->freq || !other->complex_) {
+        v->poison(); v->complex_ = true; v->freq = true;
+        return BDSP_ERR_MUST_BE_TIME;
+    }
+    hipStream_t s = lib_stream();
+    const size_t points = other->points();
+    BDSP_TRY(op_zero_pad<T>(v, points, 1)); // 7 unless the argument is longer than self
+    bool in_b = false;
+    BDSP_TRY(fft_two_buffers<T>(v->data, v->buf, points, 1, false, 0, (T)1, -1, (T)0, &in_b, s));
+    if (in_b) v->trade();
+    BDSP_TRY(ew_binary<T>(v->data, other->data, v->valid_len, true, 2, s));
+    // plain_ifft -> scale(1/points) -> swap_halves: scale and shift ride on the inverse transform
+    BDSP_TRY(fft_two_buffers<T>(v->data, v->buf, points, 1, true, BDSP_FFT_SHIFT_OUT, (T)1 / (T)points, -1, (T)0, &in_b, s));
+    if (in_b) v->trade();
+    return BDSP_OK; // delta is untouched: the transforms ran on a view (correlation.rs:150-153)
+}
+
+// interpolate_lin / interpolate_hermite (real_interpolation.rs:33-176)
+template <typename T>
+int op_interpolate_real(DevVec<T>* v, T factor, T delay, bool hermite)
+{
+    if (v->complex_) { v->poison(); return BDSP_OK; } // :47-50, :89-92
+    if (v->valid_len == 0) return BDSP_OK;             // (the reference underflows len-1 and panics)
+    const size_t dest_len = interpolate_real_len<T>(v->valid_len, factor);
+    BDSP_TRY(v->reserve(dest_len > v->valid_len ? dest_len : v->valid_len));
+    BDSP_TRY(interpolate_real_dev<T>(v->data, v->buf, v->valid_len, factor, delay, hermite, lib_stream()));
+    v->trade();
+    v->valid_len = dest_len;
+    return BDSP_OK;
+}
+
+template <typename T>
+int op_binary_smaller(DevVec<T>* v, const DevVec<T>* o, int op)
+{
+    if (o->valid_len == 0 || v->valid_len % o->valid_len != 0) return BDSP_ERR_ARG_LENGTH; // elementary.rs:613-617
+    if (!meta_agrees(v, o)) return BDSP_ERR_META_DATA;
+    return ew_binary_smaller<T>(v->data, o->data, v->valid_len, o->valid_len, v->complex_, op, lib_stream());
+}
+
+// Host-sampled callbacks (interop/src/lib.rs:245-377).  A window callback is sampled for every point
+// (or for the first ceil(P/2) points and mirrored when is_symmetric, vector_types/mod.rs:567-594).
+template <typename T>
+int upload_table(WsBlock& tb, const std::vector<T>& h, hipStream_t s)
+{
+    BDSP_TRY(tb.alloc(sizeof(T) * (h.size() ? h.size() : 1), s));
+    if (h.empty()) return BDSP_OK;
+    BDSP_HIP_TRY(hipMemcpyAsync(tb.p, h.data(), sizeof(T) * h.size(), hipMemcpyHostToDevice, s));
+    BDSP_HIP_TRY(hipStreamSynchronize(s));
+    return BDSP_OK;
+}
+
+template <typename T>
+int op_custom_window(DevVec<T>* v, T (*window)(const void*, size_t, size_t), const void* data, bool symmetric,
+                     bool unapply)
+{
+    const size_t points = v->points();
+    if (points == 0) return BDSP_OK;
+    std::vector<T> h(points);
+    const size_t half = points - points / 2;
+    for (size_t i = 0; i < points; ++i) {
+        if (symmetric && i >= half) h[i] = h[points - 1 - i];
+        else h[i] = window(data, i, points);
+    }
+    WsBlock tb;
+    hipStream_t s = lib_stream();
+    BDSP_TRY(upload_table<T>(tb, h, s));
+    return ew_point_table<T>(v->data, v->valid_len, v->complex_, tb.as<T>(), unapply, s);
+}
+
+// windowed_custom_{fft,ifft,sfft,sifft}: the table multiply cannot be fused; the transform still is
+template <typename T>
+int op_custom_windowed(DevVec<T>* v, T (*window)(const void*, size_t, size_t), const void* data, bool symmetric,
+                       int kind /* 0 fft, 1 ifft, 2 sfft, 3 sifft */)
+{
+    switch (kind) {
+    case 0:
+        if (v->freq) { v->poison(); v->complex_ = true; v->freq = true; return BDSP_OK; }
+        BDSP_TRY(op_custom_window<T>(v, window, data, symmetric, false));
+        return op_fft<T>(v, false, true, -1);
+    case 1:
+        BDSP_TRY(op_fft<T>(v, true, true, -1));
+        if (v->erroneous()) return BDSP_OK;
+        return op_custom_window<T>(v, window, data, symmetric, true);
+    case 2:
+        if (v->freq || v->complex_) { v->poison(); v->complex_ = true; v->freq = true; return BDSP_ERR_MUST_BE_TIME; }
+        if (v->valid_len % 2 == 0) { v->poison(); v->complex_ = true; v->freq = true; return BDSP_ERR_ODD_LENGTH; }
+        BDSP_TRY(op_custom_window<T>(v, window, data, symmetric, false));
+        return op_sfft<T>(v, true, -1);
+    default: {
+        int c = op_sifft<T>(v, true, -1);
+        if (c != BDSP_OK || v->erroneous()) return c;
+        return op_custom_window<T>(v, window, data, symmetric, true);
+    }
+    }
+}
+
+// multiply_frequency_response with a sampled real callback (multiply_function_priv, mod.rs:612-723):
+// element i of a natural-order spectrum uses x = fft_swap_x(false, j, max) * ratio = j/max*ratio,
+// j = -max + i, max = (points - points%2)/2; a symmetric function is evaluated on j <= 0 only.
+template <typename T>
+int op_custom_frequency_response(DevVec<T>* v, T (*fun)(const void*, T), const void* data, bool symmetric, T ratio)
+{
+    if (!v->freq) { v->poison(); return BDSP_OK; }
+    const size_t points = v->points();
+    if (points == 0) return BDSP_OK;
+    const T maxv = (T)(points - points % 2) / (T)2;
+    std::vector<T> h(points);
+    for (size_t i = 0; i < points; ++i) {
+        T j = -maxv + (T)i;
+        if (symmetric && j > (T)0) j = -j;
+        h[i] = ratio * fun(data, j / maxv * ratio);
+    }
+    WsBlock tb;
+    hipStream_t s = lib_stream();
+    BDSP_TRY(upload_table<T>(tb, h, s));
+    return ew_point_table<T>(v->data, v->valid_len, v->complex_, tb.as<T>(), false, s);
+}
+
+template <typename T>
+int op_convolve_callback(DevVec<T>* v, T (*fun)(const void*, T), const void* data, T ratio, size_t conv_len)
+{
+    const size_t points = v->points();
+    if (conv_len > points) conv_len = points;
+    std::vector<T> h(2 * conv_len + 1);
+    T j = -(T)conv_len;
+    for (size_t k = 0; k < h.size(); ++k) { h[k] = fun(data, -j * ratio); j = j + (T)1; }
+    return op_convolve_function<T>(v, 0, (T)0, ratio, conv_len, h.data());
+}
+
 template <typename T>
 const T* vec_download(DevVec<T>* v)
 {
@@ -912,7 +1095,61 @@ size_t bdsp_hip_overlap_discard_f64(double* x_time, size_t x_len, double* tmp, s
     RES windowed_sfft##SFX(VB* vector, int32_t window) { DevVec<T>* v = H<T>(vector); return finish<T>(v, op_sfft<T>(v, true, window < 0 ? 3 : window)); } \
     RES plain_sifft##SFX(VB* vector) { DevVec<T>* v = H<T>(vector); return finish<T>(v, op_sifft<T>(v, false, -1)); } \
     RES sifft##SFX(VB* vector) { DevVec<T>* v = H<T>(vector); return finish<T>(v, op_sifft<T>(v, true, -1)); } \
-    RES windowed_sifft##SFX(VB* vector, int32_t window) { DevVec<T>* v = H<T>(vector); return finish<T>(v, op_sifft<T>(v, true, window < 0 ? 3 : window)); }
+    RES windowed_sifft##SFX(VB* vector, int32_t window) { DevVec<T>* v = H<T>(vector); return finish<T>(v, op_sifft<T>(v, true, window < 0 ? 3 : window)); } \
+    VB* new_with_detailed_performance_options##SFX(int32_t is_complex, int32_t domain, T init_value, size_t length, \
+                                                   T delta, size_t, size_t, size_t, size_t, size_t)        \
+    { return reinterpret_cast<VB*>(vec_new<T>(is_complex, domain, init_value, length, delta)); }           \
+    void set_value##SFX(VB* vector, size_t index, T value)                                                  \
+    {                                                                                                       \
+        DevVec<T>* v = H<T>(vector);                                                                        \
+        if (index >= v->valid_len) return;                                                                  \
+        (void)hipMemcpyAsync(v->data + index, &value, sizeof(T), hipMemcpyHostToDevice, lib_stream());      \
+        (void)hipStreamSynchronize(lib_stream());                                                           \
+    }                                                                                                       \
+    size_t get_allocated_len##SFX(const VB* vector) { return H<T>(vector)->cap; }                           \
+    const T* complex_data##SFX(VB* vector) { return vec_download<T>(H<T>(vector)); }                        \
+    RES complex_divide##SFX(VB* vector, T re, T im)                                                         \
+    {                                                                                                       \
+        DevVec<T>* v = H<T>(vector);                                                                        \
+        if (!v->complex_) { v->poison(); return finish<T>(v, BDSP_OK); }                                    \
+        T nn = re * re + im * im; /* Complex::new(1, 0) / Complex::new(re, im), facade32.rs:550-556 */      \
+        return finish<T>(v, ew_complex_scale<T>(v->data, v->valid_len, ((T)1 * re + (T)0 * im) / nn, ((T)0 * re - (T)1 * im) / nn, lib_stream())); \
+    }                                                                                                       \
+    RES add_vector##SFX(VB* vector, const VB* operand) { DevVec<T>* v = H<T>(vector); return finish<T>(v, op_binary<T>(v, H<T>(operand), 0)); } \
+    RES sub_vector##SFX(VB* vector, const VB* operand) { DevVec<T>* v = H<T>(vector); return finish<T>(v, op_binary<T>(v, H<T>(operand), 1)); } \
+    RES mul_vector##SFX(VB* vector, const VB* operand) { DevVec<T>* v = H<T>(vector); return finish<T>(v, op_binary<T>(v, H<T>(operand), 2)); } \
+    RES div_vector##SFX(VB* vector, const VB* operand) { DevVec<T>* v = H<T>(vector); return finish<T>(v, op_binary<T>(v, H<T>(operand), 3)); } \
+    RES add_smaller_vector##SFX(VB* vector, const VB* operand) { DevVec<T>* v = H<T>(vector); return finish<T>(v, op_binary_smaller<T>(v, H<T>(operand), 0)); } \
+    RES sub_smaller_vector##SFX(VB* vector, const VB* operand) { DevVec<T>* v = H<T>(vector); return finish<T>(v, op_binary_smaller<T>(v, H<T>(operand), 1)); } \
+    RES mul_smaller_vector##SFX(VB* vector, const VB* operand) { DevVec<T>* v = H<T>(vector); return finish<T>(v, op_binary_smaller<T>(v, H<T>(operand), 2)); } \
+    RES div_smaller_vector##SFX(VB* vector, const VB* operand) { DevVec<T>* v = H<T>(vector); return finish<T>(v, op_binary_smaller<T>(v, H<T>(operand), 3)); } \
+    RES prepare_argument##SFX(VB* vector) { DevVec<T>* v = H<T>(vector); return finish<T>(v, op_prepare_argument<T>(v, false)); } \
+    RES prepare_argument_padded##SFX(VB* vector) { DevVec<T>* v = H<T>(vector); return finish<T>(v, op_prepare_argument<T>(v, true)); } \
+    RES correlate##SFX(VB* vector, const VB* other) { DevVec<T>* v = H<T>(vector); return finish<T>(v, op_correlate<T>(v, H<T>(other))); } \
+    RES convolve##SFX(VB* vector, int32_t impulse_response, T rolloff, T ratio, size_t len)                 \
+    { DevVec<T>* v = H<T>(vector); return finish<T>(v, op_convolve_function<T>(v, impulse_response == 0 ? 0 : 1, rolloff, ratio, len, nullptr)); } \
+    RES convolve_real##SFX(VB* vector, T (*impulse_response)(const void*, T), const void* impulse_response_data, \
+                           bool, T ratio, size_t len)                                                       \
+    { DevVec<T>* v = H<T>(vector); return finish<T>(v, op_convolve_callback<T>(v, impulse_response, impulse_response_data, ratio, len)); } \
+    RES multiply_frequency_response_real##SFX(VB* vector, T (*frequency_response)(const void*, T),          \
+                                              const void* frequency_response_data, bool is_symmetric, T ratio) \
+    { DevVec<T>* v = H<T>(vector); return finish<T>(v, op_custom_frequency_response<T>(v, frequency_response, frequency_response_data, is_symmetric, ratio)); } \
+    RES interpolate_lin##SFX(VB* vector, T interpolation_factor, T delay)                                   \
+    { DevVec<T>* v = H<T>(vector); return finish<T>(v, op_interpolate_real<T>(v, interpolation_factor, delay, false)); } \
+    RES interpolate_hermite##SFX(VB* vector, T interpolation_factor, T delay)                               \
+    { DevVec<T>* v = H<T>(vector); return finish<T>(v, op_interpolate_real<T>(v, interpolation_factor, delay, true)); } \
+    RES apply_custom_window##SFX(VB* vector, T (*window)(const void*, size_t, size_t), const void* window_data, bool is_symmetric) \
+    { DevVec<T>* v = H<T>(vector); return finish<T>(v, op_custom_window<T>(v, window, window_data, is_symmetric, false)); } \
+    RES unapply_custom_window##SFX(VB* vector, T (*window)(const void*, size_t, size_t), const void* window_data, bool is_symmetric) \
+    { DevVec<T>* v = H<T>(vector); return finish<T>(v, op_custom_window<T>(v, window, window_data, is_symmetric, true)); } \
+    RES windowed_custom_fft##SFX(VB* vector, T (*window)(const void*, size_t, size_t), const void* window_data, bool is_symmetric) \
+    { DevVec<T>* v = H<T>(vector); return finish<T>(v, op_custom_windowed<T>(v, window, window_data, is_symmetric, 0)); } \
+    RES windowed_custom_ifft##SFX(VB* vector, T (*window)(const void*, size_t, size_t), const void* window_data, bool is_symmetric) \
+    { DevVec<T>* v = H<T>(vector); return finish<T>(v, op_custom_windowed<T>(v, window, window_data, is_symmetric, 1)); } \
+    RES windowed_custom_sfft##SFX(VB* vector, T (*window)(const void*, size_t, size_t), const void* window_data, bool is_symmetric) \
+    { DevVec<T>* v = H<T>(vector); return finish<T>(v, op_custom_windowed<T>(v, window, window_data, is_symmetric, 2)); } \
+    RES windowed_custom_sifft##SFX(VB* vector, T (*window)(const void*, size_t, size_t), const void* window_data, bool is_symmetric) \
+    { DevVec<T>* v = H<T>(vector); return finish<T>(v, op_custom_windowed<T>(v, window, window_data, is_symmetric, 3)); }
 
 BDSP_FACADE(32, float, VecBuf32, VectorInteropResult32)
 BDSP_FACADE(64, double, VecBuf64, VectorInteropResult64)

@@ -304,6 +304,63 @@ template <typename T> int ew_binary(T* x, const T* y, size_t len, bool is_comple
     return BDSP_OK;
 }
 
+// ---- x[i] (.)= y[i mod ylen]: add_smaller / sub_smaller / mul_smaller / div_smaller (elementary.rs:591-640)
+template <typename T, bool CPLX>
+__global__ __launch_bounds__(256) void k_binary_smaller(T* __restrict__ x, const T* __restrict__ y, size_t points,
+                                                         size_t ypoints, int op)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < points; i += (size_t)gridDim.x * blockDim.x) {
+        size_t j = i % ypoints;
+        if (CPLX) {
+            T ar = x[2 * i], ai = x[2 * i + 1], br = y[2 * j], bi = y[2 * j + 1];
+            T re, im;
+            if (op == 0) { re = ar + br; im = ai + bi; }
+            else if (op == 1) { re = ar - br; im = ai - bi; }
+            else if (op == 2) { re = ar * br - ai * bi; im = ar * bi + ai * br; }
+            else { T nn = br * br + bi * bi; re = (ar * br + ai * bi) / nn; im = (ai * br - ar * bi) / nn; }
+            x[2 * i] = re; x[2 * i + 1] = im;
+        } else {
+            T a = x[i], b = y[j];
+            x[i] = op == 0 ? a + b : (op == 1 ? a - b : (op == 2 ? a * b : a / b));
+        }
+    }
+}
+template <typename T> int ew_binary_smaller(T* x, const T* y, size_t len, size_t ylen, bool is_complex, int op, hipStream_t s)
+{
+    const size_t e = is_complex ? 2 : 1, points = len / e, yp = ylen / e;
+    if (points == 0 || yp == 0) return BDSP_OK;
+    if (is_complex) hipLaunchKernelGGL((k_binary_smaller<T, true>), dim3(ew_grid(points)), dim3(256), 0, s, x, y, points, yp, op);
+    else hipLaunchKernelGGL((k_binary_smaller<T, false>), dim3(ew_grid(points)), dim3(256), 0, s, x, y, points, yp, op);
+    BDSP_LAUNCH_CHECK();
+    return BDSP_OK;
+}
+
+// ---- x[point i] *= (or /=) table[i]: host-sampled callback windows / frequency responses ------------
+// (interop/src/lib.rs:245-377: the C callbacks cannot run on the device, so the host samples them once)
+template <typename T, bool CPLX>
+__global__ __launch_bounds__(256) void k_point_table(T* __restrict__ x, const T* __restrict__ table, size_t points, bool divide)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < points; i += (size_t)gridDim.x * blockDim.x) {
+        T w = table[i];
+        if (CPLX) {
+            T re = x[2 * i], im = x[2 * i + 1];
+            x[2 * i] = divide ? re / w : re * w;
+            x[2 * i + 1] = divide ? im / w : im * w;
+        } else {
+            x[i] = divide ? x[i] / w : x[i] * w;
+        }
+    }
+}
+template <typename T> int ew_point_table(T* x, size_t len, bool is_complex, const T* table, bool divide, hipStream_t s)
+{
+    const size_t points = is_complex ? len / 2 : len;
+    if (points == 0) return BDSP_OK;
+    if (is_complex) hipLaunchKernelGGL((k_point_table<T, true>), dim3(ew_grid(points)), dim3(256), 0, s, x, table, points, divide);
+    else hipLaunchKernelGGL((k_point_table<T, false>), dim3(ew_grid(points)), dim3(256), 0, s, x, table, points, divide);
+    BDSP_LAUNCH_CHECK();
+    return BDSP_OK;
+}
+
 // ---- complex -> real (complex_to_real.rs:374-478); out may alias x (in-place compaction) -----------
 template <typename T> __device__ __forceinline__ T dev_hypot2(T a, T b);
 template <> __device__ __forceinline__ float dev_hypot2<float>(float a, float b) { return hypotf(a, b); }
@@ -351,6 +408,8 @@ template <typename T> int ew_complex_to_real(const T* x, T* out, size_t len, int
     template int ew_complex_scale<T>(T*, size_t, T, T, hipStream_t);                               \
     template int ew_complex_offset<T>(T*, size_t, T, T, hipStream_t);                              \
     template int ew_binary<T>(T*, const T*, size_t, bool, int, hipStream_t);                       \
+    template int ew_binary_smaller<T>(T*, const T*, size_t, size_t, bool, int, hipStream_t);          \
+    template int ew_point_table<T>(T*, size_t, bool, const T*, bool, hipStream_t);                   \
     template int ew_conj<T>(T*, size_t, hipStream_t);                                              \
     template int ew_mul_cexp<T>(T*, size_t, T, T, hipStream_t);                                    \
     template int ew_complex_to_real<T>(const T*, T*, size_t, int, hipStream_t);                    \

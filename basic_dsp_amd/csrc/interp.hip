@@ -264,6 +264,177 @@ int interpolatef_dev(const T* in, T* out, size_t len, bool is_complex, int fid, 
     return BDSP_OK;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// convolve(function, ratio, len) in the time domain: convolve_function_priv (time_freq/mod.rs:174-213)
+//   y[i] = sum_{m=-L}^{L} x[(i + m) mod N] * f(-m * ratio)         (WrappingIterator pre-increments)
+// The weights do not depend on i: they are tabulated once (2L+1 values, stored at `stride` scalars,
+// optionally reversed so that the table is the tap vector of the centred convolution a9).
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void k_conv_fn_taps(T* __restrict__ taps, long long L, int fid, T rolloff, T ratio, int stride,
+                               bool reversed)
+{
+    long long k = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (k > 2 * L) return;
+    T j = (T)k - (T)L; // the reference accumulates j = -L, -L+1, ...: integers, exact in T
+    T w = conv_time_value<T>(fid, rolloff, -j * ratio);
+    long long at = reversed ? 2 * L - k : k;
+    taps[at * stride] = w;
+    if (stride == 2) taps[at * 2 + 1] = (T)0;
+}
+
+template <typename T, bool CPLX>
+__global__ void __launch_bounds__(256)
+k_conv_function(const T* __restrict__ in, T* __restrict__ out, const T* __restrict__ taps, long long points, long long L)
+{
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < points; i += (long long)gridDim.x * 256) {
+        long long p = (i - L) % points;
+        if (p < 0) p += points;
+        T sre = 0, sim = 0;
+        for (long long k = 0; k <= 2 * L; ++k) {
+            T w = taps[k];
+            if (CPLX) {
+                sre = sre + in[2 * p] * w;
+                sim = sim + in[2 * p + 1] * w;
+            } else {
+                sre = sre + in[p] * w;
+            }
+            if (++p == points) p = 0;
+        }
+        if (CPLX) { out[2 * i] = sre; out[2 * i + 1] = sim; }
+        else out[i] = sre;
+    }
+}
+
+template <typename T>
+int conv_function_taps(T* taps, size_t conv_len, int fid, T rolloff, T ratio, int stride, bool reversed, hipStream_t s)
+{
+    size_t n = 2 * conv_len + 1;
+    hipLaunchKernelGGL((k_conv_fn_taps<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, taps,
+                       (long long)conv_len, fid, rolloff, ratio, stride, reversed);
+    BDSP_LAUNCH_CHECK();
+    return BDSP_OK;
+}
+
+template <typename T>
+int conv_function_direct(const T* in, T* out, size_t points, bool is_complex, const T* taps, size_t conv_len, hipStream_t s)
+{
+    if (points == 0) return BDSP_OK;
+    size_t blocks = (points + 255) / 256, cap = (size_t)num_cus() * 16;
+    if (blocks > cap) blocks = cap;
+    if (is_complex)
+        hipLaunchKernelGGL((k_conv_function<T, true>), dim3((unsigned)blocks), dim3(256), 0, s, in, out, taps,
+                           (long long)points, (long long)conv_len);
+    else
+        hipLaunchKernelGGL((k_conv_function<T, false>), dim3((unsigned)blocks), dim3(256), 0, s, in, out, taps,
+                           (long long)points, (long long)conv_len);
+    BDSP_LAUNCH_CHECK();
+    return BDSP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Real-only interpolation between samples (time_freq/real_interpolation.rs:33-176): linear and
+// piecewise cubic Hermite (Catmull-Rom) with linearly extrapolated end points; no wrap-around.
+// dest_len = round((len-1)*factor) + 1.  Evaluated in T with the reference's operation order.
+// Reads the reference would panic on (a delay that pushes an index past the ends) are clamped.
+// The reference accumulates the output index in T (i = i + 1), which stalls at 2^24 in f32; this
+// kernel converts the integer index instead -- identical below 2^24 outputs.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+size_t interpolate_real_len(size_t len, T factor)
+{
+    if (len == 0) return 0;
+    T v = (T)(len - 1) * factor;
+    return (size_t)(sizeof(T) == 4 ? roundf((float)v) : round((double)v)) + 1;
+}
+
+template <typename T>
+__device__ __forceinline__ T clamped(const T* __restrict__ x, long long len, long long i)
+{
+    i = i < 0 ? 0 : (i >= len ? len - 1 : i);
+    return x[i];
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_interp_lin(const T* __restrict__ in, T* __restrict__ out, long long len, long long dest_len, T factor, T delay)
+{
+    for (long long n = (long long)blockIdx.x * 256 + threadIdx.x; n < dest_len; n += (long long)gridDim.x * 256) {
+        if (n == dest_len - 1) { out[n] = in[len - 1]; continue; } // :68
+        T rounded = (T)n / factor + delay;
+        T beforef = dev_floor(rounded);
+        long long before = (long long)beforef;
+        T y0 = clamped(in, len, before), y1 = clamped(in, len, before + 1);
+        out[n] = y0 + (y1 - y0) * (rounded - beforef);
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_interp_hermite(const T* __restrict__ in, T* __restrict__ out, long long len, long long dest_len, T factor, T delay,
+                 long long start, long long tail)
+{
+    const T half = (T)0.5, c15 = (T)1.5, two = (T)2, c25 = (T)2.5;
+    for (long long n = (long long)blockIdx.x * 256 + threadIdx.x; n < dest_len; n += (long long)gridDim.x * 256) {
+        T rounded = (T)n / factor + delay;
+        T beforef = dev_floor(rounded);
+        long long before = (long long)beforef;
+        T x = rounded - beforef;
+        T y0, y1, y2, y3;
+        if (n < start) { // :103-124
+            y1 = clamped(in, len, before); y2 = clamped(in, len, before + 1); y3 = clamped(in, len, before + 2);
+            y0 = y1 - (y2 - y1);
+        } else if (n < tail) { // :126-145
+            y0 = clamped(in, len, before - 1); y1 = clamped(in, len, before);
+            y2 = clamped(in, len, before + 1); y3 = clamped(in, len, before + 2);
+        } else { // :147-172
+            y0 = clamped(in, len, before - 1); y1 = clamped(in, len, before);
+            y2 = (before >= 0 && before < len - 1) ? in[before + 1] : y1 + (y1 - y0);
+            y3 = (before >= 0 && before + 2 < len) ? in[before + 2] : y2 + (y2 - y1);
+        }
+        T x2 = x * x;
+        T a0 = -half * y0 + c15 * y1 - c15 * y2 + half * y3;
+        T a1 = y0 - c25 * y1 + two * y2 - half * y3;
+        T a2 = -half * y0 + half * y2;
+        T a3 = y1;
+        out[n] = (a0 * x * x2) + (a1 * x2) + (a2 * x) + a3;
+    }
+}
+
+template <typename T>
+int interpolate_real_dev(const T* in, T* out, size_t len, T factor, T delay, bool hermite, hipStream_t s)
+{
+    if (len == 0) return BDSP_OK;
+    const size_t dest_len = interpolate_real_len<T>(len, factor);
+    size_t blocks = (dest_len + 255) / 256, cap = (size_t)num_cus() * 16;
+    if (blocks > cap) blocks = cap;
+    if (!hermite) {
+        hipLaunchKernelGGL((k_interp_lin<T>), dim3((unsigned)blocks), dim3(256), 0, s, in, out, (long long)len,
+                           (long long)dest_len, factor, delay);
+    } else {
+        T st = ((T)1 - delay) * factor;
+        double c = sizeof(T) == 4 ? (double)ceilf((float)st) : ceil((double)st);
+        long long start = c < 0 ? 0 : (long long)c, end = start + 1;
+        if (start > (long long)dest_len) start = (long long)dest_len;
+        long long tail = (long long)dest_len > end ? (long long)dest_len - end : 0;
+        if (tail < start) tail = start;
+        hipLaunchKernelGGL((k_interp_hermite<T>), dim3((unsigned)blocks), dim3(256), 0, s, in, out, (long long)len,
+                           (long long)dest_len, factor, delay, start, tail);
+    }
+    BDSP_LAUNCH_CHECK();
+    return BDSP_OK;
+}
+
+#define BDSP_INST(T)                                                                                          \
+    template int conv_function_taps<T>(T*, size_t, int, T, T, int, bool, hipStream_t);                        \
+    template int conv_function_direct<T>(const T*, T*, size_t, bool, const T*, size_t, hipStream_t);          \
+    template size_t interpolate_real_len<T>(size_t, T);                                                       \
+    template int interpolate_real_dev<T>(const T*, T*, size_t, T, T, bool, hipStream_t);
+BDSP_INST(float)
+BDSP_INST(double)
+#undef BDSP_INST
+
 template int interpolatef_dev<float>(const float*, float*, size_t, bool, int, float, float, float, size_t, float, hipStream_t);
 template int interpolatef_dev<double>(const double*, double*, size_t, bool, int, double, double, double, size_t, double, hipStream_t);
 

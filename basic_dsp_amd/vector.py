@@ -247,6 +247,80 @@ class DspVec:
     def windowed_sifft(self, window):
         return self._call("windowed_sifft", int(window))
 
+    # ------------------------------------------------------------------ correlation, function convolution
+    def prepare_argument(self):
+        return self._call("prepare_argument")
+
+    def prepare_argument_padded(self):
+        return self._call("prepare_argument_padded")
+
+    def correlate(self, other):
+        return self._call("correlate", other._h)
+
+    def convolve(self, function, ratio, conv_len, rolloff=0.0):
+        """Convolution with a built-in impulse response id, or with a Python callable f(x) that the
+        host samples into 2*conv_len+1 weights (the facade's convolve_real callback variant)."""
+        if callable(function):
+            cb = self._real_fn(lambda _data, x: function(x))
+            return self._call("convolve_real", cb, None, True, ratio, int(conv_len))
+        return self._call("convolve", int(function), rolloff, ratio, int(conv_len))
+
+    def multiply_frequency_response_fn(self, function, ratio, is_symmetric=True):
+        cb = self._real_fn(lambda _data, x: function(x))
+        return self._call("multiply_frequency_response_real", cb, None, bool(is_symmetric), ratio)
+
+    def _real_fn(self, f):
+        return (_lib.REAL_FN32 if self._sfx == "32" else _lib.REAL_FN64)(f)
+
+    def _window_fn(self, f):
+        return (_lib.WINDOW_FN32 if self._sfx == "32" else _lib.WINDOW_FN64)(lambda _d, n, length: f(n, length))
+
+    def apply_custom_window(self, window, is_symmetric=True):
+        return self._call("apply_custom_window", self._window_fn(window), None, bool(is_symmetric))
+
+    def unapply_custom_window(self, window, is_symmetric=True):
+        return self._call("unapply_custom_window", self._window_fn(window), None, bool(is_symmetric))
+
+    def windowed_custom_fft(self, window, is_symmetric=True):
+        return self._call("windowed_custom_fft", self._window_fn(window), None, bool(is_symmetric))
+
+    def windowed_custom_ifft(self, window, is_symmetric=True):
+        return self._call("windowed_custom_ifft", self._window_fn(window), None, bool(is_symmetric))
+
+    def windowed_custom_sfft(self, window, is_symmetric=True):
+        return self._call("windowed_custom_sfft", self._window_fn(window), None, bool(is_symmetric))
+
+    def windowed_custom_sifft(self, window, is_symmetric=True):
+        return self._call("windowed_custom_sifft", self._window_fn(window), None, bool(is_symmetric))
+
+    # ------------------------------------------------------------------ real interpolation, wrap-around ops
+    def interpolate_lin(self, interpolation_factor, delay=0.0):
+        return self._call("interpolate_lin", interpolation_factor, delay)
+
+    def interpolate_hermite(self, interpolation_factor, delay=0.0):
+        return self._call("interpolate_hermite", interpolation_factor, delay)
+
+    def add_smaller(self, other):
+        return self._call("add_smaller_vector", other._h)
+
+    def sub_smaller(self, other):
+        return self._call("sub_smaller_vector", other._h)
+
+    def mul_smaller(self, other):
+        return self._call("mul_smaller_vector", other._h)
+
+    def div_smaller(self, other):
+        return self._call("div_smaller_vector", other._h)
+
+    def complex_divide(self, value):
+        return self._call("complex_divide", value.real, value.imag)
+
+    def set_value(self, index, value):
+        self._fn("set_value")(self._h, int(index), value)
+
+    def allocated_len(self):
+        return self._fn("get_allocated_len")(self._h)
+
     def interpolatef(self, function, interpolation_factor, delay, conv_len, rolloff=0.0):
         return self._call("interpolatef", int(function), rolloff, interpolation_factor, delay,
                           int(conv_len))

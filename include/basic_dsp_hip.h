@@ -24,6 +24,7 @@
 #define BASIC_DSP_HIP_H
 
 #include <stddef.h>
+#include <stdbool.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -210,6 +211,54 @@ VectorInteropResult32 plain_sifft32(VecBuf32 *vector);                         /
 VectorInteropResult32 sifft32(VecBuf32 *vector);                               /* facade32.rs:954-956 */
 VectorInteropResult32 windowed_sifft32(VecBuf32 *vector, int32_t window);      /* facade32.rs:1018-1024 */
 
+/* Correlation, function convolution, real interpolation, wrap-around binary ops, callback variants.
+ * Callbacks (interop/src/lib.rs:245-377) cannot run on the device: the host samples them once into a
+ * table (window: every point, or the first half mirrored when is_symmetric; convolution: 2*len+1
+ * weights; frequency response: one value per bin) and a device kernel applies the table. */
+typedef float (*bdsp_window_fn32)(const void *window_data, size_t n, size_t length);   /* lib.rs:306-311 */
+typedef float (*bdsp_real_fn32)(const void *function_data, float x);                     /* lib.rs:245-250 */
+VecBuf32 *new_with_detailed_performance_options32(int32_t is_complex, int32_t domain, float init_value,
+        size_t length, float delta, size_t core_limit, size_t med_dual_core_threshold,
+        size_t med_multi_core_threshold, size_t large_dual_core_threshold,
+        size_t large_multi_core_threshold);                                         /* facade32.rs:70-102 (options ignored) */
+void set_value32(VecBuf32 *vector, size_t index, float value);                        /* facade32.rs:110-112 */
+size_t get_allocated_len32(const VecBuf32 *vector);                                 /* facade32.rs:168-170 */
+const float *complex_data32(VecBuf32 *vector);  /* facade32.rs:163-165; interleaved pairs, host mirror like data32 */
+VectorInteropResult32 complex_divide32(VecBuf32 *vector, float re, float im);           /* facade32.rs:550-556 */
+VectorInteropResult32 add_vector32(VecBuf32 *vector, const VecBuf32 *operand);      /* facade32.rs:704-709 */
+VectorInteropResult32 sub_vector32(VecBuf32 *vector, const VecBuf32 *operand);      /* facade32.rs:712-717 */
+VectorInteropResult32 div_vector32(VecBuf32 *vector, const VecBuf32 *operand);      /* facade32.rs:720-725 */
+VectorInteropResult32 mul_vector32(VecBuf32 *vector, const VecBuf32 *operand);      /* facade32.rs:728-733 */
+VectorInteropResult32 add_smaller_vector32(VecBuf32 *vector, const VecBuf32 *operand); /* facade32.rs:736-741 */
+VectorInteropResult32 sub_smaller_vector32(VecBuf32 *vector, const VecBuf32 *operand); /* facade32.rs:744-749 */
+VectorInteropResult32 div_smaller_vector32(VecBuf32 *vector, const VecBuf32 *operand); /* facade32.rs:752-757 */
+VectorInteropResult32 mul_smaller_vector32(VecBuf32 *vector, const VecBuf32 *operand); /* facade32.rs:760-765 */
+VectorInteropResult32 prepare_argument32(VecBuf32 *vector);                         /* facade32.rs:1156-1158 */
+VectorInteropResult32 prepare_argument_padded32(VecBuf32 *vector);                  /* facade32.rs:1161-1163 */
+VectorInteropResult32 correlate32(VecBuf32 *vector, const VecBuf32 *other);         /* facade32.rs:1166-1168 */
+VectorInteropResult32 convolve32(VecBuf32 *vector, int32_t impulse_response, float rolloff, float ratio,
+                                 size_t len);                                       /* facade32.rs:1231-1240 */
+VectorInteropResult32 convolve_real32(VecBuf32 *vector, bdsp_real_fn32 impulse_response,
+                                      const void *impulse_response_data, bool is_symmetric, float ratio,
+                                      size_t len);                                  /* facade32.rs:1183-1203 */
+VectorInteropResult32 multiply_frequency_response_real32(VecBuf32 *vector, bdsp_real_fn32 frequency_response,
+                                      const void *frequency_response_data, bool is_symmetric,
+                                      float ratio);                                   /* facade32.rs:1247-1262 */
+VectorInteropResult32 interpolate_lin32(VecBuf32 *vector, float interpolation_factor, float delay);     /* facade32.rs:1437-1443 */
+VectorInteropResult32 interpolate_hermite32(VecBuf32 *vector, float interpolation_factor, float delay); /* facade32.rs:1446-1452 */
+VectorInteropResult32 apply_custom_window32(VecBuf32 *vector, bdsp_window_fn32 window, const void *window_data,
+                                            bool is_symmetric);                     /* facade32.rs:1030-1044 */
+VectorInteropResult32 unapply_custom_window32(VecBuf32 *vector, bdsp_window_fn32 window, const void *window_data,
+                                              bool is_symmetric);                   /* facade32.rs:1049-1063 */
+VectorInteropResult32 windowed_custom_fft32(VecBuf32 *vector, bdsp_window_fn32 window, const void *window_data,
+                                            bool is_symmetric);                     /* facade32.rs:1068-1082 */
+VectorInteropResult32 windowed_custom_sfft32(VecBuf32 *vector, bdsp_window_fn32 window, const void *window_data,
+                                             bool is_symmetric);                    /* facade32.rs:1087-1101 */
+VectorInteropResult32 windowed_custom_ifft32(VecBuf32 *vector, bdsp_window_fn32 window, const void *window_data,
+                                             bool is_symmetric);                    /* facade32.rs:1106-1120 */
+VectorInteropResult32 windowed_custom_sifft32(VecBuf32 *vector, bdsp_window_fn32 window, const void *window_data,
+                                              bool is_symmetric);                   /* facade32.rs:1125-1139 */
+
 VecBuf64 *new64(int32_t is_complex, int32_t domain, double init_value, size_t length, double delta);
 VecBuf64 *new_with_performance_options64(int32_t is_complex, int32_t domain, double init_value,
                                          size_t length, double delta, size_t core_limit,
@@ -275,6 +324,54 @@ VectorInteropResult64 windowed_sfft64(VecBuf64 *vector, int32_t window);
 VectorInteropResult64 plain_sifft64(VecBuf64 *vector);
 VectorInteropResult64 sifft64(VecBuf64 *vector);
 VectorInteropResult64 windowed_sifft64(VecBuf64 *vector, int32_t window);
+
+/* Correlation, function convolution, real interpolation, wrap-around binary ops, callback variants.
+ * Callbacks (interop/src/lib.rs:245-377) cannot run on the device: the host samples them once into a
+ * table (window: every point, or the first half mirrored when is_symmetric; convolution: 2*len+1
+ * weights; frequency response: one value per bin) and a device kernel applies the table. */
+typedef double (*bdsp_window_fn64)(const void *window_data, size_t n, size_t length);   /* lib.rs:306-311 */
+typedef double (*bdsp_real_fn64)(const void *function_data, double x);                     /* lib.rs:245-250 */
+VecBuf64 *new_with_detailed_performance_options64(int32_t is_complex, int32_t domain, double init_value,
+        size_t length, double delta, size_t core_limit, size_t med_dual_core_threshold,
+        size_t med_multi_core_threshold, size_t large_dual_core_threshold,
+        size_t large_multi_core_threshold);                                         /* facade32.rs:70-102 (options ignored) */
+void set_value64(VecBuf64 *vector, size_t index, double value);                        /* facade32.rs:110-112 */
+size_t get_allocated_len64(const VecBuf64 *vector);                                 /* facade32.rs:168-170 */
+const double *complex_data64(VecBuf64 *vector);  /* facade32.rs:163-165; interleaved pairs, host mirror like data64 */
+VectorInteropResult64 complex_divide64(VecBuf64 *vector, double re, double im);           /* facade32.rs:550-556 */
+VectorInteropResult64 add_vector64(VecBuf64 *vector, const VecBuf64 *operand);      /* facade32.rs:704-709 */
+VectorInteropResult64 sub_vector64(VecBuf64 *vector, const VecBuf64 *operand);      /* facade32.rs:712-717 */
+VectorInteropResult64 div_vector64(VecBuf64 *vector, const VecBuf64 *operand);      /* facade32.rs:720-725 */
+VectorInteropResult64 mul_vector64(VecBuf64 *vector, const VecBuf64 *operand);      /* facade32.rs:728-733 */
+VectorInteropResult64 add_smaller_vector64(VecBuf64 *vector, const VecBuf64 *operand); /* facade32.rs:736-741 */
+VectorInteropResult64 sub_smaller_vector64(VecBuf64 *vector, const VecBuf64 *operand); /* facade32.rs:744-749 */
+VectorInteropResult64 div_smaller_vector64(VecBuf64 *vector, const VecBuf64 *operand); /* facade32.rs:752-757 */
+VectorInteropResult64 mul_smaller_vector64(VecBuf64 *vector, const VecBuf64 *operand); /* facade32.rs:760-765 */
+VectorInteropResult64 prepare_argument64(VecBuf64 *vector);                         /* facade32.rs:1156-1158 */
+VectorInteropResult64 prepare_argument_padded64(VecBuf64 *vector);                  /* facade32.rs:1161-1163 */
+VectorInteropResult64 correlate64(VecBuf64 *vector, const VecBuf64 *other);         /* facade32.rs:1166-1168 */
+VectorInteropResult64 convolve64(VecBuf64 *vector, int32_t impulse_response, double rolloff, double ratio,
+                                 size_t len);                                       /* facade32.rs:1231-1240 */
+VectorInteropResult64 convolve_real64(VecBuf64 *vector, bdsp_real_fn64 impulse_response,
+                                      const void *impulse_response_data, bool is_symmetric, double ratio,
+                                      size_t len);                                  /* facade32.rs:1183-1203 */
+VectorInteropResult64 multiply_frequency_response_real64(VecBuf64 *vector, bdsp_real_fn64 frequency_response,
+                                      const void *frequency_response_data, bool is_symmetric,
+                                      double ratio);                                   /* facade32.rs:1247-1262 */
+VectorInteropResult64 interpolate_lin64(VecBuf64 *vector, double interpolation_factor, double delay);     /* facade32.rs:1437-1443 */
+VectorInteropResult64 interpolate_hermite64(VecBuf64 *vector, double interpolation_factor, double delay); /* facade32.rs:1446-1452 */
+VectorInteropResult64 apply_custom_window64(VecBuf64 *vector, bdsp_window_fn64 window, const void *window_data,
+                                            bool is_symmetric);                     /* facade32.rs:1030-1044 */
+VectorInteropResult64 unapply_custom_window64(VecBuf64 *vector, bdsp_window_fn64 window, const void *window_data,
+                                              bool is_symmetric);                   /* facade32.rs:1049-1063 */
+VectorInteropResult64 windowed_custom_fft64(VecBuf64 *vector, bdsp_window_fn64 window, const void *window_data,
+                                            bool is_symmetric);                     /* facade32.rs:1068-1082 */
+VectorInteropResult64 windowed_custom_sfft64(VecBuf64 *vector, bdsp_window_fn64 window, const void *window_data,
+                                             bool is_symmetric);                    /* facade32.rs:1087-1101 */
+VectorInteropResult64 windowed_custom_ifft64(VecBuf64 *vector, bdsp_window_fn64 window, const void *window_data,
+                                             bool is_symmetric);                    /* facade32.rs:1106-1120 */
+VectorInteropResult64 windowed_custom_sifft64(VecBuf64 *vector, bdsp_window_fn64 window, const void *window_data,
+                                              bool is_symmetric);                   /* facade32.rs:1125-1139 */
 
 /* Device pointer of the handle's live buffer (valid until the next mutating call); lets the
  * batch driver feed RCCL without a host round trip.  No reference counterpart. */

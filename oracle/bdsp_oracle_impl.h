@@ -888,3 +888,144 @@ size_t SFX(orc_decimatei)(const REAL *x, size_t len, int is_complex, unsigned fa
         for (size_t e = 0; e < elem; ++e) out[j * elem + e] = x[i * elem + e];
     return j * elem;
 }
+
+/* ------------------------------------------------------------------------------------------
+ * convolve(function, ratio, len) in the time domain: convolve_function_priv
+ * (time_freq/mod.rs:174-213).  WrappingIterator pre-increments (mod.rs:741-757), so the window of
+ * output i is x[i-L .. i+L] (wrapping), weighted by f(-j*ratio), j = -L .. L accumulated in REAL.
+ * conv_len is clamped to the number of points (:197).
+ * ---------------------------------------------------------------------------------------- */
+void SFX(orc_convolve_function)(const REAL *x, size_t len, int is_complex, int fid, REAL rolloff,
+                                REAL ratio, size_t conv_len, REAL *out)
+{
+    size_t elem = is_complex ? 2 : 1, points = len / elem;
+    if (points == 0) return;
+    if (conv_len > points) conv_len = points;
+    for (size_t i = 0; i < points; ++i) {
+        REAL sre = 0, sim = 0;
+        REAL j = -(REAL)conv_len;
+        for (size_t k = 0; k < 2 * conv_len + 1; ++k) {
+            size_t p = SFX(wrap)((long long)i - (long long)conv_len + (long long)k, points);
+            REAL w = SFX(orc_conv_time)(fid, rolloff, -j * ratio);
+            if (is_complex) {
+                /* Complex * Complex::new(w, 0) */
+                REAL re = x[2 * p], im = x[2 * p + 1];
+                sre = sre + (re * w - im * (REAL)0);
+                sim = sim + (re * (REAL)0 + im * w);
+            } else {
+                sre = sre + x[p] * w;
+            }
+            j = j + (REAL)1;
+        }
+        out[i * elem] = sre;
+        if (is_complex) out[i * elem + 1] = sim;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Cross correlation (time_freq/correlation.rs:96-160).
+ * prepare_argument(_padded): [zero_pad_b(2*points-1, Surround)] -> plain_fft -> conj.
+ * correlate: zero_pad_b(other.points, Surround) -> plain_fft -> mul(other) -> plain_ifft ->
+ * scale(1/points) -> swap_halves.  All vectors complex.  `arg` is the PREPARED argument
+ * (arg_len scalars); out holds arg_len scalars.  Returns 0, 7 (other not longer than self:
+ * zero_pad_b fails) -- the caller checks domains.
+ * ---------------------------------------------------------------------------------------- */
+int SFX(orc_prepare_argument)(const REAL *x, size_t len, int padded, REAL *out)
+{
+    size_t points = len / 2, np = padded ? 2 * points - 1 : points;
+    if (padded) {
+        if (SFX(orc_zero_pad)(x, len, 1, np, 1, 1, out)) return 7;
+    } else {
+        memcpy(out, x, len * sizeof(REAL));
+    }
+    SFX(orc_fft)(out, np, 0);
+    SFX(orc_conj)(out, 2 * np);
+    return 0;
+}
+
+int SFX(orc_correlate)(const REAL *x, size_t len, const REAL *arg, size_t arg_len, REAL *out)
+{
+    size_t points = arg_len / 2;
+    int code = SFX(orc_zero_pad)(x, len, 1, points, 1, 1, out);
+    if (code) return code;
+    SFX(orc_fft)(out, points, 0);
+    SFX(orc_binary)(out, arg_len, arg, arg_len, 1, 2);
+    SFX(orc_fft)(out, points, 1);
+    SFX(orc_real_scale)(out, arg_len, (REAL)1 / (REAL)points);
+    SFX(orc_swap_halves)(out, arg_len, 1, 1);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Real-only interpolation between samples (time_freq/real_interpolation.rs:33-176).
+ * dest_len = round((len-1)*factor) + 1; no wrap-around.  Index reads the reference would panic on
+ * (delay pushing `before+1` past the end) are clamped to the last sample here.
+ * ---------------------------------------------------------------------------------------- */
+size_t SFX(orc_interpolate_real_len)(size_t len, REAL factor)
+{
+    return (size_t)R_ROUND((REAL)(len - 1) * factor) + 1;
+}
+
+static inline REAL SFX(at)(const REAL *x, size_t len, long long i)
+{
+    if (i < 0) i = 0;
+    if ((size_t)i >= len) i = (long long)len - 1;
+    return x[i];
+}
+
+void SFX(orc_interpolate_lin)(const REAL *x, size_t len, REAL factor, REAL delay, REAL *out)
+{
+    size_t dest_len = SFX(orc_interpolate_real_len)(len, factor);
+    REAL i = 0;
+    for (size_t n = 0; n + 1 < dest_len; ++n) {
+        REAL rounded = i / factor + delay;
+        REAL beforef = R_FLOOR(rounded);
+        long long before = (long long)beforef;
+        REAL y0 = SFX(at)(x, len, before), y1 = SFX(at)(x, len, before + 1);
+        out[n] = y0 + (y1 - y0) * (rounded - beforef);
+        i = i + (REAL)1;
+    }
+    out[dest_len - 1] = x[len - 1];
+}
+
+static REAL SFX(hermite)(REAL y0, REAL y1, REAL y2, REAL y3, REAL x)
+{
+    const REAL half = (REAL)0.5, c15 = (REAL)1.5, two = (REAL)2, c25 = (REAL)2.5;
+    REAL x2 = x * x;
+    REAL a0 = -half * y0 + c15 * y1 - c15 * y2 + half * y3;
+    REAL a1 = y0 - c25 * y1 + two * y2 - half * y3;
+    REAL a2 = -half * y0 + half * y2;
+    REAL a3 = y1;
+    return (a0 * x * x2) + (a1 * x2) + (a2 * x) + a3;
+}
+
+void SFX(orc_interpolate_hermite)(const REAL *x, size_t len, REAL factor, REAL delay, REAL *out)
+{
+    size_t dest_len = SFX(orc_interpolate_real_len)(len, factor);
+    size_t start = (size_t)(-R_FLOOR(-(((REAL)1 - delay) * factor))); /* ceil */
+    size_t end = start + 1;
+    if (start > dest_len) start = dest_len;
+    size_t tail = dest_len > end ? dest_len - end : 0;
+    if (tail < start) tail = start;
+    REAL i = 0;
+    for (size_t n = 0; n < dest_len; ++n) {
+        REAL rounded = i / factor + delay;
+        REAL beforef = R_FLOOR(rounded);
+        long long before = (long long)beforef;
+        REAL xf = rounded - beforef;
+        REAL y0, y1, y2, y3;
+        if (n < start) { /* :103-124 first interval: y0 extrapolated */
+            y1 = SFX(at)(x, len, before); y2 = SFX(at)(x, len, before + 1); y3 = SFX(at)(x, len, before + 2);
+            y0 = y1 - (y2 - y1);
+        } else if (n < tail) { /* :126-145 */
+            y0 = SFX(at)(x, len, before - 1); y1 = SFX(at)(x, len, before);
+            y2 = SFX(at)(x, len, before + 1); y3 = SFX(at)(x, len, before + 2);
+        } else { /* :147-172 last intervals: y2/y3 extrapolated when past the end */
+            y0 = SFX(at)(x, len, before - 1); y1 = SFX(at)(x, len, before);
+            y2 = (before >= 0 && (size_t)before < len - 1) ? x[before + 1] : y1 + (y1 - y0);
+            y3 = (before >= 0 && (size_t)before + 2 < len) ? x[before + 2] : y2 + (y2 - y1);
+        }
+        out[n] = SFX(hermite)(y0, y1, y2, y3, xf);
+        i = i + (REAL)1;
+    }
+}

@@ -273,3 +273,45 @@ def decimatei(x, is_complex, factor, delay):
     x = np.ascontiguousarray(x); out = np.zeros_like(x); fn = _fn("orc_decimatei", x.dtype)
     fn.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_uint, C.c_uint, C.c_void_p]; fn.restype = C.c_size_t
     n = fn(_p(x), x.size, int(is_complex), factor, delay, _p(out)); return out[:n]
+
+
+def convolve_function(x, is_complex, fid, rolloff, ratio, conv_len):
+    x = np.ascontiguousarray(x); out = np.zeros_like(x); fn = _fn("orc_convolve_function", x.dtype); r = _real(x.dtype)
+    fn.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, r, r, C.c_size_t, C.c_void_p]; fn.restype = None
+    fn(_p(x), x.size, int(is_complex), fid, rolloff, ratio, conv_len, _p(out)); return out
+
+
+def prepare_argument(x, padded):
+    x = np.ascontiguousarray(x); points = x.size // 2
+    out = np.zeros(2 * (2 * points - 1 if padded else points), dtype=x.dtype)
+    fn = _fn("orc_prepare_argument", x.dtype)
+    fn.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]; fn.restype = C.c_int
+    code = fn(_p(x), x.size, int(padded), _p(out)); return code, out
+
+
+def correlate(x, arg):
+    x = np.ascontiguousarray(x); arg = np.ascontiguousarray(arg, dtype=x.dtype); out = np.zeros_like(arg)
+    fn = _fn("orc_correlate", x.dtype)
+    fn.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]; fn.restype = C.c_int
+    code = fn(_p(x), x.size, _p(arg), arg.size, _p(out)); return code, out
+
+
+def interpolate_real_len(length, factor, dtype=np.float32):
+    fn = _fn("orc_interpolate_real_len", np.dtype(dtype)); r = _real(np.dtype(dtype))
+    fn.argtypes = [C.c_size_t, r]; fn.restype = C.c_size_t
+    return fn(length, factor)
+
+
+def _interp_real(name, x, factor, delay):
+    x = np.ascontiguousarray(x); out = np.zeros(interpolate_real_len(x.size, factor, x.dtype), dtype=x.dtype)
+    fn = _fn(name, x.dtype); r = _real(x.dtype)
+    fn.argtypes = [C.c_void_p, C.c_size_t, r, r, C.c_void_p]; fn.restype = None
+    fn(_p(x), x.size, factor, delay, _p(out)); return out
+
+
+def interpolate_lin(x, factor, delay=0.0):
+    return _interp_real("orc_interpolate_lin", x, factor, delay)
+
+
+def interpolate_hermite(x, factor, delay=0.0):
+    return _interp_real("orc_interpolate_hermite", x, factor, delay)

@@ -14,6 +14,7 @@ def declared_functions():
     text = open(HEADER).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     text = re.sub(r"^\s*#.*$", "", text, flags=re.M)  # preprocessor lines (#define X (-1) ...)
+    text = re.sub(r"typedef[^;{]*\(\s*\*[^;]*;", "", text)  # function-pointer typedefs are not exports
     names = re.findall(r"\b([A-Za-z_][A-Za-z0-9_]*)\s*\([^;{}]*\)\s*;", text)
     return sorted(set(n for n in names if n not in ("defined",)))
 

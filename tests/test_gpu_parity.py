@@ -509,3 +509,135 @@ def test_symmetric_fft_family(dtype):
     assert DspVec(np.zeros(10, dtype), is_complex=True).plain_sifft() == 6  # must be frequency domain
     bad = DspVec(np.array([1.0, 0.5, 2.0, 0.0], dtype), is_complex=True, domain=V.FREQ)
     assert bad.plain_sifft() == 8                                            # first bin must be real
+
+
+# ------------------------------------------------------------------ correlate, convolve(function), real interpolation
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_correlate_and_prepare_argument(dtype):
+    # the doc example and KAT of correlation.rs:52-62, 201-215
+    a = DspVec(np.array([1, 1, 2, 1, 3, 1], dtype), is_complex=True)
+    b = DspVec(np.array([4, 1, 5, 1, 6, 1], dtype), is_complex=True)
+    assert b.prepare_argument_padded() == 0
+    assert b.domain() == V.FREQ and b.points() == 5
+    assert a.correlate(b) == 0
+    np.testing.assert_allclose(a.data(), [7, 5, 19, 8, 35, 9, 25, 4, 13, 1], atol=1e-4)
+    assert a.delta() == 1.0 and a.domain() == V.TIME
+    tol = 2e-6 if dtype == np.float32 else 1e-12
+    for n in (100, 1000, 4097):
+        x = orc.fill_uniform(2 * n, 11 + n, -10, 10, dtype)
+        y = orc.fill_uniform(2 * n, 12 + n, -10, 10, dtype)
+        for padded in (True, False):
+            arg = DspVec(y, is_complex=True)
+            assert (arg.prepare_argument_padded() if padded else arg.prepare_argument()) == 0
+            _, ref_arg = orc.prepare_argument(y.astype(np.float64), padded)
+            assert rel_l2(arg.data(), ref_arg) < tol
+            v = DspVec(x, is_complex=True)
+            code = v.correlate(arg)
+            ref_code, ref = orc.correlate(x.astype(np.float64), ref_arg)
+            assert code == ref_code == (0 if padded else 7)  # an unpadded argument is not longer: zero_pad_b fails
+            if code == 0:
+                assert rel_l2(v.data(), ref) < tol, (n, padded)
+    # type-state errors (correlation.rs:134-146): both report InputMustBeInTimeDomain and poison
+    t = DspVec(np.ones(8, dtype), is_complex=True)
+    notprepared = DspVec(np.ones(16, dtype), is_complex=True)
+    assert t.correlate(notprepared) == 5 and t.is_erroneous()
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_convolve_with_function(dtype):
+    # KATs convolution.rs:651-702
+    x = np.zeros(10, dtype)
+    x[5] = 1.0
+    v = DspVec(x)
+    assert v.convolve(V.CONV_RAISED_COSINE, 0.2, 5, rolloff=0.35) == 0
+    np.testing.assert_allclose(v.data(), [0.0, 0.2171850639713355, 0.4840621929215732, 0.7430526238101408,
+                                          0.9312114164253432, 1.0, 0.9312114164253432, 0.7430526238101408,
+                                          0.4840621929215732, 0.2171850639713355], atol=1e-4)
+    tol = 2e-6 if dtype == np.float32 else 1e-12
+    for cplx in (True, False):
+        e = 2 if cplx else 1
+        # (points, L): table longer than the vector, equal, overlap-save path, long vector
+        for points, L, ratio in ((11, 5, 0.5), (8, 8, 0.25), (7, 20, 0.3), (5000, 12, 0.25), (70000, 300, 0.1)):
+            xx = orc.fill_uniform(points * e, 900 + points, -10, 10, dtype)
+            for fid, ro in ((0, 0.0), (1, 0.35)):
+                v = DspVec(xx, is_complex=cplx)
+                assert v.convolve(fid, ratio, L, rolloff=ro) == 0
+                ref = orc.convolve_function(xx.astype(np.float64), cplx, fid, ro, ratio, L)
+                assert rel_l2(v.data(), ref) < tol, (cplx, points, L, fid)
+    # the callback variant samples the function on the host
+    xx = orc.fill_uniform(2 * 1000, 4, -10, 10, dtype)
+    v = DspVec(xx, is_complex=True)
+    assert v.convolve(lambda t: float(np.sinc(t)), 0.5, 9) == 0
+    ref = orc.convolve_function(xx.astype(np.float64), True, 0, 0.0, 0.5, 9)
+    assert rel_l2(v.data(), ref) < tol
+    f = DspVec(xx, is_complex=True, domain=V.FREQ)
+    assert f.convolve(0, 0.5, 3) == -1  # assert_time!
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_interpolate_lin_hermite_bit_exact(dtype):
+    # KATs real_interpolation.rs:198-237
+    x = np.array([-1.0, -2.0, -1.0, 0.0, 1.0, 3.0, 4.0], dtype)
+    v = DspVec(x)
+    assert v.interpolate_lin(4.0) == 0
+    np.testing.assert_allclose(v.data(), [-1.0, -1.25, -1.5, -1.75, -2.0, -1.75, -1.5, -1.25, -1.0, -0.75, -0.5,
+                                          -0.25, 0.0, 0.25, 0.5, 0.75, 1.0, 1.5, 2.0, 2.5, 3.0, 3.25, 3.5, 3.75,
+                                          4.0], atol=1e-6)
+    for n, factor, delay in ((7, 4.0, 0.0), (7, 3.0, 0.0), (1000, 2.5, 0.0), (4097, 7.0, 0.0), (100000, 1.37, 0.0),
+                             (513, 0.5, 0.0), (2000, 3.0, 0.25)):
+        xx = orc.fill_uniform(n, 50 + n, -10, 10, dtype)
+        for hermite in (False, True):
+            v = DspVec(xx)
+            code = v.interpolate_hermite(factor, delay) if hermite else v.interpolate_lin(factor, delay)
+            assert code == 0
+            ref = (orc.interpolate_hermite if hermite else orc.interpolate_lin)(xx, factor, delay)
+            assert len(v) == ref.size
+            assert np.array_equal(v.data(), ref), (n, factor, delay, hermite)
+    c = DspVec(np.ones(8, dtype), is_complex=True)
+    assert c.interpolate_lin(2.0) == -1  # complex input poisons the vector (real_interpolation.rs:47-50)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_smaller_vector_ops_custom_windows_misc(dtype):
+    for cplx in (False, True):
+        x = orc.fill_uniform(1200, 1, -10, 10, dtype)
+        y = orc.fill_uniform(24, 2, 1, 10, dtype)
+        for op, name in enumerate(("add_smaller", "sub_smaller", "mul_smaller", "div_smaller")):
+            v = DspVec(x, is_complex=cplx)
+            assert getattr(v, name)(DspVec(y, is_complex=cplx)) == 0
+            _, ref = orc.binary(x, np.tile(y, 50), cplx, op)
+            assert np.array_equal(v.data(), ref), (cplx, name)
+        v = DspVec(x, is_complex=cplx)
+        assert v.add_smaller(DspVec(orc.fill_uniform(14, 2, 1, 10, dtype), is_complex=cplx)) == 7
+    # callback windows: sampled on the host, applied on the device; must equal the built-in Hamming
+    x = orc.fill_uniform(2 * 1001, 8, -10, 10, dtype)
+    ham = lambda n, length: 0.54 - 0.46 * np.cos(2 * np.pi * n / (length - 1))  # noqa: E731
+    for sym in (True, False):
+        a, b = DspVec(x, is_complex=True), DspVec(x, is_complex=True)
+        assert a.apply_custom_window(ham, sym) == 0 and b.apply_window(V.WINDOW_HAMMING) == 0
+        assert rel_l2(a.data(), b.data()) < (1e-6 if dtype == np.float32 else 1e-14)
+        assert a.unapply_custom_window(ham, sym) == 0
+        assert rel_l2(a.data(), x) < (1e-6 if dtype == np.float32 else 1e-14)
+    a, b = DspVec(x, is_complex=True), DspVec(x, is_complex=True)
+    assert a.windowed_custom_fft(ham) == 0 and b.windowed_fft(V.WINDOW_HAMMING) == 0
+    assert rel_l2(a.data(), b.data()) < (2e-6 if dtype == np.float32 else 1e-12)
+    assert a.windowed_custom_ifft(ham) == 0 and b.windowed_ifft(V.WINDOW_HAMMING) == 0
+    assert rel_l2(a.data(), b.data()) < (2e-5 if dtype == np.float32 else 1e-10)
+    r = orc.fill_uniform(1001, 9, -10, 10, dtype)
+    a, b = DspVec(r), DspVec(r)
+    assert a.windowed_custom_sfft(ham) == 0 and b.windowed_sfft(V.WINDOW_HAMMING) == 0
+    assert rel_l2(a.data(), b.data()) < (2e-6 if dtype == np.float32 else 1e-12)
+    # callback frequency response equals the built-in raised cosine
+    xs = orc.fill_uniform(2 * 1000, 3, -1, 1, dtype)
+    rc = lambda t: float(orc.conv_freq(1, 0.35, t, np.float64))  # noqa: E731
+    a, b = DspVec(xs, is_complex=True, domain=V.FREQ), DspVec(xs, is_complex=True, domain=V.FREQ)
+    assert a.multiply_frequency_response_fn(rc, 1.7) == 0
+    assert b.multiply_frequency_response(V.CONV_RAISED_COSINE, 1.7, 0.35) == 0
+    assert rel_l2(a.data(), b.data()) < (1e-6 if dtype == np.float32 else 1e-13)
+    # complex_divide, set_value, allocated_len
+    v = DspVec(xs, is_complex=True)
+    assert v.complex_divide(2.0 - 1.5j) == 0
+    assert rel_l2(v.datac(), xs.view(np.complex64 if dtype == np.float32 else np.complex128) / (2.0 - 1.5j)) < \
+        (1e-6 if dtype == np.float32 else 1e-14)
+    v.set_value(3, 42.0)
+    assert v.data()[3] == 42.0 and v.allocated_len() >= len(v)

@@ -403,3 +403,53 @@ def test_decimatei_kat():
     # interpolation.rs:963-969
     got = orc.decimatei(kat("decimatei_test", 0), True, 2, 1)
     assert np.array_equal(got, kat("decimatei_test", 1))
+
+
+# ---------------------------------------------------------------- convolve(function), correlate, real interpolation
+def test_convolve_function_kats():
+    # convolution.rs:651-669: real impulse, raised cosine 0.35, ratio 0.2, len 5
+    x = np.zeros(10, np.float32)
+    x[5] = 1.0
+    got = orc.convolve_function(x, False, 1, 0.35, 0.2, 5)
+    np.testing.assert_allclose(got, kat("convolve_real_time_and_time32"), atol=1e-4)
+    # :672-702: complex impulse, sinc, ratio 0.5, len 11/2 -> magnitude
+    t = np.zeros(22, np.float32)
+    t[11] = 1.0  # data_mut(len): scalar index 11 = imaginary part of point 5
+    got = orc.convolve_function(t, True, 0, 0.0, 0.5, 5)
+    np.testing.assert_allclose(orc.magnitude(got), kat("convolve_complex_time_and_time32"), atol=1e-4)
+
+
+def test_correlate_kats():
+    # correlation.rs:171-215: prepare_argument_padded + correlate, tolerance 0.1
+    for name in ("time_correlation_test", "time_correlation_test2"):
+        a = kat(name, 0).astype(np.float32)
+        b = kat(name, 1).astype(np.float32)
+        code, arg = orc.prepare_argument(b, True)
+        assert code == 0 and arg.size == 2 * (b.size - 1)
+        code, res = orc.correlate(a, arg)
+        assert code == 0
+        np.testing.assert_allclose(res, kat(name, 2), atol=0.1)
+    # the doc example (correlation.rs:52-62)
+    a = np.array([1, 1, 2, 2, 3, 3], np.float32)
+    b = np.array([3, 3, 2, 2, 1, 1], np.float32)
+    _, arg = orc.prepare_argument(b, True)
+    _, res = orc.correlate(a, arg)
+    np.testing.assert_allclose(res, [2, 0, 8, 0, 20, 0, 24, 0, 18, 0], atol=1e-4)
+    # an argument that is not longer than the vector makes zero_pad_b fail (code 7)
+    _, arg = orc.prepare_argument(b, False)
+    code, _ = orc.correlate(np.ones(8, np.float32), arg)
+    assert code == 7
+
+
+def test_real_interpolation_kats():
+    # real_interpolation.rs:198-237
+    x = kat("hermit_spline_test", 0).astype(np.float32)
+    got = orc.interpolate_hermite(x, 4.0)
+    exp = kat("hermit_spline_test", 1)
+    assert got.size == exp.size
+    np.testing.assert_allclose(got[4:-4], exp[4:-4], atol=6e-2)
+    x = kat("hermit_spline_test_linear_increment", 0).astype(np.float32)
+    np.testing.assert_allclose(orc.interpolate_hermite(x, 3.0), kat("hermit_spline_test_linear_increment", 1),
+                               atol=5e-3)
+    x = kat("linear_test", 0).astype(np.float32)
+    np.testing.assert_allclose(orc.interpolate_lin(x, 4.0), kat("linear_test", 1), atol=0.1)

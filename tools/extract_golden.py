@@ -49,6 +49,10 @@ SOURCES = [
         "interpolatef_by_integer_sinc_odd_test", "interpolatef_by_fractional_sinc_test",
         "interpolate_by_fractional_sinc_test", "interpolatef_delayed_sinc_test",
         "interpolate_delayed_sinc_test", "decimatei_test", "decimate_with_interpolate_test"]),
+    ("vector/src/vector_types/time_freq/correlation.rs", ["time_correlation_test",
+                                                          "time_correlation_test2"]),
+    ("vector/src/vector_types/time_freq/real_interpolation.rs", [
+        "hermit_spline_test", "hermit_spline_test_linear_increment", "linear_test"]),
 ]
 
 NUM = r"[-+]?(?:\d+\.\d*|\.\d+|\d+)(?:[eE][-+]?\d+)?"
