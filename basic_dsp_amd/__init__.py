@@ -6,5 +6,6 @@ benchmark and the multi-GPU batch driver; it has no CPU fallback.
 """
 from ._lib import BackendError, LIB_PATH, lib, last_error, require_gpu  # noqa: F401
 from .vector import DspVec  # noqa: F401
+from .matrix import DspMat  # noqa: F401
 
-__all__ = ["DspVec", "BackendError", "lib", "LIB_PATH", "last_error", "require_gpu"]
+__all__ = ["DspVec", "DspMat", "BackendError", "lib", "LIB_PATH", "last_error", "require_gpu"]

@@ -138,6 +138,36 @@ for _s, _t, _R in (("32", _F, VectorInteropResult32), ("64", _D, VectorInteropRe
                "windowed_custom_sfft", "windowed_custom_ifft", "windowed_custom_sifft"):
         _proto(_n + _s, _R, _P, _P, _P, C.c_bool)
 
+    # matrix / batch API
+    _m = "bdsp_hip_mat_"
+    _proto(_m + "new" + _s, _P, C.c_int32, C.c_int32, _SZ, _SZ, _t)
+    _proto(_m + "delete" + _s, None, _P)
+    for _n in ("rows", "row_len", "row_points"):
+        _proto(_m + _n + _s, _SZ, _P)
+    for _n in ("is_complex", "get_domain"):
+        _proto(_m + _n + _s, C.c_int32, _P)
+    _proto(_m + "get_delta" + _s, _t, _P)
+    _proto(_m + "device_ptr" + _s, _P, _P)
+    _proto(_m + "upload" + _s, C.c_int32, _P, _P, _SZ)
+    _proto(_m + "download" + _s, C.c_int32, _P, _P, _SZ)
+    _proto(_m + "get_row" + _s, _P, _P, _SZ)
+    _proto(_m + "set_row" + _s, C.c_int32, _P, _SZ, _P)
+    for _n in ("real_scale", "real_offset"):
+        _proto(_m + _n + _s, C.c_int32, _P, _t)
+    _proto(_m + "complex_scale" + _s, C.c_int32, _P, _t, _t)
+    for _n in ("conj", "magnitude", "magnitude_squared", "to_real", "to_imag", "phase", "plain_fft", "fft",
+               "plain_ifft", "ifft", "swap_halves", "fft_shift", "ifft_shift"):
+        _proto(_m + _n + _s, C.c_int32, _P)
+    for _n in ("add", "sub", "mul", "div", "add_vector", "sub_vector", "mul_vector", "div_vector",
+               "convolve_signal"):
+        _proto(_m + _n + _s, C.c_int32, _P, _P)
+    for _n in ("windowed_fft", "windowed_ifft", "apply_window", "unapply_window"):
+        _proto(_m + _n + _s, C.c_int32, _P, C.c_int32)
+    _proto(_m + "zero_pad" + _s, C.c_int32, _P, _SZ, C.c_int32)
+    _proto(_m + "convolve_signal_mat" + _s, C.c_int32, _P, C.POINTER(_P), _SZ)
+    _proto(_m + "interpolatef" + _s, C.c_int32, _P, C.c_int32, _t, _t, _t, _SZ)
+    _proto(_m + "multiply_frequency_response" + _s, C.c_int32, _P, C.c_int32, _t, _t)
+
 WINDOW_FN32 = C.CFUNCTYPE(_F, _P, _SZ, _SZ)
 WINDOW_FN64 = C.CFUNCTYPE(_D, _P, _SZ, _SZ)
 REAL_FN32 = C.CFUNCTYPE(_F, _P, _F)

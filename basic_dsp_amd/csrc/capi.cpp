@@ -204,18 +204,18 @@ int conv_complex_dev(const T* in, T* out, size_t points, size_t batch, const T* 
 
 // real data: complexify (zero imaginary parts), run the complex path, keep the real parts
 template <typename T>
-int conv_real_dev(const T* in, T* out, size_t points, const T* taps, size_t ntaps, hipStream_t s)
+int conv_real_dev(const T* in, T* out, size_t points, const T* taps, size_t ntaps, hipStream_t s, size_t batch = 1)
 {
     if (!(ntaps >= 1 && ntaps - 1 <= 1024 && ntaps <= points))
-        return convolve_direct<T>(in, out, points, 1, taps, ntaps, false, s);
+        return convolve_direct<T>(in, out, points, batch, taps, ntaps, false, s);
     WsBlock xc, yc, hc;
-    BDSP_TRY(xc.alloc(sizeof(T) * 2 * points, s));
-    BDSP_TRY(yc.alloc(sizeof(T) * 2 * points, s));
+    BDSP_TRY(xc.alloc(sizeof(T) * 2 * points * batch, s));
+    BDSP_TRY(yc.alloc(sizeof(T) * 2 * points * batch, s));
     BDSP_TRY(hc.alloc(sizeof(T) * 2 * ntaps, s));
-    BDSP_TRY(rg_zero_interleave<T>(in, xc.as<T>(), points, 1, 2, s));
+    BDSP_TRY(rg_zero_interleave<T>(in, xc.as<T>(), points * batch, 1, 2, s));
     BDSP_TRY(rg_zero_interleave<T>(taps, hc.as<T>(), ntaps, 1, 2, s));
-    BDSP_TRY(conv_complex_dev<T>(xc.as<T>(), yc.as<T>(), points, 1, hc.as<T>(), ntaps, s));
-    return ew_complex_to_real<T>(yc.as<T>(), out, 2 * points, 2, s);
+    BDSP_TRY(conv_complex_dev<T>(xc.as<T>(), yc.as<T>(), points, batch, hc.as<T>(), ntaps, s));
+    return ew_complex_to_real<T>(yc.as<T>(), out, 2 * points * batch, 2, s);
 }
 
 template <typename T>
@@ -435,8 +435,10 @@ void map_window(int id, int* wid, T* alpha)
 // plain_fft / fft / windowed_fft (time_to_freq.rs:136-176) and plain_ifft / ifft / windowed_ifft
 // (freq_to_time.rs:136-177) with the shift, window and 1/N scale fused into the transform.
 template <typename T>
-int op_fft(DevVec<T>* v, bool inverse, bool shift, int window /* -1 none */)
+int op_fft(DevVec<T>* v, bool inverse, bool shift, int window /* -1 none */, size_t rows = 1)
 {
+    // rows > 1: the vector holds `rows` equally long rows back to back (the matrix API); every row is
+    // transformed by the same batched launches
     hipStream_t s = lib_stream();
     if (!inverse) {
         if (v->freq) { v->poison(); v->complex_ = true; v->freq = true; return BDSP_OK; } // :140-145
@@ -444,7 +446,7 @@ int op_fft(DevVec<T>* v, bool inverse, bool shift, int window /* -1 none */)
         if (!v->freq) { v->poison(); v->complex_ = true; v->freq = true; return BDSP_OK; } // :142-147
     }
     unsigned flags = 0;
-    size_t points = v->points();
+    size_t points = v->points() / rows;
     if (!v->complex_) { // real input is zero-interleaved to complex first (:147-150)
         flags |= FFT_IN_REAL;
         BDSP_TRY(v->reserve(2 * v->valid_len));
@@ -476,11 +478,13 @@ int op_fft(DevVec<T>* v, bool inverse, bool shift, int window /* -1 none */)
     if (out_div) flags &= ~FFT_WINDOW_OUT_DIV;
     int fwid = (out_div ? -1 : wid);
     bool in_b = false;
-    BDSP_TRY(fft_two_buffers<T>(v->data, v->buf, points, 1, inverse, flags, in_scale, fwid, alpha, &in_b, s));
+    BDSP_TRY(fft_two_buffers<T>(v->data, v->buf, points, rows, inverse, flags, in_scale, fwid, alpha, &in_b, s));
     if (in_b) v->trade();
-    v->valid_len = 2 * points;
+    v->valid_len = 2 * points * rows;
     v->complex_ = true;
-    if (out_div) BDSP_TRY(ew_window<T>(v->data, v->valid_len, true, wid, alpha, true, s));
+    if (out_div)
+        for (size_t r = 0; r < rows; ++r)
+            BDSP_TRY(ew_window<T>(v->data + 2 * points * r, 2 * points, true, wid, alpha, true, s));
     // fft(): delta <- points * delta (time_freq/mod.rs:54-55; the reference's own GPU branch
     // forgets this, SURVEY.md section 3.1 -- the CPU behaviour is the contract)
     v->delta = (T)points * v->delta;
@@ -939,6 +943,220 @@ const T* vec_download(DevVec<T>* v)
     return v->mirror.data();
 }
 
+// ----------------------------------------------------------------------------------------------
+// Matrix / batch API: `rows` equally long vectors back to back in ONE allocation, every operation a
+// batched launch over all rows.  Mirrors the matrix crate (matrix/src/lib.rs:195-208 applies an
+// operation to the rows one after the other; matrix/src/time_freq.rs:49-530 forwards the
+// time/frequency traits row by row) -- here the row loop is the grid's batch dimension.
+// ----------------------------------------------------------------------------------------------
+template <typename T>
+struct DevMat {
+    DevVec<T> v;       // flat storage: rows * row_len scalars, shared metadata
+    size_t rows = 0;
+    size_t row_len() const { return rows ? v.valid_len / rows : 0; }
+    size_t row_points() const { return v.complex_ ? row_len() / 2 : row_len(); }
+};
+
+template <typename T>
+DevMat<T>* mat_new(int is_complex, int domain, size_t rows, size_t row_len, T delta)
+{
+    if (device_ready() != BDSP_OK) return nullptr;
+    if (is_complex && row_len % 2 != 0) { set_last_error("complex rows need an even scalar length"); return nullptr; }
+    DevMat<T>* m = new DevMat<T>();
+    m->v.complex_ = is_complex != 0;
+    m->v.freq = domain != 0;
+    m->v.delta = delta;
+    m->rows = rows;
+    const size_t total = rows * row_len;
+    if (m->v.reserve(total ? total : 1) != BDSP_OK) { delete m; return nullptr; }
+    m->v.valid_len = total;
+    if (total) (void)hipMemsetAsync(m->v.data, 0, sizeof(T) * total, lib_stream());
+    return m;
+}
+
+template <typename T> int mat_code(DevMat<T>* m, int code)
+{
+    if (code == BDSP_OK && m->v.erroneous()) return BDSP_ERR_POISONED;
+    return code;
+}
+
+// run a single-vector kernel launcher on every row (index-dependent maps): fn(row_ptr, row_len)
+template <typename T, class F>
+int mat_each_row(DevMat<T>* m, F fn)
+{
+    const size_t rl = m->row_len();
+    for (size_t r = 0; r < m->rows; ++r) BDSP_TRY(fn(m->v.data + r * rl, rl));
+    return BDSP_OK;
+}
+
+// rows change length: fn(in_row, out_row) writes new_len scalars per row into the trade buffer
+template <typename T, class F>
+int mat_resize_rows(DevMat<T>* m, size_t new_len, F fn)
+{
+    const size_t rl = m->row_len();
+    const size_t need = m->rows * (new_len > rl ? new_len : rl);
+    BDSP_TRY(m->v.reserve(need));
+    for (size_t r = 0; r < m->rows; ++r) BDSP_TRY(fn(m->v.data + r * rl, m->v.buf + r * new_len));
+    m->v.trade();
+    m->v.valid_len = m->rows * new_len;
+    return BDSP_OK;
+}
+
+template <typename T>
+int mat_binary(DevMat<T>* m, const DevMat<T>* o, int op)
+{
+    if (m->rows != o->rows) return BDSP_ERR_ARG_LENGTH; // matrix/src/general/elementary.rs: row counts must agree
+    return op_binary<T>(&m->v, &o->v, op);
+}
+
+template <typename T>
+int mat_binary_vector(DevMat<T>* m, const DevVec<T>* o, int op)
+{
+    // every row (.)= the same vector: the wrap-around kernel with period = one row
+    if (o->valid_len != m->row_len()) return BDSP_ERR_SAME_SIZE;
+    if (!meta_agrees(&m->v, o)) return BDSP_ERR_META_DATA;
+    return ew_binary_smaller<T>(m->v.data, o->data, m->v.valid_len, o->valid_len, m->v.complex_, op, lib_stream());
+}
+
+template <typename T>
+int mat_complex_to_real(DevMat<T>* m, int kind) { return op_complex_to_real<T>(&m->v, kind); }
+
+template <typename T>
+int mat_window(DevMat<T>* m, int window, bool unapply)
+{
+    int wid;
+    T alpha;
+    map_window<T>(window, &wid, &alpha);
+    const bool c = m->v.complex_;
+    return mat_each_row<T>(m, [&](T* row, size_t len) { return ew_window<T>(row, len, c, wid, alpha, unapply, lib_stream()); });
+}
+
+template <typename T>
+int mat_swap(DevMat<T>* m, bool forward)
+{
+    const size_t p = m->row_points(), e = m->v.complex_ ? 2 : 1;
+    if (p == 0) return BDSP_OK;
+    const size_t shift = forward ? p - p / 2 : p / 2;
+    return mat_resize_rows<T>(m, m->row_len(), [&](const T* in, T* out) { return rg_rotate<T>(in, out, p, e, shift, lib_stream()); });
+}
+
+template <typename T>
+int mat_zero_pad(DevMat<T>* m, size_t points, int option)
+{
+    const size_t step = m->v.complex_ ? 2 : 1, len = points * step, rl = m->row_len();
+    if (len <= rl) return BDSP_ERR_ARG_LENGTH;
+    const int opt = option == 0 ? 0 : (option == 1 ? 1 : 2);
+    const bool c = m->v.complex_;
+    return mat_resize_rows<T>(m, len, [&](const T* in, T* out) { return rg_zero_pad<T>(in, out, rl, c, points, opt, lib_stream()); });
+}
+
+// convolve_signal with ONE impulse response shared by all rows (matrix/src/time_freq.rs:421-431)
+template <typename T>
+int mat_convolve_signal(DevMat<T>* m, const DevVec<T>* h)
+{
+    if (!meta_agrees(&m->v, h)) return BDSP_ERR_META_DATA;
+    if (m->v.freq) return BDSP_ERR_MUST_BE_TIME;
+    const size_t p = m->row_points();
+    if (p < h->points()) return BDSP_ERR_ARG_LENGTH;
+    if (p == 0 || h->points() == 0 || m->rows == 0) return BDSP_OK;
+    hipStream_t s = lib_stream();
+    if (m->v.complex_) BDSP_TRY(conv_complex_dev<T>(m->v.data, m->v.buf, p, m->rows, h->data, h->points(), s));
+    else BDSP_TRY(conv_real_dev<T>(m->v.data, m->v.buf, p, h->data, h->points(), s, m->rows));
+    m->v.trade();
+    return BDSP_OK;
+}
+
+// convolve_signal with a rows x rows matrix of impulse responses (convolve_mat, time_freq/mod.rs:365-453):
+//   out_row[n] = sum_r  row[r] (*) h[n][r]          (MIMO filtering; h row-major [n][r])
+template <typename T>
+int mat_convolve_mimo(DevMat<T>* m, const DevVec<T>* const* h, size_t count)
+{
+    const size_t R = m->rows;
+    if (count != R * R || R == 0) return BDSP_ERR_ARG_LENGTH; // mod.rs:373-375
+    for (size_t i = 0; i < count; ++i) {
+        if (h[i]->valid_len != h[0]->valid_len) return BDSP_ERR_ARG_LENGTH; // :384-389
+        if (!meta_agrees(&m->v, h[i])) return BDSP_ERR_META_DATA;
+    }
+    const size_t p = m->row_points(), rl = m->row_len(), hp = h[0]->points();
+    if (p == 0 || hp == 0) return BDSP_OK;
+    hipStream_t s = lib_stream();
+    BDSP_TRY(m->v.reserve(m->v.valid_len));
+    WsBlock tmp;
+    BDSP_TRY(tmp.alloc(sizeof(T) * rl, s));
+    for (size_t n = 0; n < R; ++n) {
+        T* out = m->v.buf + n * rl;
+        for (size_t r = 0; r < R; ++r) {
+            T* dst = r == 0 ? out : tmp.as<T>();
+            const T* row = m->v.data + r * rl;
+            const DevVec<T>* hh = h[n * R + r];
+            if (m->v.complex_) BDSP_TRY(conv_complex_dev<T>(row, dst, p, 1, hh->data, hp, s));
+            else BDSP_TRY(conv_real_dev<T>(row, dst, p, hh->data, hp, s));
+            if (r) BDSP_TRY(ew_binary<T>(out, tmp.as<T>(), rl, m->v.complex_, 0, s));
+        }
+    }
+    m->v.trade();
+    return BDSP_OK;
+}
+
+template <typename T>
+int mat_interpolatef(DevMat<T>* m, int fid, T rolloff, T factor, T delay, size_t conv_len)
+{
+    const size_t rl = m->row_len();
+    if (rl == 0) return BDSP_OK;
+    const size_t new_len = interpolatef_new_len<T>(rl, factor);
+    const bool c = m->v.complex_;
+    const T delta = m->v.delta;
+    return mat_resize_rows<T>(m, new_len, [&](const T* in, T* out) {
+        return interpolatef_dev<T>(in, out, rl, c, fid, rolloff, factor, delay, conv_len, delta, lib_stream());
+    });
+}
+
+template <typename T>
+int mat_multiply_frequency_response(DevMat<T>* m, int fid, T rolloff, T ratio)
+{
+    if (!m->v.freq) { m->v.poison(); return BDSP_OK; }
+    const bool c = m->v.complex_;
+    return mat_each_row<T>(m, [&](T* row, size_t len) { return ew_freq_response<T>(row, len, c, fid, rolloff, ratio, false, lib_stream()); });
+}
+
+template <typename T>
+DevVec<T>* mat_get_row(const DevMat<T>* m, size_t row)
+{
+    if (row >= m->rows) return nullptr;
+    DevVec<T>* v = new DevVec<T>();
+    v->complex_ = m->v.complex_;
+    v->freq = m->v.freq;
+    v->delta = m->v.delta;
+    const size_t rl = m->row_len();
+    if (v->reserve(rl ? rl : 1) != BDSP_OK) { delete v; return nullptr; }
+    v->valid_len = rl;
+    if (rl) (void)hipMemcpyAsync(v->data, m->v.data + row * rl, sizeof(T) * rl, hipMemcpyDeviceToDevice, lib_stream());
+    return v;
+}
+
+template <typename T>
+int mat_set_row(DevMat<T>* m, size_t row, const DevVec<T>* v)
+{
+    if (row >= m->rows || v->valid_len != m->row_len()) return BDSP_ERR_ARG_LENGTH;
+    if (v->valid_len)
+        BDSP_HIP_TRY(hipMemcpyAsync(m->v.data + row * v->valid_len, v->data, sizeof(T) * v->valid_len,
+                                    hipMemcpyDeviceToDevice, lib_stream()));
+    return BDSP_OK;
+}
+
+template <typename T>
+int mat_transfer(DevMat<T>* m, T* host, const T* src, size_t len)
+{
+    if (len != m->v.valid_len) return BDSP_ERR_ARG_LENGTH;
+    hipStream_t s = lib_stream();
+    if (len) {
+        if (src) BDSP_HIP_TRY(hipMemcpyAsync(m->v.data, src, sizeof(T) * len, hipMemcpyHostToDevice, s));
+        else BDSP_HIP_TRY(hipMemcpyAsync(host, m->v.data, sizeof(T) * len, hipMemcpyDeviceToHost, s));
+    }
+    BDSP_HIP_TRY(hipStreamSynchronize(s));
+    return BDSP_OK;
+}
+
 } // namespace
 
 // ==============================================================================================
@@ -1154,6 +1372,75 @@ size_t bdsp_hip_overlap_discard_f64(double* x_time, size_t x_len, double* tmp, s
 BDSP_FACADE(32, float, VecBuf32, VectorInteropResult32)
 BDSP_FACADE(64, double, VecBuf64, VectorInteropResult64)
 #undef BDSP_FACADE
+
+// ---------------------------------------------------------------------------------------------- matrix / batch
+#define BDSP_MAT(SFX, T, MB, VB)                                                                            \
+    static inline DevMat<T>* M##SFX(MB* m) { return reinterpret_cast<DevMat<T>*>(m); }                      \
+    static inline const DevMat<T>* MC##SFX(const MB* m) { return reinterpret_cast<const DevMat<T>*>(m); }   \
+    MB* bdsp_hip_mat_new##SFX(int32_t is_complex, int32_t domain, size_t rows, size_t row_len, T delta)     \
+    { return reinterpret_cast<MB*>(mat_new<T>(is_complex, domain, rows, row_len, delta)); }                \
+    void bdsp_hip_mat_delete##SFX(MB* m) { delete M##SFX(m); }                                              \
+    size_t bdsp_hip_mat_rows##SFX(const MB* m) { return MC##SFX(m)->rows; }                                 \
+    size_t bdsp_hip_mat_row_len##SFX(const MB* m) { return MC##SFX(m)->row_len(); }                         \
+    size_t bdsp_hip_mat_row_points##SFX(const MB* m) { return MC##SFX(m)->row_points(); }                   \
+    int32_t bdsp_hip_mat_is_complex##SFX(const MB* m) { return MC##SFX(m)->v.complex_ ? 1 : 0; }            \
+    int32_t bdsp_hip_mat_get_domain##SFX(const MB* m) { return MC##SFX(m)->v.freq ? 1 : 0; }                \
+    T bdsp_hip_mat_get_delta##SFX(const MB* m) { return MC##SFX(m)->v.delta; }                              \
+    void* bdsp_hip_mat_device_ptr##SFX(MB* m) { return M##SFX(m)->v.data; }                                 \
+    int32_t bdsp_hip_mat_upload##SFX(MB* m, const T* data, size_t len) { return mat_transfer<T>(M##SFX(m), nullptr, data, len); } \
+    int32_t bdsp_hip_mat_download##SFX(MB* m, T* out, size_t len) { return mat_transfer<T>(M##SFX(m), out, nullptr, len); } \
+    VB* bdsp_hip_mat_get_row##SFX(const MB* m, size_t row) { return reinterpret_cast<VB*>(mat_get_row<T>(MC##SFX(m), row)); } \
+    int32_t bdsp_hip_mat_set_row##SFX(MB* m, size_t row, const VB* vector) { return mat_set_row<T>(M##SFX(m), row, H<T>(vector)); } \
+    int32_t bdsp_hip_mat_real_scale##SFX(MB* m, T f) { DevMat<T>* a = M##SFX(m); return mat_code<T>(a, ew_real_scale<T>(a->v.data, a->v.valid_len, f, lib_stream())); } \
+    int32_t bdsp_hip_mat_real_offset##SFX(MB* m, T f) { DevMat<T>* a = M##SFX(m); return mat_code<T>(a, ew_real_offset<T>(a->v.data, a->v.valid_len, a->v.complex_, f, lib_stream())); } \
+    int32_t bdsp_hip_mat_complex_scale##SFX(MB* m, T re, T im)                                              \
+    {                                                                                                       \
+        DevMat<T>* a = M##SFX(m);                                                                           \
+        if (!a->v.complex_) { a->v.poison(); return BDSP_ERR_POISONED; }                                    \
+        return mat_code<T>(a, ew_complex_scale<T>(a->v.data, a->v.valid_len, re, im, lib_stream()));        \
+    }                                                                                                       \
+    int32_t bdsp_hip_mat_conj##SFX(MB* m)                                                                   \
+    {                                                                                                       \
+        DevMat<T>* a = M##SFX(m);                                                                           \
+        if (!a->v.complex_) { a->v.poison(); return BDSP_ERR_POISONED; }                                    \
+        return mat_code<T>(a, ew_conj<T>(a->v.data, a->v.valid_len, lib_stream()));                         \
+    }                                                                                                       \
+    int32_t bdsp_hip_mat_add##SFX(MB* m, const MB* o) { DevMat<T>* a = M##SFX(m); return mat_code<T>(a, mat_binary<T>(a, MC##SFX(o), 0)); } \
+    int32_t bdsp_hip_mat_sub##SFX(MB* m, const MB* o) { DevMat<T>* a = M##SFX(m); return mat_code<T>(a, mat_binary<T>(a, MC##SFX(o), 1)); } \
+    int32_t bdsp_hip_mat_mul##SFX(MB* m, const MB* o) { DevMat<T>* a = M##SFX(m); return mat_code<T>(a, mat_binary<T>(a, MC##SFX(o), 2)); } \
+    int32_t bdsp_hip_mat_div##SFX(MB* m, const MB* o) { DevMat<T>* a = M##SFX(m); return mat_code<T>(a, mat_binary<T>(a, MC##SFX(o), 3)); } \
+    int32_t bdsp_hip_mat_add_vector##SFX(MB* m, const VB* o) { DevMat<T>* a = M##SFX(m); return mat_code<T>(a, mat_binary_vector<T>(a, H<T>(o), 0)); } \
+    int32_t bdsp_hip_mat_sub_vector##SFX(MB* m, const VB* o) { DevMat<T>* a = M##SFX(m); return mat_code<T>(a, mat_binary_vector<T>(a, H<T>(o), 1)); } \
+    int32_t bdsp_hip_mat_mul_vector##SFX(MB* m, const VB* o) { DevMat<T>* a = M##SFX(m); return mat_code<T>(a, mat_binary_vector<T>(a, H<T>(o), 2)); } \
+    int32_t bdsp_hip_mat_div_vector##SFX(MB* m, const VB* o) { DevMat<T>* a = M##SFX(m); return mat_code<T>(a, mat_binary_vector<T>(a, H<T>(o), 3)); } \
+    int32_t bdsp_hip_mat_magnitude##SFX(MB* m) { DevMat<T>* a = M##SFX(m); return mat_code<T>(a, mat_complex_to_real<T>(a, 0)); } \
+    int32_t bdsp_hip_mat_magnitude_squared##SFX(MB* m) { DevMat<T>* a = M##SFX(m); return mat_code<T>(a, mat_complex_to_real<T>(a, 1)); } \
+    int32_t bdsp_hip_mat_to_real##SFX(MB* m) { DevMat<T>* a = M##SFX(m); return mat_code<T>(a, mat_complex_to_real<T>(a, 2)); } \
+    int32_t bdsp_hip_mat_to_imag##SFX(MB* m) { DevMat<T>* a = M##SFX(m); return mat_code<T>(a, mat_complex_to_real<T>(a, 3)); } \
+    int32_t bdsp_hip_mat_phase##SFX(MB* m) { DevMat<T>* a = M##SFX(m); return mat_code<T>(a, mat_complex_to_real<T>(a, 4)); } \
+    int32_t bdsp_hip_mat_plain_fft##SFX(MB* m) { DevMat<T>* a = M##SFX(m); return mat_code<T>(a, op_fft<T>(&a->v, false, false, -1, a->rows)); } \
+    int32_t bdsp_hip_mat_fft##SFX(MB* m) { DevMat<T>* a = M##SFX(m); return mat_code<T>(a, op_fft<T>(&a->v, false, true, -1, a->rows)); } \
+    int32_t bdsp_hip_mat_windowed_fft##SFX(MB* m, int32_t window) { DevMat<T>* a = M##SFX(m); return mat_code<T>(a, op_fft<T>(&a->v, false, true, window < 0 ? 3 : window, a->rows)); } \
+    int32_t bdsp_hip_mat_plain_ifft##SFX(MB* m) { DevMat<T>* a = M##SFX(m); return mat_code<T>(a, op_fft<T>(&a->v, true, false, -1, a->rows)); } \
+    int32_t bdsp_hip_mat_ifft##SFX(MB* m) { DevMat<T>* a = M##SFX(m); return mat_code<T>(a, op_fft<T>(&a->v, true, true, -1, a->rows)); } \
+    int32_t bdsp_hip_mat_windowed_ifft##SFX(MB* m, int32_t window) { DevMat<T>* a = M##SFX(m); return mat_code<T>(a, op_fft<T>(&a->v, true, true, window < 0 ? 3 : window, a->rows)); } \
+    int32_t bdsp_hip_mat_apply_window##SFX(MB* m, int32_t window) { DevMat<T>* a = M##SFX(m); return mat_code<T>(a, mat_window<T>(a, window, false)); } \
+    int32_t bdsp_hip_mat_unapply_window##SFX(MB* m, int32_t window) { DevMat<T>* a = M##SFX(m); return mat_code<T>(a, mat_window<T>(a, window, true)); } \
+    int32_t bdsp_hip_mat_swap_halves##SFX(MB* m) { DevMat<T>* a = M##SFX(m); return mat_code<T>(a, mat_swap<T>(a, true)); } \
+    int32_t bdsp_hip_mat_fft_shift##SFX(MB* m) { DevMat<T>* a = M##SFX(m); return mat_code<T>(a, mat_swap<T>(a, true)); } \
+    int32_t bdsp_hip_mat_ifft_shift##SFX(MB* m) { DevMat<T>* a = M##SFX(m); return mat_code<T>(a, mat_swap<T>(a, false)); } \
+    int32_t bdsp_hip_mat_zero_pad##SFX(MB* m, size_t points, int32_t option) { DevMat<T>* a = M##SFX(m); return mat_code<T>(a, mat_zero_pad<T>(a, points, option)); } \
+    int32_t bdsp_hip_mat_convolve_signal##SFX(MB* m, const VB* impulse_response) { DevMat<T>* a = M##SFX(m); return mat_code<T>(a, mat_convolve_signal<T>(a, H<T>(impulse_response))); } \
+    int32_t bdsp_hip_mat_convolve_signal_mat##SFX(MB* m, const VB* const* impulse_responses, size_t count)  \
+    { DevMat<T>* a = M##SFX(m); return mat_code<T>(a, mat_convolve_mimo<T>(a, reinterpret_cast<const DevVec<T>* const*>(impulse_responses), count)); } \
+    int32_t bdsp_hip_mat_interpolatef##SFX(MB* m, int32_t impulse_response, T rolloff, T interpolation_factor, T delay, size_t conv_len) \
+    { DevMat<T>* a = M##SFX(m); return mat_code<T>(a, mat_interpolatef<T>(a, impulse_response == 0 ? 0 : 1, rolloff, interpolation_factor, delay, conv_len)); } \
+    int32_t bdsp_hip_mat_multiply_frequency_response##SFX(MB* m, int32_t frequency_response, T rolloff, T ratio) \
+    { DevMat<T>* a = M##SFX(m); return mat_code<T>(a, mat_multiply_frequency_response<T>(a, frequency_response == 0 ? 0 : 1, rolloff, ratio)); }
+
+BDSP_MAT(32, float, MatBuf32, VecBuf32)
+BDSP_MAT(64, double, MatBuf64, VecBuf64)
+#undef BDSP_MAT
 
 // ---------------------------------------------------------------------------------------------- B3
 int bdsp_hip_dev_fft(int elem, void* data, void* scratch, size_t points, size_t batch, unsigned flags,

@@ -378,6 +378,114 @@ VectorInteropResult64 windowed_custom_sifft64(VecBuf64 *vector, bdsp_window_fn64
 void *bdsp_hip_vec_device_ptr32(VecBuf32 *vector);
 void *bdsp_hip_vec_device_ptr64(VecBuf64 *vector);
 
+/* ========================================================================================
+ * B2m -- matrix / batch API: `rows` equally long vectors in one allocation, every operation a
+ *        batched launch.  The reference's matrix crate has no C facade; these entry points mirror
+ *        its Rust API (matrix/src/lib.rs:195-208 row loop, matrix/src/time_freq.rs:49-530 trait
+ *        forwarding, MatrixMxN::convolve_signal with a matrix of impulse responses :439-483 ->
+ *        DspVec::convolve_mat, vector/src/vector_types/time_freq/mod.rs:365-453).
+ *        Operations return the facade result codes (0, -1 poisoned, 1..14, <= -100 backend).
+ * ======================================================================================== */
+typedef struct MatBuf32 MatBuf32;
+typedef struct MatBuf64 MatBuf64;
+MatBuf32 *bdsp_hip_mat_new32(int32_t is_complex, int32_t domain, size_t rows, size_t row_len, float delta); /* row_len in scalars; zero filled */
+void bdsp_hip_mat_delete32(MatBuf32 *m);
+size_t bdsp_hip_mat_rows32(const MatBuf32 *m);        /* col_len() of the reference (number of row vectors) */
+size_t bdsp_hip_mat_row_len32(const MatBuf32 *m);     /* row_len(): scalars per row */
+size_t bdsp_hip_mat_row_points32(const MatBuf32 *m);
+int32_t bdsp_hip_mat_is_complex32(const MatBuf32 *m);
+int32_t bdsp_hip_mat_get_domain32(const MatBuf32 *m);
+float bdsp_hip_mat_get_delta32(const MatBuf32 *m);
+void *bdsp_hip_mat_device_ptr32(MatBuf32 *m);         /* [rows][row_len] contiguous */
+int32_t bdsp_hip_mat_upload32(MatBuf32 *m, const float *data, size_t len);   /* len == rows*row_len */
+int32_t bdsp_hip_mat_download32(MatBuf32 *m, float *out, size_t len);
+VecBuf32 *bdsp_hip_mat_get_row32(const MatBuf32 *m, size_t row);           /* copy of one row as a vector handle */
+int32_t bdsp_hip_mat_set_row32(MatBuf32 *m, size_t row, const VecBuf32 *vector);
+int32_t bdsp_hip_mat_real_scale32(MatBuf32 *m, float factor);
+int32_t bdsp_hip_mat_real_offset32(MatBuf32 *m, float offset);
+int32_t bdsp_hip_mat_complex_scale32(MatBuf32 *m, float re, float im);
+int32_t bdsp_hip_mat_conj32(MatBuf32 *m);
+int32_t bdsp_hip_mat_add32(MatBuf32 *m, const MatBuf32 *other);            /* matrix (.) matrix */
+int32_t bdsp_hip_mat_sub32(MatBuf32 *m, const MatBuf32 *other);
+int32_t bdsp_hip_mat_mul32(MatBuf32 *m, const MatBuf32 *other);
+int32_t bdsp_hip_mat_div32(MatBuf32 *m, const MatBuf32 *other);
+int32_t bdsp_hip_mat_add_vector32(MatBuf32 *m, const VecBuf32 *operand);   /* every row (.) the same vector */
+int32_t bdsp_hip_mat_sub_vector32(MatBuf32 *m, const VecBuf32 *operand);
+int32_t bdsp_hip_mat_mul_vector32(MatBuf32 *m, const VecBuf32 *operand);
+int32_t bdsp_hip_mat_div_vector32(MatBuf32 *m, const VecBuf32 *operand);
+int32_t bdsp_hip_mat_magnitude32(MatBuf32 *m);
+int32_t bdsp_hip_mat_magnitude_squared32(MatBuf32 *m);
+int32_t bdsp_hip_mat_to_real32(MatBuf32 *m);
+int32_t bdsp_hip_mat_to_imag32(MatBuf32 *m);
+int32_t bdsp_hip_mat_phase32(MatBuf32 *m);
+int32_t bdsp_hip_mat_plain_fft32(MatBuf32 *m);                             /* matrix/src/time_freq.rs:53-61 */
+int32_t bdsp_hip_mat_fft32(MatBuf32 *m);                                   /* :63-71 */
+int32_t bdsp_hip_mat_windowed_fft32(MatBuf32 *m, int32_t window);          /* :73-81 */
+int32_t bdsp_hip_mat_plain_ifft32(MatBuf32 *m);                            /* :120-128 */
+int32_t bdsp_hip_mat_ifft32(MatBuf32 *m);                                  /* :130-138 */
+int32_t bdsp_hip_mat_windowed_ifft32(MatBuf32 *m, int32_t window);         /* :140-148 */
+int32_t bdsp_hip_mat_apply_window32(MatBuf32 *m, int32_t window);
+int32_t bdsp_hip_mat_unapply_window32(MatBuf32 *m, int32_t window);
+int32_t bdsp_hip_mat_swap_halves32(MatBuf32 *m);
+int32_t bdsp_hip_mat_fft_shift32(MatBuf32 *m);
+int32_t bdsp_hip_mat_ifft_shift32(MatBuf32 *m);
+int32_t bdsp_hip_mat_zero_pad32(MatBuf32 *m, size_t points, int32_t padding_option);
+int32_t bdsp_hip_mat_convolve_signal32(MatBuf32 *m, const VecBuf32 *impulse_response);      /* :421-431, one filter for all rows */
+int32_t bdsp_hip_mat_convolve_signal_mat32(MatBuf32 *m, const VecBuf32 *const *impulse_responses,
+                                           size_t count); /* :439-483: count == rows*rows, row-major [out][in] */
+int32_t bdsp_hip_mat_interpolatef32(MatBuf32 *m, int32_t impulse_response, float rolloff,
+                                    float interpolation_factor, float delay, size_t conv_len);
+int32_t bdsp_hip_mat_multiply_frequency_response32(MatBuf32 *m, int32_t frequency_response, float rolloff, float ratio);
+
+MatBuf64 *bdsp_hip_mat_new64(int32_t is_complex, int32_t domain, size_t rows, size_t row_len, double delta); /* row_len in scalars; zero filled */
+void bdsp_hip_mat_delete64(MatBuf64 *m);
+size_t bdsp_hip_mat_rows64(const MatBuf64 *m);        /* col_len() of the reference (number of row vectors) */
+size_t bdsp_hip_mat_row_len64(const MatBuf64 *m);     /* row_len(): scalars per row */
+size_t bdsp_hip_mat_row_points64(const MatBuf64 *m);
+int32_t bdsp_hip_mat_is_complex64(const MatBuf64 *m);
+int32_t bdsp_hip_mat_get_domain64(const MatBuf64 *m);
+double bdsp_hip_mat_get_delta64(const MatBuf64 *m);
+void *bdsp_hip_mat_device_ptr64(MatBuf64 *m);         /* [rows][row_len] contiguous */
+int32_t bdsp_hip_mat_upload64(MatBuf64 *m, const double *data, size_t len);   /* len == rows*row_len */
+int32_t bdsp_hip_mat_download64(MatBuf64 *m, double *out, size_t len);
+VecBuf64 *bdsp_hip_mat_get_row64(const MatBuf64 *m, size_t row);           /* copy of one row as a vector handle */
+int32_t bdsp_hip_mat_set_row64(MatBuf64 *m, size_t row, const VecBuf64 *vector);
+int32_t bdsp_hip_mat_real_scale64(MatBuf64 *m, double factor);
+int32_t bdsp_hip_mat_real_offset64(MatBuf64 *m, double offset);
+int32_t bdsp_hip_mat_complex_scale64(MatBuf64 *m, double re, double im);
+int32_t bdsp_hip_mat_conj64(MatBuf64 *m);
+int32_t bdsp_hip_mat_add64(MatBuf64 *m, const MatBuf64 *other);            /* matrix (.) matrix */
+int32_t bdsp_hip_mat_sub64(MatBuf64 *m, const MatBuf64 *other);
+int32_t bdsp_hip_mat_mul64(MatBuf64 *m, const MatBuf64 *other);
+int32_t bdsp_hip_mat_div64(MatBuf64 *m, const MatBuf64 *other);
+int32_t bdsp_hip_mat_add_vector64(MatBuf64 *m, const VecBuf64 *operand);   /* every row (.) the same vector */
+int32_t bdsp_hip_mat_sub_vector64(MatBuf64 *m, const VecBuf64 *operand);
+int32_t bdsp_hip_mat_mul_vector64(MatBuf64 *m, const VecBuf64 *operand);
+int32_t bdsp_hip_mat_div_vector64(MatBuf64 *m, const VecBuf64 *operand);
+int32_t bdsp_hip_mat_magnitude64(MatBuf64 *m);
+int32_t bdsp_hip_mat_magnitude_squared64(MatBuf64 *m);
+int32_t bdsp_hip_mat_to_real64(MatBuf64 *m);
+int32_t bdsp_hip_mat_to_imag64(MatBuf64 *m);
+int32_t bdsp_hip_mat_phase64(MatBuf64 *m);
+int32_t bdsp_hip_mat_plain_fft64(MatBuf64 *m);                             /* matrix/src/time_freq.rs:53-61 */
+int32_t bdsp_hip_mat_fft64(MatBuf64 *m);                                   /* :63-71 */
+int32_t bdsp_hip_mat_windowed_fft64(MatBuf64 *m, int32_t window);          /* :73-81 */
+int32_t bdsp_hip_mat_plain_ifft64(MatBuf64 *m);                            /* :120-128 */
+int32_t bdsp_hip_mat_ifft64(MatBuf64 *m);                                  /* :130-138 */
+int32_t bdsp_hip_mat_windowed_ifft64(MatBuf64 *m, int32_t window);         /* :140-148 */
+int32_t bdsp_hip_mat_apply_window64(MatBuf64 *m, int32_t window);
+int32_t bdsp_hip_mat_unapply_window64(MatBuf64 *m, int32_t window);
+int32_t bdsp_hip_mat_swap_halves64(MatBuf64 *m);
+int32_t bdsp_hip_mat_fft_shift64(MatBuf64 *m);
+int32_t bdsp_hip_mat_ifft_shift64(MatBuf64 *m);
+int32_t bdsp_hip_mat_zero_pad64(MatBuf64 *m, size_t points, int32_t padding_option);
+int32_t bdsp_hip_mat_convolve_signal64(MatBuf64 *m, const VecBuf64 *impulse_response);      /* :421-431, one filter for all rows */
+int32_t bdsp_hip_mat_convolve_signal_mat64(MatBuf64 *m, const VecBuf64 *const *impulse_responses,
+                                           size_t count); /* :439-483: count == rows*rows, row-major [out][in] */
+int32_t bdsp_hip_mat_interpolatef64(MatBuf64 *m, int32_t impulse_response, double rolloff,
+                                    double interpolation_factor, double delay, size_t conv_len);
+int32_t bdsp_hip_mat_multiply_frequency_response64(MatBuf64 *m, int32_t frequency_response, double rolloff, double ratio);
+
 /* ==========================================================================================
  * B3 -- kernels on caller-owned DEVICE memory.  `stream` is a hipStream_t passed as void*
  * (NULL = the library's own stream).  Calls are asynchronous on that stream unless noted.
