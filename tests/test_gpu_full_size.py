@@ -1,0 +1,136 @@
+"""Parity at BASELINE.json's FULL sizes, through the C ABI on the GPU.
+
+The oracle cannot produce a full 16M-point x 1024-tap convolution in seconds, so these tests combine
+(a) oracle comparisons where the oracle is fast enough (whole 1M/4M-point transforms, windows of the
+16M-point convolution, single DFT bins) with (b) size-independent properties: round trips, Parseval,
+linearity, shift identities.  Tolerances are north_star's: 1e-6 rel-L2 for f32, 1e-12 for f64.
+"""
+import numpy as np
+import pytest
+
+import oracle_lib as orc
+from basic_dsp_amd import DspVec
+from basic_dsp_amd import vector as V
+
+pytestmark = pytest.mark.gpu
+
+SEED_C2, SEED_C3_X, SEED_C3_H, SEED_C4 = 201511212, 201601171, 201601172, 201602221
+
+
+def rel_l2(got, ref):
+    got = np.asarray(got, np.float64).ravel()
+    ref = np.asarray(ref, np.float64).ravel()
+    return float(np.linalg.norm(got - ref) / max(np.linalg.norm(ref), 1e-300))
+
+
+def test_c2_fft_magnitude_1m_vs_oracle():
+    n = 1 << 20
+    x = orc.fill_uniform(2 * n, SEED_C2, -10, 10, np.float32)
+    v = DspVec(x, is_complex=True)
+    assert v.plain_fft() == 0 and v.magnitude() == 0
+    ref = orc.magnitude(orc.fft(x.astype(np.float64)))
+    assert len(v) == n and rel_l2(v.data(), ref) < 1e-6
+
+
+def test_c3_convolution_16m_windows_and_identities():
+    n, m = 1 << 24, 1024
+    x = orc.fill_uniform(2 * n, SEED_C3_X, -10, 10, np.float32)
+    h = (orc.fill_uniform(2 * m, SEED_C3_H, -1, 1, np.float32) / np.float32(m)).astype(np.float32)
+    hv = DspVec(h, is_complex=True)
+    v = DspVec(x, is_complex=True)
+    assert v.convolve_signal(hv) == 0
+    y = v.data()
+    # (i) direct-form oracle (f64) on windows: start and end (both wrap around), block seams, interior
+    x64, h64 = x.astype(np.float64), h.astype(np.float64)
+    for first in (0, 3072 - 8, 5_000_000, 11_184_810, n - 4096):
+        ref = orc.convolve_direct(x64, h64, True, first, 4096)
+        assert rel_l2(y[2 * first:2 * (first + 4096)], ref) < 1e-6, first
+    # (ii) linearity on the full vector: conv(2.5 x + z) == 2.5 conv(x) + conv(z)
+    z = orc.fill_uniform(2 * n, SEED_C3_X + 7, -10, 10, np.float32)
+    vz = DspVec(z, is_complex=True)
+    assert vz.convolve_signal(hv) == 0
+    mix = DspVec(x, is_complex=True)
+    assert mix.scale(2.5) == 0 and mix.add(DspVec(z, is_complex=True)) == 0 and mix.convolve_signal(hv) == 0
+    assert rel_l2(mix.data(), 2.5 * y.astype(np.float64) + vz.data()) < 1e-6
+    # (iii) shift identity at full size (convolution.rs:819-842): taps [0, 0, 1] delay by one sample with
+    # wrap-around; a single tap [1] is the identity
+    d = np.zeros(2 * 3, np.float32)
+    d[4] = 1.0
+    s = DspVec(x, is_complex=True)
+    assert s.convolve_signal(DspVec(d, is_complex=True)) == 0
+    assert rel_l2(s.data(), np.roll(x, 2)) < 1e-6
+    one = DspVec(np.array([1.0, 0.0], np.float32), is_complex=True)
+    s = DspVec(x, is_complex=True)
+    assert s.convolve_signal(one) == 0
+    assert rel_l2(s.data(), x) < 1e-6
+
+
+def test_fft_16m_bins_parseval_roundtrip():
+    n = 1 << 24
+    x = orc.fill_uniform(2 * n, SEED_C3_X, -10, 10, np.float32)
+    v = DspVec(x, is_complex=True)
+    assert v.plain_fft() == 0
+    X = v.datac().astype(np.complex128)
+    xc = x.view(np.complex64).astype(np.complex128)
+    # selected bins against the DFT definition evaluated in f64 (exact phase via integer k*n mod N)
+    idx = np.arange(n, dtype=np.int64)
+    scale = np.sqrt(n) * 10.0  # typical bin magnitude
+    for k in (0, 1, 4097, n // 2, n - 1, 12_345_678):
+        ph = (idx * k) % n
+        ref = np.sum(xc * np.exp(-2j * np.pi * ph / n))
+        assert abs(X[k] - ref) / scale < 2e-6, k
+    # Parseval
+    e_t, e_f = np.sum(np.abs(xc) ** 2), np.sum(np.abs(X) ** 2) / n
+    assert abs(e_f - e_t) / e_t < 1e-6
+    # round trip and delta bookkeeping
+    assert v.delta() == float(n)
+    assert v.plain_ifft() == 0 and v.scale(1.0 / n) == 0
+    assert rel_l2(v.data(), x) < 2e-6
+    # a pure tone lands in one bin
+    k0 = 1_000_003
+    tone = np.exp(2j * np.pi * ((idx * k0) % n) / n).astype(np.complex64)
+    t = DspVec(tone, is_complex=True)
+    assert t.plain_fft() == 0
+    T = t.datac()
+    assert abs(T[k0] - n) / n < 1e-6
+    T[k0] = 0
+    assert np.linalg.norm(T) / n < 1e-6
+
+
+def test_c4_f64_windowed_fft_and_interpolatef_4m():
+    n = 1 << 22
+    x = orc.fill_uniform(2 * n, SEED_C4, -10, 10, np.float64)
+    # (i) windowed_fft(Hann) against the oracle: window -> fft -> fft_shift
+    v = DspVec(x, is_complex=True)
+    assert v.windowed_fft(V.WINDOW_HANN) == 0
+    ref = orc.swap_halves(orc.fft(orc.apply_window(x, True, 1, 0.5)), True, True)
+    assert rel_l2(v.data(), ref) < 1e-12
+    assert v.windowed_ifft(V.WINDOW_HANN) == 0
+    got = v.data()
+    # the Hann window tends to zero at both ends (w(n) ~ (pi n / N)^2): un-applying it amplifies the
+    # transform's rounding error by 1/w there, so the round trip is checked where w > 0.03
+    edge = 2 * (n // 16)
+    assert rel_l2(got[edge:-edge], x[edge:-edge]) < 1e-11
+    # (ii) interpolatef(RC 0.35, x4, delay 0, conv_len 12) against the oracle (same tap windows)
+    v = DspVec(x, is_complex=True)
+    assert v.interpolatef(V.CONV_RAISED_COSINE, 4.0, 0.0, 12, rolloff=0.35) == 0
+    ref, path = orc.interpolatef(x, True, 1, 0.35, 4.0, 0.0, 12)
+    assert path == 1 and len(v) == ref.size == 8 * n
+    assert rel_l2(v.data(), ref) < 1e-13
+
+
+def test_c5_batch_of_1m_vectors_equals_single_vector_path():
+    import torch
+    from basic_dsp_amd.batch import process_shard_gpu
+    nvec, n, m = 8, 1 << 20, 1024
+    rows = np.stack([orc.fill_uniform(2 * n, SEED_C2 + r, -10, 10, np.float32) for r in range(nvec)])
+    taps = (orc.fill_uniform(2 * m, SEED_C3_H, -1, 1, np.float32) / np.float32(m)).astype(np.float32)
+    out = process_shard_gpu(torch.from_numpy(rows).cuda(), torch.from_numpy(taps).cuda(), n)
+    torch.cuda.synchronize()
+    out = out.cpu().numpy()
+    for r in (0, 3, nvec - 1):
+        v = DspVec(rows[r], is_complex=True)
+        assert v.convolve_signal(DspVec(taps, is_complex=True)) == 0 and v.plain_fft() == 0
+        assert rel_l2(out[r], v.data()) < 1e-6
+    ref = orc.fft(orc.convolve_signal(rows[1].astype(np.float64), taps.astype(np.float64), True)[1])
+    assert rel_l2(out[1], ref) < 1e-6
