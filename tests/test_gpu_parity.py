@@ -743,3 +743,36 @@ def test_matrix_convolve_signal_mimo_kats():
     for n in range(3):
         ref = sum(orc.convolve_direct(a[r], hs[n][r], True) for r in range(3))
         assert rel_l2(got[n], ref) < 1e-12
+
+
+def test_b1_entry_points_are_thread_safe():
+    # GpuSupport<T> is called from whichever thread owns the vector (T: Send + Sync):
+    # concurrent host threads must not corrupt each other's results
+    import threading
+    n, m = 20000, 65
+    cases = []
+    for k in range(8):
+        x = orc.fill_uniform(2 * n, 1000 + k, -10, 10, np.float32)
+        h = orc.fill_uniform(2 * m, 2000 + k, -1, 1, np.float32)
+        cases.append((x, h, orc.convolve_direct(x.astype(np.float64), h.astype(np.float64), True),
+                      orc.fft(x.astype(np.float64))))
+    errors = []
+
+    def worker(k):
+        x, h, ref_conv, ref_fft = cases[k]
+        try:
+            for _ in range(5):
+                got, rng = V.gpu_convolve_vector(x, h, True)
+                assert rng == (0, x.size) and rel_l2(got, ref_conv) < 2e-6
+                assert rel_l2(V.gpu_fft(x.copy()), ref_fft) < 2e-6
+                v = DspVec(x, is_complex=True)
+                assert v.plain_fft() == 0 and rel_l2(v.data(), ref_fft) < 2e-6
+        except Exception as exc:  # noqa: BLE001
+            errors.append((k, repr(exc)))
+
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(8)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
