@@ -133,5 +133,15 @@ template <typename T> int conv_function_direct(const T* in, T* out, size_t point
 template <typename T> size_t interpolate_real_len(size_t len, T factor);
 template <typename T> int interpolate_real_dev(const T* in, T* out, size_t len, T factor, T delay, bool hermite, hipStream_t s);
 
+// bluestein.hip
+template <typename T> int bs_chirp(T* c, size_t n, bool inverse, hipStream_t s);
+template <typename T> int bs_kernel(const T* c, T* b, size_t n, size_t m, hipStream_t s);
+template <typename T>
+int bs_pre(const T* x, T* a, const T* c, size_t n, size_t m, size_t batch, bool in_real, T in_scale, size_t rot,
+           int window_id, T alpha, hipStream_t s);
+template <typename T>
+int bs_post(const T* conv, T* out, const T* c, size_t n, size_t m, size_t batch, int out_kind, size_t rot,
+            int div_window_id, T alpha, hipStream_t s);
+
 // window value shared by fft.hip and elementwise.hip (device) -- defined inline in window.h
 } // namespace bdsp

@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstring>
 #include <limits>
+#include <mutex>
 #include <vector>
 
 #include "bdsp_internal.h"
@@ -60,105 +61,100 @@ int fft_two_buffers(T* a, T* b, size_t points, size_t batch, bool inverse, unsig
     return fft_pow2<T>(io, b, a, batch, inverse, s);
 }
 
-// Bluestein chirp-z for lengths that are not powers of two (any N, like rustfft):
-//   X[k] = conj(c[k]) * sum_n (x[n] conj(c[n])) c[k-n],   c[n] = exp(+i*pi*n^2/N) (forward)
-// evaluated as a circular convolution of length m = next_pow2(2N-1) on the pow2 kernels.
-// The chirp is generated on the host in double (exact n^2 mod 2N) and cached per call; prologue
-// and epilogue options are honoured by separate elementwise passes (this is the slow path).
+// Bluestein chirp-z for lengths that are not powers of two (any N, like rustfft); kernels and the
+// algebra are in bluestein.hip.  The chirp and the spectrum of the convolution kernel depend only on
+// (N, direction, precision): they are built once on the device and cached (LRU, bounded), so a
+// steady-state call is pre -> FFT_m -> x B/m -> IFFT_m -> post with every option fused into pre/post.
+struct BsPlan {
+    void* chirp = nullptr; // N complex
+    void* bspec = nullptr; // m complex: FFT_m of the wrapped chirp
+    size_t n = 0, m = 0, bytes = 0;
+    bool inverse = false;
+    int esz = 0, dev = 0;
+    unsigned long long stamp = 0;
+};
+static std::mutex g_bs_mu;
+static std::vector<BsPlan> g_bs_plans;
+static unsigned long long g_bs_clock = 0;
+constexpr size_t BS_CACHE_BYTES = size_t(1) << 30;
+
+template <typename T>
+int bs_plan(size_t n, size_t m, bool inverse, hipStream_t s, const T** chirp, const T** bspec)
+{
+    int dev = 0;
+    BDSP_HIP_TRY(hipGetDevice(&dev));
+    for (auto& p : g_bs_plans)
+        if (p.n == n && p.inverse == inverse && p.esz == (int)sizeof(T) && p.dev == dev) {
+            p.stamp = ++g_bs_clock;
+            *chirp = (const T*)p.chirp;
+            *bspec = (const T*)p.bspec;
+            return BDSP_OK;
+        }
+    BsPlan p;
+    p.n = n; p.m = m; p.inverse = inverse; p.esz = (int)sizeof(T); p.dev = dev;
+    p.bytes = sizeof(T) * 2 * (n + m);
+    // make room: least recently used plans go first (after the device has drained their users)
+    size_t used = 0;
+    for (auto& q : g_bs_plans) used += q.bytes;
+    while (!g_bs_plans.empty() && used + p.bytes > BS_CACHE_BYTES) {
+        size_t lru = 0;
+        for (size_t i = 1; i < g_bs_plans.size(); ++i)
+            if (g_bs_plans[i].stamp < g_bs_plans[lru].stamp) lru = i;
+        BDSP_HIP_TRY(hipDeviceSynchronize());
+        (void)hipFree(g_bs_plans[lru].chirp);
+        (void)hipFree(g_bs_plans[lru].bspec);
+        used -= g_bs_plans[lru].bytes;
+        g_bs_plans.erase(g_bs_plans.begin() + (long)lru);
+    }
+    BDSP_HIP_TRY(hipMalloc(&p.chirp, sizeof(T) * 2 * n));
+    if (hipMalloc(&p.bspec, sizeof(T) * 2 * m) != hipSuccess) { (void)hipFree(p.chirp); set_last_error("hipMalloc failed"); return BDSP_ERR_HIP; }
+    WsBlock scr;
+    int c = scr.alloc(sizeof(T) * 2 * m, s);
+    if (c == BDSP_OK) c = bs_chirp<T>((T*)p.chirp, n, inverse, s);
+    if (c == BDSP_OK) c = bs_kernel<T>((const T*)p.chirp, (T*)p.bspec, n, m, s);
+    bool rb = false;
+    if (c == BDSP_OK) c = fft_two_buffers<T>((T*)p.bspec, scr.as<T>(), m, 1, false, 0, (T)1, -1, (T)0, &rb, s);
+    if (c == BDSP_OK && rb &&
+        hipMemcpyAsync(p.bspec, scr.p, sizeof(T) * 2 * m, hipMemcpyDeviceToDevice, s) != hipSuccess) c = BDSP_ERR_HIP;
+    // the plan may be used from another stream next: finish building it first
+    if (c == BDSP_OK && hipStreamSynchronize(s) != hipSuccess) c = BDSP_ERR_HIP;
+    if (c != BDSP_OK) { (void)hipFree(p.chirp); (void)hipFree(p.bspec); return c; }
+    p.stamp = ++g_bs_clock;
+    g_bs_plans.push_back(p);
+    *chirp = (const T*)p.chirp;
+    *bspec = (const T*)p.bspec;
+    return BDSP_OK;
+}
+
 template <typename T>
 int fft_any_len(T* a, T* b, size_t n, size_t batch, bool inverse, unsigned flags, T in_scale,
                 int window_id, T window_alpha, bool* in_b, hipStream_t s)
 {
-    *in_b = false;
-    if (flags & (FFT_IN_REAL | BDSP_FFT_MAGNITUDE | FFT_OUT_REAL | FFT_WINDOW_OUT_DIV)) {
-        set_last_error("non power-of-two FFT: fused real/magnitude options are not implemented");
-        return BDSP_ERR_UNSUPPORTED;
-    }
+    (void)b;
+    *in_b = false; // the epilogue writes the result back over the (consumed) input buffer
     size_t m = 1;
     while (m < 2 * n - 1) m <<= 1;
     if (m > (size_t(1) << 30)) { set_last_error("Bluestein length above 2^30"); return BDSP_ERR_UNSUPPORTED; }
-    // host chirp
-    std::vector<T> chirp(2 * n), bk(2 * m, (T)0);
-    for (size_t i = 0; i < n; ++i) {
-        unsigned __int128 sq = (unsigned __int128)i * i;
-        size_t r = (size_t)(sq % (2 * n));
-        long double ang = (inverse ? -1.0L : 1.0L) * 3.14159265358979323846264338327950288L *
-                          (long double)r / (long double)n;
-        chirp[2 * i] = (T)cosl(ang);
-        chirp[2 * i + 1] = (T)sinl(ang);
-        bk[2 * i] = chirp[2 * i];
-        bk[2 * i + 1] = chirp[2 * i + 1];
-        if (i) { bk[2 * (m - i)] = chirp[2 * i]; bk[2 * (m - i) + 1] = chirp[2 * i + 1]; }
-    }
-    WsBlock wc, wb, wa, wt;
-    BDSP_TRY(wc.alloc(sizeof(T) * 2 * n, s));
-    BDSP_TRY(wb.alloc(sizeof(T) * 2 * m, s));
+    std::lock_guard<std::mutex> lk(g_bs_mu); // plans cannot be evicted between lookup and launch
+    const T *chirp = nullptr, *bspec = nullptr;
+    BDSP_TRY(bs_plan<T>(n, m, inverse, s, &chirp, &bspec));
+    WsBlock wa, wt;
     BDSP_TRY(wa.alloc(sizeof(T) * 2 * m * batch, s));
     BDSP_TRY(wt.alloc(sizeof(T) * 2 * m * batch, s));
-    BDSP_HIP_TRY(hipMemcpyAsync(wc.p, chirp.data(), sizeof(T) * 2 * n, hipMemcpyHostToDevice, s));
-    BDSP_HIP_TRY(hipMemcpyAsync(wb.p, bk.data(), sizeof(T) * 2 * m, hipMemcpyHostToDevice, s));
-    BDSP_HIP_TRY(hipStreamSynchronize(s)); // host vectors go out of scope
-    T* dc = wc.as<T>();
-    T* db = wb.as<T>();
-    T* da = wa.as<T>();
-    T* dt = wt.as<T>();
-    // optional prologue on the input itself (window / shift / scale), in place or via b
-    T* src = a;
-    if (flags & BDSP_FFT_SHIFT_IN) {
-        for (size_t v = 0; v < batch; ++v)
-            BDSP_TRY(rg_rotate<T>(a + 2 * n * v, b + 2 * n * v, n, 2, n / 2, s));
-        src = b;
-    }
-    if (window_id >= 0)
-        for (size_t v = 0; v < batch; ++v)
-            BDSP_TRY(ew_window<T>(src + 2 * n * v, 2 * n, true, window_id, window_alpha, false, s));
-    if (in_scale != (T)1) BDSP_TRY(ew_real_scale<T>(src, 2 * n * batch, in_scale, s));
-    // a_pad[v] = x[v] * conj(c), zero padded to m
-    BDSP_HIP_TRY(hipMemsetAsync(da, 0, sizeof(T) * 2 * m * batch, s));
-    BDSP_HIP_TRY(hipMemcpy2DAsync(da, sizeof(T) * 2 * m, src, sizeof(T) * 2 * n, sizeof(T) * 2 * n,
-                                  batch, hipMemcpyDeviceToDevice, s));
-    {
-        // multiply by conj(chirp): conj the chirp once into dt[0..2n), then broadcast-multiply
-        BDSP_HIP_TRY(hipMemsetAsync(dt, 0, sizeof(T) * 2 * m, s));
-        BDSP_HIP_TRY(hipMemcpyAsync(dt, dc, sizeof(T) * 2 * n, hipMemcpyDeviceToDevice, s));
-        BDSP_TRY(ew_conj<T>(dt, 2 * n, s));
-        // positions >= n of dt are zero and da is zero there too, so a plain broadcast product works
-        BDSP_TRY(mul_bcast<T>(da, dt, m, batch, (T)1, s));
-    }
-    bool rb = false;
-    // B = FFT_m(b)
-    BDSP_TRY(fft_two_buffers<T>(db, dt, m, 1, false, 0, (T)1, -1, (T)0, &rb, s));
-    T* spec_b = rb ? dt : db;
-    T* other = rb ? db : dt;
-    (void)other;
-    // A = FFT_m(a_pad) (batch), needs its own scratch
-    WsBlock ws2;
-    BDSP_TRY(ws2.alloc(sizeof(T) * 2 * m * batch, s));
+    const bool out_div = (flags & FFT_WINDOW_OUT_DIV) != 0;
+    BDSP_TRY(bs_pre<T>(a, wa.as<T>(), chirp, n, m, batch, (flags & FFT_IN_REAL) != 0, in_scale,
+                       (flags & BDSP_FFT_SHIFT_IN) ? n / 2 : 0, out_div ? -1 : window_id, window_alpha, s));
     bool ra = false;
-    BDSP_TRY(fft_two_buffers<T>(da, ws2.as<T>(), m, batch, false, 0, (T)1, -1, (T)0, &ra, s));
-    T* spec_a = ra ? ws2.as<T>() : da;
-    T* scr_a = ra ? da : ws2.as<T>();
-    BDSP_TRY(mul_bcast<T>(spec_a, spec_b, m, batch, (T)1 / (T)m, s));
+    BDSP_TRY(fft_two_buffers<T>(wa.as<T>(), wt.as<T>(), m, batch, false, 0, (T)1, -1, (T)0, &ra, s));
+    T* spec = ra ? wt.as<T>() : wa.as<T>();
+    T* scr = ra ? wa.as<T>() : wt.as<T>();
+    BDSP_TRY(mul_bcast<T>(spec, bspec, m, batch, (T)1 / (T)m, s));
     bool rc = false;
-    BDSP_TRY(fft_two_buffers<T>(spec_a, scr_a, m, batch, true, 0, (T)1, -1, (T)0, &rc, s));
-    T* conv = rc ? scr_a : spec_a;
-    // X[k] = conv[k] * conj(c[k]), k < n: reuse dt (conj chirp, zero beyond n) on the m-strided rows
-    BDSP_HIP_TRY(hipMemsetAsync(dt, 0, sizeof(T) * 2 * m, s));
-    BDSP_HIP_TRY(hipMemcpyAsync(dt, dc, sizeof(T) * 2 * n, hipMemcpyDeviceToDevice, s));
-    BDSP_TRY(ew_conj<T>(dt, 2 * n, s));
-    BDSP_TRY(mul_bcast<T>(conv, dt, m, batch, (T)1, s));
-    T* dst = a;
-    if (flags & BDSP_FFT_SHIFT_OUT) {
-        // gather rows into b, then rotate into a
-        BDSP_HIP_TRY(hipMemcpy2DAsync(b, sizeof(T) * 2 * n, conv, sizeof(T) * 2 * m, sizeof(T) * 2 * n,
-                                      batch, hipMemcpyDeviceToDevice, s));
-        for (size_t v = 0; v < batch; ++v)
-            BDSP_TRY(rg_rotate<T>(b + 2 * n * v, a + 2 * n * v, n, 2, n - n / 2, s));
-    } else {
-        BDSP_HIP_TRY(hipMemcpy2DAsync(dst, sizeof(T) * 2 * n, conv, sizeof(T) * 2 * m, sizeof(T) * 2 * n,
-                                      batch, hipMemcpyDeviceToDevice, s));
-    }
-    return BDSP_OK;
+    BDSP_TRY(fft_two_buffers<T>(spec, scr, m, batch, true, 0, (T)1, -1, (T)0, &rc, s));
+    const T* conv = rc ? scr : spec;
+    const int out_kind = (flags & BDSP_FFT_MAGNITUDE) ? 2 : ((flags & FFT_OUT_REAL) ? 1 : 0);
+    return bs_post<T>(conv, a, chirp, n, m, batch, out_kind, (flags & BDSP_FFT_SHIFT_OUT) ? n - n / 2 : 0,
+                      out_div ? window_id : -1, window_alpha, s);
 }
 
 template <typename T> constexpr int elem_of() { return sizeof(T) == 8; }
@@ -464,27 +460,11 @@ int op_fft(DevVec<T>* v, bool inverse, bool shift, int window /* -1 none */, siz
         if (window >= 0) { map_window<T>(window, &wid, &alpha); flags |= FFT_WINDOW_OUT_DIV; }
     }
     if (points == 0) { v->complex_ = true; v->freq = !inverse; return BDSP_OK; }
-    if (!is_pow2(points) && (flags & (FFT_IN_REAL | FFT_WINDOW_OUT_DIV))) {
-        // slow path pieces the fused kernels do not cover for Bluestein lengths
-        if (flags & FFT_IN_REAL) {
-            BDSP_TRY(rg_zero_interleave<T>(v->data, v->buf, v->valid_len, 1, 2, s));
-            v->trade();
-            v->valid_len *= 2;
-            v->complex_ = true;
-            flags &= ~FFT_IN_REAL;
-        }
-    }
-    bool out_div = (flags & FFT_WINDOW_OUT_DIV) && !is_pow2(points);
-    if (out_div) flags &= ~FFT_WINDOW_OUT_DIV;
-    int fwid = (out_div ? -1 : wid);
     bool in_b = false;
-    BDSP_TRY(fft_two_buffers<T>(v->data, v->buf, points, rows, inverse, flags, in_scale, fwid, alpha, &in_b, s));
+    BDSP_TRY(fft_two_buffers<T>(v->data, v->buf, points, rows, inverse, flags, in_scale, wid, alpha, &in_b, s));
     if (in_b) v->trade();
     v->valid_len = 2 * points * rows;
     v->complex_ = true;
-    if (out_div)
-        for (size_t r = 0; r < rows; ++r)
-            BDSP_TRY(ew_window<T>(v->data + 2 * points * r, 2 * points, true, wid, alpha, true, s));
     // fft(): delta <- points * delta (time_freq/mod.rs:54-55; the reference's own GPU branch
     // forgets this, SURVEY.md section 3.1 -- the CPU behaviour is the contract)
     v->delta = (T)points * v->delta;

@@ -458,7 +458,7 @@ static int launch_pass_rp(int rp, int w, const FftIo<T>& io, const cpx<T>* src, 
 // Super-radix plan for n = 2^bits > 4096: 2 passes up to 2^20, 3 passes up to 2^30, bits split as
 // evenly as possible, largest first (the first pass is the one whose stores are always long
 // contiguous runs, so it can afford the narrowest tile).
-static int plan_passes(size_t n, int rp[3], int w[3])
+static int plan_passes(size_t n, size_t batch, int rp[3], int w[3])
 {
     int bits = 0;
     while ((size_t(1) << bits) < n) ++bits;
@@ -484,7 +484,9 @@ static int plan_passes(size_t n, int rp[3], int w[3])
         // 1024-point columns: 8-wide tiles (64-byte segments, 512 threads) measured 14 % faster than
         // 4-wide ones on 64 x 2^20 points; 2-pass plans for 2^24 (4096x2 / 4096x4 tiles) measured
         // 30-70 % SLOWER than three fully coalesced 256-point passes, so 3 passes stay.
-        if (rp[i] == 1024) w[i] = 8;
+        // ... unless that leaves fewer tiles than two per CU (a single 2^20-point vector has 128):
+        // then 4-wide tiles fill the chip (measured 19.8 -> 17.2 us for one 2^20-point transform)
+        if (rp[i] == 1024) w[i] = (n * batch / 8192 >= (size_t)2 * num_cus()) ? 8 : 4;
     }
     return passes;
 }
@@ -520,7 +522,7 @@ int fft_pow2(const FftIo<T>& io, T* scratch_a, T* scratch_b, size_t batch, bool 
     default: break;
     }
     int rp[3], w[3];
-    int passes = plan_passes(n, rp, w);
+    int passes = plan_passes(n, batch, rp, w);
     if (passes == 0) { set_last_error("FFT length above 2^30 points"); return BDSP_ERR_UNSUPPORTED; }
     if (!scratch_a || (passes == 3 && !scratch_b)) {
         set_last_error("fft_pow2: scratch missing");
