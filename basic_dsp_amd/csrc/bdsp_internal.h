@@ -92,7 +92,9 @@ int conv_prepare_spectrum(const T* taps_dev, size_t taps, const T* h_freq_dev, T
 template <typename T>
 int conv_run_blocks(const T* in, T* out, size_t points, size_t batch, const T* hs, size_t taps,
                     long long in_off, long long out_off, size_t nblocks_limit, T* last_block_out,
-                    hipStream_t s);
+                    hipStream_t s, bool real_data = false);
+// real_data: in/out are REAL vectors of `points` samples and hs is the spectrum of REAL taps; two real
+// blocks share one complex transform pair
 // the spectrum handed to conv_run_blocks is UNSCALED; the kernel multiplies by 1/L while it loads it
 template <typename T> int mul_bcast(T* z, const T* h, size_t l, size_t nb, T scale, hipStream_t s);
 template <typename T>

@@ -198,20 +198,18 @@ int conv_complex_dev(const T* in, T* out, size_t points, size_t batch, const T* 
     return convolve_direct<T>(in, out, points, batch, taps, ntaps, true, s);
 }
 
-// real data: complexify (zero imaginary parts), run the complex path, keep the real parts
+// real data with real taps: the block kernel packs two real blocks into one complex transform pair
 template <typename T>
 int conv_real_dev(const T* in, T* out, size_t points, const T* taps, size_t ntaps, hipStream_t s, size_t batch = 1)
 {
     if (!(ntaps >= 1 && ntaps - 1 <= 1024 && ntaps <= points))
         return convolve_direct<T>(in, out, points, batch, taps, ntaps, false, s);
-    WsBlock xc, yc, hc;
-    BDSP_TRY(xc.alloc(sizeof(T) * 2 * points * batch, s));
-    BDSP_TRY(yc.alloc(sizeof(T) * 2 * points * batch, s));
+    WsBlock hc, hsb;
     BDSP_TRY(hc.alloc(sizeof(T) * 2 * ntaps, s));
-    BDSP_TRY(rg_zero_interleave<T>(in, xc.as<T>(), points * batch, 1, 2, s));
+    BDSP_TRY(hsb.alloc(sizeof(T) * 2 * conv_fft_len(ntaps), s));
     BDSP_TRY(rg_zero_interleave<T>(taps, hc.as<T>(), ntaps, 1, 2, s));
-    BDSP_TRY(conv_complex_dev<T>(xc.as<T>(), yc.as<T>(), points, batch, hc.as<T>(), ntaps, s));
-    return ew_complex_to_real<T>(yc.as<T>(), out, 2 * points * batch, 2, s);
+    BDSP_TRY(conv_prepare_spectrum<T>(hc.as<T>(), ntaps, nullptr, hsb.as<T>(), s));
+    return conv_run_blocks<T>(in, out, points, batch, hsb.as<T>(), ntaps, -(long long)(ntaps / 2), 0, 0, nullptr, s, true);
 }
 
 template <typename T>

@@ -40,9 +40,13 @@ size_t conv_fft_len(size_t) { return CONV_L; }
 //     4 with H re-read from L2 and 20 spilled registers 99 us, ping-pong LDS buffers (4 barriers
 //     instead of 8) 80 us, one-block-per-workgroup with every table re-read 149 us;
 //   * the generic build (f64) keeps everything in L2 and prefetches one block.
-template <typename T, bool FAST>
-__global__ __launch_bounds__(256, 3) void k_overlap_save(
-    const cpx<T>* __restrict__ x, cpx<T>* __restrict__ y, const cpx<T>* __restrict__ hs,
+//   * REAL: the vector is REAL (and so are the taps): two consecutive blocks travel through the
+//     complex transform pair as real and imaginary part (convolution with a real filter is
+//     real-linear, so they come out separated) -- half the butterflies and 8 B of traffic per sample
+//     instead of complexify -> convolve -> project (40 B per sample).
+template <typename T, bool FAST, bool REAL>
+__global__ __launch_bounds__(256, sizeof(T) == 4 ? 3 : 2) void k_overlap_save(
+    const void* __restrict__ x_, void* __restrict__ y_, const cpx<T>* __restrict__ hs,
     const cpx<T>* __restrict__ wtab, unsigned n, int m_taps, long long in_off, long long out_off,
     unsigned blocks_per_vec, unsigned out_limit, int store_all)
 {
@@ -58,7 +62,7 @@ __global__ __launch_bounds__(256, 3) void k_overlap_save(
     // natural V = L-(M-1) = 3073 each 512-byte wave access straddled five lines instead of four and
     // began mid-line (timeline: 12 stores took 2.3k cycles to issue).
     const unsigned Vfull = (unsigned)(L - ov);
-    const unsigned V = Vfull >= 16 ? (Vfull & ~15u) : Vfull;
+    const unsigned V = REAL ? (Vfull >= 32 ? (Vfull & ~31u) : Vfull) : (Vfull >= 16 ? (Vfull & ~15u) : Vfull);
     const T hscale = (T)1 / (T)L; // the inverse transform below is unnormalised
     auto tw = [&](int mm) { return wtab[mm]; };
 
@@ -71,20 +75,49 @@ __global__ __launch_bounds__(256, 3) void k_overlap_save(
             cpx<T> hv = hs[ut + 256u * r];
             hreg[r] = cpx<T>{hv.x * hscale, hv.y * hscale};
         }
-        if (t < 240) {
-            int k = t / 15, r = t % 15 + 1;
-            tw2l[k * 17 + r - 1] = wtab[r * k * 16];
-        }
-        __syncthreads();
     }
+    // stage-2 twiddles (16 distinct rows of 15) in LDS for both builds
+    if (t < 240) {
+        int k = t / 15, r = t % 15 + 1;
+        tw2l[k * 17 + r - 1] = wtab[r * k * 16];
+    }
+    __syncthreads();
     const cpx<T>* tw2p = tw2l + (t & 15) * 17;
     const size_t vec = blockIdx.y;
-    const cpx<T>* __restrict__ xv = x + vec * (size_t)n;
-    cpx<T>* __restrict__ yv = y + vec * (size_t)(store_all ? (unsigned)L : n);
+    // per-vector bases; a REAL vector has n real samples (half the bytes of n complex ones)
+    const cpx<T>* __restrict__ xv = REAL
+        ? reinterpret_cast<const cpx<T>*>(reinterpret_cast<const T*>(x_) + vec * (size_t)n)
+        : reinterpret_cast<const cpx<T>*>(x_) + vec * (size_t)n;
+    cpx<T>* __restrict__ yv = REAL
+        ? reinterpret_cast<cpx<T>*>(reinterpret_cast<T*>(y_) + vec * (size_t)n)
+        : reinterpret_cast<cpx<T>*>(y_) + vec * (size_t)(store_all ? (unsigned)L : n);
 
     // block b reads x[(b*V + in_off + i) mod n], i = t + 256 r.  Global addressing is
     // uniform 64-bit base (scalar registers) + small unsigned lane index.
+    // REAL: "block" b is the pair of real blocks 2b (real part) and 2b+1 (imaginary part)
+    auto load_real = [&](unsigned rb, T (&d)[16]) {
+        const T* __restrict__ xr = reinterpret_cast<const T*>(xv); // REAL: n real samples per vector
+        long long base = (long long)rb * V + in_off;
+        if (base >= 0 && base + L <= (long long)n) {
+            const T* xb = xr + base;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) d[r] = xb[ut + 256u * r];
+        } else {
+            long long sb = base % (long long)n;
+            if (sb < 0) sb += n;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) d[r] = xr[((unsigned long long)sb + ut + 256u * r) % n];
+        }
+    };
     auto load_block = [&](unsigned b, cpx<T> (&d)[16]) {
+        if constexpr (REAL) {
+            T re[16], im[16];
+            load_real(2 * b, re);
+            load_real(2 * b + 1, im); // past the end it wraps around; its outputs are never stored
+#pragma unroll
+            for (int r = 0; r < 16; ++r) d[r] = cpx<T>{re[r], im[r]};
+            return;
+        }
         long long base = (long long)b * V + in_off;
         if (base >= 0 && base + L <= (long long)n) {
             const cpx<T>* xb = xv + base;
@@ -132,8 +165,7 @@ __global__ __launch_bounds__(256, 3) void k_overlap_save(
         F::template scatter<16, 1>(v, t, lds);
         __syncthreads();
         F::template gather<16>(v, t, lds);
-        if constexpr (FAST) F::template compute_pre<16, 16, -1>(v, tw2p);
-        else F::template compute<16, 16, -1>(v, t, twl);
+        F::template compute_pre<16, 16, -1>(v, tw2p);
         __syncthreads();
         F::template scatter<16, 16>(v, t, lds);
         __syncthreads();
@@ -157,8 +189,7 @@ __global__ __launch_bounds__(256, 3) void k_overlap_save(
         F::template scatter<16, 1>(v, t, lds);
         __syncthreads();
         F::template gather<16>(v, t, lds);
-        if constexpr (FAST) F::template compute_pre<16, 16, 1>(v, tw2p);
-        else F::template compute<16, 16, 1>(v, t, twl);
+        F::template compute_pre<16, 16, 1>(v, tw2p);
         __syncthreads();
         F::template scatter<16, 16>(v, t, lds);
         __syncthreads();
@@ -167,7 +198,21 @@ __global__ __launch_bounds__(256, 3) void k_overlap_save(
         else F::template compute<16, 256, 1>(v, t, twl);
 
         // ---- store: z[n'] for n' >= M-1 is output b*V + out_off + (n' - (M-1))
-        if (store_all) {
+        if constexpr (REAL) {
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const long long obase = (long long)(2 * b + half) * V + out_off - ov;
+                long long room = (long long)out_limit - obase;
+                unsigned lim = room <= 0 ? 0u : (room > L ? (unsigned)L : (unsigned)room);
+                if (lim > (unsigned)ov + V) lim = (unsigned)ov + V;
+                T* yb = reinterpret_cast<T*>(yv) + obase;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    unsigned np = ut + 256u * r;
+                    if (np >= (unsigned)ov && np < lim) yb[np] = half ? v[r].y : v[r].x;
+                }
+            }
+        } else if (store_all) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) yv[ut + 256u * r] = v[r];
         } else {
@@ -185,9 +230,8 @@ __global__ __launch_bounds__(256, 3) void k_overlap_save(
         }
     };
 
-    if constexpr (FAST) {
-        // two blocks of input in flight per workgroup (prefetch distance 2): with one block the
-        // request stream had gaps and HBM sat idle half of the time
+    constexpr bool PREFETCH = false;
+    if constexpr (!PREFETCH) {
         for (unsigned b = wl; b < blocks_per_vec; b += G) {
             cpx<T> v[16];
             load_block(b, v);
@@ -272,7 +316,7 @@ int conv_prepare_spectrum(const T* taps_dev, size_t taps, const T* h_freq_dev, T
 template <typename T>
 int conv_run_blocks(const T* in, T* out, size_t points, size_t batch, const T* hs, size_t taps,
                     long long in_off, long long out_off, size_t nblocks_limit, T* last_block_out,
-                    hipStream_t s)
+                    hipStream_t s, bool real_data)
 {
     constexpr int L = CONV_L;
     if (taps == 0 || taps - 1 > (size_t)L / 4 || points == 0) {
@@ -286,11 +330,16 @@ int conv_run_blocks(const T* in, T* out, size_t points, size_t batch, const T* h
         return BDSP_ERR_UNSUPPORTED;
     }
     long long V = L - (long long)(taps - 1);
-    if (V >= 16) V &= ~15LL; // must match the kernel's aligned block step
+    if (real_data) { if (V >= 32) V &= ~31LL; }
+    else if (V >= 16) V &= ~15LL; // must match the kernel's aligned block step
     long long per_vec = nblocks_limit ? (long long)nblocks_limit : ((long long)points + V - 1) / V;
+    if (real_data) {
+        if (nblocks_limit || last_block_out) { set_last_error("real block pairs: partial runs unsupported"); return BDSP_ERR_UNSUPPORTED; }
+        per_vec = (per_vec + 1) / 2; // two real blocks per complex transform pair
+    }
     size_t lds = conv_lds_bytes<T>();
     constexpr bool FAST = sizeof(T) == 4;
-    auto kern = k_overlap_save<T, FAST>;
+    auto kern = real_data ? k_overlap_save<T, FAST, true> : k_overlap_save<T, FAST, false>;
     if (lds > 64 * 1024)
         BDSP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -303,7 +352,7 @@ int conv_run_blocks(const T* in, T* out, size_t points, size_t batch, const T* h
     if (gx < 1) gx = 1;
     if (per_vec > 0) {
         hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)batch), dim3(256), lds, s,
-                           reinterpret_cast<const cpx<T>*>(in), reinterpret_cast<cpx<T>*>(out),
+                           static_cast<const void*>(in), static_cast<void*>(out),
                            reinterpret_cast<const cpx<T>*>(hs), wtab, (unsigned)points, (int)taps,
                            in_off, out_off, (unsigned)per_vec, (unsigned)points, 0);
         BDSP_LAUNCH_CHECK();
@@ -311,8 +360,8 @@ int conv_run_blocks(const T* in, T* out, size_t points, size_t batch, const T* h
     if (last_block_out) {
         long long b = (long long)nblocks_limit;
         hipLaunchKernelGGL(kern, dim3(1, 1), dim3(256), lds, s,
-                           reinterpret_cast<const cpx<T>*>(in),
-                           reinterpret_cast<cpx<T>*>(last_block_out),
+                           static_cast<const void*>(in),
+                           static_cast<void*>(last_block_out),
                            reinterpret_cast<const cpx<T>*>(hs), wtab, (unsigned)points, (int)taps,
                            in_off + b * V, 0LL, 1u, (unsigned)L, 1);
         BDSP_LAUNCH_CHECK();
@@ -329,7 +378,7 @@ int convolve_overlap_save(const T* in, T* out, size_t points, size_t batch, cons
     BDSP_TRY(hsb.alloc(sizeof(cpx<T>) * CONV_L, s));
     BDSP_TRY(conv_prepare_spectrum<T>(taps_dev, taps, h_freq_dev, hsb.as<T>(), s));
     return conv_run_blocks<T>(in, out, points, batch, hsb.as<T>(), taps, in_off, out_off,
-                              nblocks_limit, last_block_out, s);
+                              nblocks_limit, last_block_out, s, false);
 }
 
 template <typename T>
@@ -364,8 +413,8 @@ template int convolve_overlap_save<double>(const double*, double*, size_t, size_
                                            long long, long long, size_t, double*, const double*, hipStream_t);
 template int conv_prepare_spectrum<float>(const float*, size_t, const float*, float*, hipStream_t);
 template int conv_prepare_spectrum<double>(const double*, size_t, const double*, double*, hipStream_t);
-template int conv_run_blocks<float>(const float*, float*, size_t, size_t, const float*, size_t, long long, long long, size_t, float*, hipStream_t);
-template int conv_run_blocks<double>(const double*, double*, size_t, size_t, const double*, size_t, long long, long long, size_t, double*, hipStream_t);
+template int conv_run_blocks<float>(const float*, float*, size_t, size_t, const float*, size_t, long long, long long, size_t, float*, hipStream_t, bool);
+template int conv_run_blocks<double>(const double*, double*, size_t, size_t, const double*, size_t, long long, long long, size_t, double*, hipStream_t, bool);
 template int convolve_direct<float>(const float*, float*, size_t, size_t, const float*, size_t, bool, hipStream_t);
 template int convolve_direct<double>(const double*, double*, size_t, size_t, const double*, size_t, bool, hipStream_t);
 
