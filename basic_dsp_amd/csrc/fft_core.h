@@ -184,6 +184,43 @@ BDSP_HD void dft8(C* v)
     v[3] = cadd(e3, o3); v[7] = csub(e3, o3);
 }
 
+// dft16 in two halves (dft16 = dft16_a; dft16_b) for kernels that put a barrier in the middle
+template <int DIR, typename C>
+BDSP_HD void dft16_a(C* v)
+{
+    using T = typename real_of<C>::type;
+    dft4<DIR>(v[0], v[4], v[8], v[12]);
+    dft4<DIR>(v[1], v[5], v[9], v[13]);
+    dft4<DIR>(v[2], v[6], v[10], v[14]);
+    dft4<DIR>(v[3], v[7], v[11], v[15]);
+    const T c1 = (T)0.92387953251128675613, s1 = (T)0.38268343236508977173;
+    const C w1 = {c1, -s1}, w3 = {s1, -c1};
+    v[5] = twmul<DIR>(v[5], w1);
+    v[6] = mul_w8_1<DIR>(v[6]);
+    v[7] = twmul<DIR>(v[7], w3);
+    v[9] = mul_w8_1<DIR>(v[9]);
+    v[10] = rot_i<DIR>(v[10]);
+    v[11] = mul_w8_3<DIR>(v[11]);
+    v[13] = twmul<DIR>(v[13], w3);
+    v[14] = mul_w8_3<DIR>(v[14]);
+    v[15] = twmul<DIR>(v[15], C{-c1, s1});
+}
+template <int DIR, typename C>
+BDSP_HD void dft16_b(C* v)
+{
+    dft4<DIR>(v[0], v[1], v[2], v[3]);
+    dft4<DIR>(v[4], v[5], v[6], v[7]);
+    dft4<DIR>(v[8], v[9], v[10], v[11]);
+    dft4<DIR>(v[12], v[13], v[14], v[15]);
+    C t;
+    t = v[1]; v[1] = v[4]; v[4] = t;
+    t = v[2]; v[2] = v[8]; v[8] = t;
+    t = v[3]; v[3] = v[12]; v[12] = t;
+    t = v[6]; v[6] = v[9]; v[9] = t;
+    t = v[7]; v[7] = v[13]; v[13] = t;
+    t = v[11]; v[11] = v[14]; v[14] = t;
+}
+
 template <int DIR, typename C>
 BDSP_HD void dft16(C* v)
 {
@@ -281,6 +318,32 @@ struct WgFft {
             dft<R, DIR>(&v[b * R]);
         }
     }
+    // Radix-16 twiddles w^r, r = 1..15, held as SIX values: r = 4a + b, w^r = w^(4a) * w^b with
+    // twb = {w, w^2, w^3} and twa = {w^4, w^8, w^12}.  Costs 9 extra complex multiplies per butterfly
+    // and frees 18 registers per thread (the overlap-save kernel was two registers short of running
+    // without scratch spills, and every spill reload next to a store waits for that store to retire).
+    template <int NS, int DIR>
+    static BDSP_HD void compute_pre16_split(cpx<T> (&v)[E], const cpx<T>* twa, const cpx<T>* twb)
+    {
+        static_assert(E == 16, "one radix-16 butterfly per thread");
+#pragma unroll
+        for (int r = 1; r < 16; ++r) {
+            if (r & 3) v[r] = twmul<DIR>(v[r], twb[(r & 3) - 1]);
+            if (r >> 2) v[r] = twmul<DIR>(v[r], twa[(r >> 2) - 1]);
+        }
+        dft<16, DIR>(&v[0]);
+    }
+    template <int NS, class TW>
+    static BDSP_HD void load_twiddles16_split(cpx<T>* twa, cpx<T>* twb, int t, TW tw)
+    {
+        const int k = t % NS, step = N / (NS * 16);
+#pragma unroll
+        for (int i = 1; i < 4; ++i) {
+            twb[i - 1] = tw(i * k * step);
+            twa[i - 1] = tw(4 * i * k * step);
+        }
+    }
+
     template <int R, int NS, class TW>
     static BDSP_HD void load_twiddles(cpx<T>* tws, int t, TW tw)
     {
