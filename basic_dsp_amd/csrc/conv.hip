@@ -172,14 +172,14 @@ __global__ __launch_bounds__(256, sizeof(T) == 4 ? 3 : 2) void k_overlap_save(
         // ---- forward FFT_L
         F::template compute<16, 1, -1>(v, t, twl);
         __syncthreads(); // previous block's last gather is done
-        F::template scatter<16, 1>(v, t, lds);
+        F::scatter_a(v, t, lds);
         __syncthreads();
-        F::template gather<16>(v, t, lds);
+        F::gather_a(v, t, lds);
         F::template compute_pre<16, 16, -1>(v, tw2p);
         __syncthreads();
-        F::template scatter<16, 16>(v, t, lds);
+        F::scatter_b(v, t, lds);
         __syncthreads();
-        F::template gather<16>(v, t, lds);
+        F::gather_b(v, t, lds);
         if constexpr (FAST) F::template compute_pre16_split<256, -1>(v, tw3a, tw3b);
         else F::template compute<16, 256, -1>(v, t, twl);
 
@@ -196,14 +196,14 @@ __global__ __launch_bounds__(256, sizeof(T) == 4 ? 3 : 2) void k_overlap_save(
         // ---- inverse FFT_L
         F::template compute<16, 1, 1>(v, t, twl);
         __syncthreads();
-        F::template scatter<16, 1>(v, t, lds);
+        F::scatter_a(v, t, lds);
         __syncthreads();
-        F::template gather<16>(v, t, lds);
+        F::gather_a(v, t, lds);
         F::template compute_pre<16, 16, 1>(v, tw2p);
         __syncthreads();
-        F::template scatter<16, 16>(v, t, lds);
+        F::scatter_b(v, t, lds);
         __syncthreads();
-        F::template gather<16>(v, t, lds);
+        F::gather_b(v, t, lds);
         if constexpr (FAST) F::template compute_pre16_split<256, 1>(v, tw3a, tw3b);
         else F::template compute<16, 256, 1>(v, t, twl);
 

@@ -19,9 +19,10 @@ __global__ __launch_bounds__(256, 3) void k_xchg(cpx<float>* out, int iters)
     for (int r = 0; r < 16; ++r) v[r] = cpx<float>{(float)(t + r), (float)(t - r)};
     for (int i = 0; i < iters; ++i) {
         __syncthreads();
-        if (WHICH == 0) F::scatter<16, 1>(v, t, lds); else F::scatter<16, 16>(v, t, lds);
+        if (WHICH == 0) F::scatter<16, 1>(v, t, lds); else if (WHICH == 1) F::scatter<16, 16>(v, t, lds);
+        else if (WHICH == 2) F::scatter_a(v, t, lds); else F::scatter_b(v, t, lds);
         __syncthreads();
-        F::gather<16>(v, t, lds);
+        if (WHICH < 2) F::gather<16>(v, t, lds); else if (WHICH == 2) F::gather_a(v, t, lds); else F::gather_b(v, t, lds);
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) out[(size_t)blockIdx.x * 4096 + t + 256 * r] = v[r];
@@ -36,11 +37,14 @@ int main()
     const int iters = 2000;
     hipFuncSetAttribute((const void*)k_xchg<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     hipFuncSetAttribute((const void*)k_xchg<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-    for (int which = 0; which < 2; ++which)
+    hipFuncSetAttribute((const void*)k_xchg<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    hipFuncSetAttribute((const void*)k_xchg<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    const char* names[4] = {"16,1 pad16", "16,16 pad16", "A pad32x1", "B pad32x2"};
+    for (int which = 0; which < 4; ++which)
         for (int k = 1; k <= 4; ++k) {
             size_t lds = (size_t)(150 * 1024) / k - 1024;
             hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-            auto kern = which ? k_xchg<1> : k_xchg<0>;
+            auto kern = which == 0 ? k_xchg<0> : which == 1 ? k_xchg<1> : which == 2 ? k_xchg<2> : k_xchg<3>;
             hipLaunchKernelGGL(kern, dim3(cus * k), dim3(256), lds, 0, out, 10);
             hipDeviceSynchronize();
             hipEventRecord(e0, 0);
@@ -49,7 +53,7 @@ int main()
             hipDeviceSynchronize();
             float ms; hipEventElapsedTime(&ms, e0, e1);
             printf("scatter<%s> wg/CU %d: %.3f ms -> %.1f ns per exchange per CU (%.1f ns per workgroup-exchange)\n",
-                   which ? "16,16" : "16,1", k, ms, ms * 1e6 / iters / k, ms * 1e6 / iters);
+                   names[which], k, ms, ms * 1e6 / iters / k, ms * 1e6 / iters);
         }
     return 0;
 }
