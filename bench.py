@@ -160,8 +160,23 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    conv_ms, fft_ms = [], []
+    # what an event pair costs by itself on this stream (two records with nothing between): the
+    # per-kernel durations below are event deltas minus this, so they are comparable with rocprofv3's
+    # kernel-only durations (profiles/*_bench_kernel_stats.csv)
     ms = C.c_float(0)
+    empty = []
+    for _ in range(20):
+        ea, eb = lib.bdsp_hip_event_create(), lib.bdsp_hip_event_create()
+        lib.bdsp_hip_event_record(ea, sp)
+        lib.bdsp_hip_event_record(eb, sp)
+        lib.bdsp_hip_synchronize(sp)
+        lib.bdsp_hip_event_elapsed_ms(ea, eb, C.byref(ms))
+        empty.append(ms.value)
+        lib.bdsp_hip_event_destroy(ea)
+        lib.bdsp_hip_event_destroy(eb)
+    event_overhead = sorted(empty)[len(empty) // 2]
+
+    conv_ms, fft_ms = [], []
     for e in events:
         lib.bdsp_hip_event_elapsed_ms(e[0], e[1], C.byref(ms))
         conv_ms.append(ms.value)
@@ -169,8 +184,9 @@ def main():
         fft_ms.append(ms.value)
         for h in e:
             lib.bdsp_hip_event_destroy(h)
-    conv_avg = sum(conv_ms) / len(conv_ms)
-    fft_avg = sum(fft_ms) / len(fft_ms)
+    conv_raw = sum(conv_ms) / len(conv_ms)
+    conv_avg = max(conv_raw - event_overhead, 1e-6)
+    fft_avg = max(sum(fft_ms) / len(fft_ms) - event_overhead, 1e-6)
 
     if rank == 0:
         samples = n * world * args.steps
@@ -206,6 +222,7 @@ def main():
                 "traffic": pmc_traffic("k_overlap_save<float") if (n, m) == (POINTS, TAPS) else None,
                 "algorithmic_bytes_per_launch": algo_bytes,
                 "avg_launch_ms": conv_avg,
+                "event_delta_ms": conv_raw, "event_pair_overhead_ms": event_overhead,
                 "dominant": bool(dominant_conv),
             },
             "kernels": {
