@@ -188,8 +188,49 @@ _proto("bdsp_hip_event_create", _P)
 _proto("bdsp_hip_event_record", _I, _P, _P)
 _proto("bdsp_hip_event_elapsed_ms", _I, _P, _P, C.POINTER(_F))
 _proto("bdsp_hip_event_destroy", None, _P)
+_proto("bdsp_hip_capture_begin", _I, _P)
+_proto("bdsp_hip_capture_end", _I, _P, C.POINTER(_P))
+_proto("bdsp_hip_graph_launch", _I, _P, _P)
+_proto("bdsp_hip_graph_destroy", None, _P)
 
 FFT_INVERSE, FFT_SHIFT_OUT, FFT_SHIFT_IN, FFT_MAGNITUDE = 1, 2, 4, 8
+
+
+class Graph:
+    """A captured sequence of library calls (HIP graph).  Usage:
+        g = Graph.capture(lambda: (v.scale(2.5), v.offset(-1.25)))   # runs fn once to warm up, then captures
+        g.launch()                                                   # replays with one launch
+    Capture and replay happen on the library stream unless `stream` (a hipStream_t int) is given."""
+
+    def __init__(self, handle, stream):
+        self._h, self._stream = handle, stream
+
+    @classmethod
+    def capture(cls, fn, stream=None, warmup=True):
+        sp = C.c_void_p(stream)
+        if warmup:
+            fn()
+            check(lib.bdsp_hip_synchronize(sp), "synchronize")
+        check(lib.bdsp_hip_capture_begin(sp), "capture_begin")
+        try:
+            fn()
+        finally:
+            h = C.c_void_p(None)
+            code = lib.bdsp_hip_capture_end(sp, C.byref(h))
+        check(code, "capture_end")
+        return cls(h, sp)
+
+    def launch(self):
+        return check(lib.bdsp_hip_graph_launch(self._h, self._stream), "graph_launch")
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            try:
+                lib.bdsp_hip_graph_destroy(h)
+            except Exception:  # interpreter shutdown
+                pass
+            self._h = None
 
 
 def last_error():

@@ -1543,4 +1543,38 @@ int bdsp_hip_event_elapsed_ms(void* start, void* stop, float* ms)
 }
 void bdsp_hip_event_destroy(void* event) { if (event) (void)hipEventDestroy((hipEvent_t)event); }
 
+// ---- HIP graphs: capture a sequence of calls once, replay it with one launch -------------------------
+// Small vectors are launch-bound (config C1: scale + offset of 65 536 samples is two ~3 us launches
+// around ~1 us of work).  Everything this library enqueues after warm-up is plain kernel launches and
+// device-to-device copies on one stream -- workspace comes from the per-stream cache, twiddle tables and
+// Bluestein plans are built on first use -- so a sequence of B2/B3 calls can be stream-captured.
+// Rules: run the sequence once before capturing it (tables, plans, workspace), replay on the stream it
+// was captured on (workspace reuse is ordered per stream), and do not capture calls that talk to the
+// host (data32, get_value32, overwrite_data32, the B1 entry points, plain_sifft32's symmetry check).
+int bdsp_hip_capture_begin(void* stream)
+{
+    BDSP_TRY(check_device());
+    BDSP_HIP_TRY(hipStreamBeginCapture(pick_stream(stream), hipStreamCaptureModeRelaxed));
+    return BDSP_OK;
+}
+int bdsp_hip_capture_end(void* stream, void** graph_exec)
+{
+    if (!graph_exec) return BDSP_ERR_ARG_LENGTH;
+    *graph_exec = nullptr;
+    hipGraph_t g = nullptr;
+    BDSP_HIP_TRY(hipStreamEndCapture(pick_stream(stream), &g));
+    hipGraphExec_t e = nullptr;
+    hipError_t rc = hipGraphInstantiate(&e, g, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(g);
+    if (rc != hipSuccess) { set_last_error("hipGraphInstantiate failed"); return BDSP_ERR_HIP; }
+    *graph_exec = e;
+    return BDSP_OK;
+}
+int bdsp_hip_graph_launch(void* graph_exec, void* stream)
+{
+    BDSP_HIP_TRY(hipGraphLaunch((hipGraphExec_t)graph_exec, pick_stream(stream)));
+    return BDSP_OK;
+}
+void bdsp_hip_graph_destroy(void* graph_exec) { if (graph_exec) (void)hipGraphExecDestroy((hipGraphExec_t)graph_exec); }
+
 } // extern "C"

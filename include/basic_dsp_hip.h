@@ -545,6 +545,16 @@ int bdsp_hip_event_record(void *event, void *stream);
 int bdsp_hip_event_elapsed_ms(void *start, void *stop, float *ms);
 void bdsp_hip_event_destroy(void *event);
 
+/* HIP graphs: capture a sequence of B2/B3 calls on one stream and replay it with a single launch
+ * (small vectors are launch-bound).  Run the sequence once before capturing (tables, plans and workspace
+ * are created on first use), replay on the capture stream, and keep host-facing calls (data32,
+ * overwrite_data32, get_value32, B1 entry points, plain_sifft32) out of the captured region.
+ * stream: hipStream_t as void*, NULL = the library's own stream (the one B2 handles use). */
+int bdsp_hip_capture_begin(void *stream);
+int bdsp_hip_capture_end(void *stream, void **graph_exec);
+int bdsp_hip_graph_launch(void *graph_exec, void *stream);
+void bdsp_hip_graph_destroy(void *graph_exec);
+
 #ifdef __cplusplus
 }
 #endif

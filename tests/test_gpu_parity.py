@@ -776,3 +776,58 @@ def test_b1_entry_points_are_thread_safe():
     for t in threads:
         t.join()
     assert not errors, errors
+
+
+def test_hip_graph_capture_and_replay():
+    import time
+    from basic_dsp_amd import Graph, lib
+    # config C1: real f32, 65 536 samples, scale(2.5) then offset(-1.25) -- two launch-bound kernels
+    x = orc.fill_uniform(65536, 201511141, -10, 10, np.float32)
+    v = DspVec(x)
+    g = Graph.capture(lambda: (v.scale(2.5), v.offset(-1.25)))   # one warm-up run; capturing records, not runs
+    ref = orc.real_offset(orc.real_scale(x, 2.5), -1.25)
+    assert np.array_equal(v.data(), ref)
+    g.launch()
+    ref = orc.real_offset(orc.real_scale(ref, 2.5), -1.25)
+    assert np.array_equal(v.data(), ref)
+    # a transform chain: fft -> ifft is the identity, so replaying it leaves the vector unchanged
+    c = DspVec(orc.fill_uniform(2 * 16384, 5, -10, 10, np.float32), is_complex=True)
+    before = c.data()
+    g2 = Graph.capture(lambda: (c.fft(), c.ifft()))
+    for _ in range(5):
+        g2.launch()
+    assert rel_l2(c.data(), before) < 2e-5
+    # replay is cheaper than issuing the calls one by one
+    w = DspVec(x)
+    w.scale(1.0); w.offset(0.0)
+    g3 = Graph.capture(lambda: (w.scale(1.0), w.offset(0.0)))
+    lib.bdsp_hip_synchronize(None)
+    t0 = time.perf_counter()
+    for _ in range(200):
+        w.scale(1.0); w.offset(0.0)
+    lib.bdsp_hip_synchronize(None)
+    t_direct = (time.perf_counter() - t0) / 200
+    t0 = time.perf_counter()
+    for _ in range(200):
+        g3.launch()
+    lib.bdsp_hip_synchronize(None)
+    t_graph = (time.perf_counter() - t0) / 200
+    print("C1 scale+offset: %.1f us direct, %.1f us as a graph" % (t_direct * 1e6, t_graph * 1e6))
+    assert np.array_equal(w.data(), x)
+    # a longer chain (12 kernels)
+    def chain():
+        for _ in range(6):
+            w.scale(1.0); w.offset(0.0)
+    g4 = Graph.capture(chain)
+    lib.bdsp_hip_synchronize(None)
+    t0 = time.perf_counter()
+    for _ in range(100):
+        chain()
+    lib.bdsp_hip_synchronize(None)
+    t_direct = (time.perf_counter() - t0) / 100
+    t0 = time.perf_counter()
+    for _ in range(100):
+        g4.launch()
+    lib.bdsp_hip_synchronize(None)
+    t_graph = (time.perf_counter() - t0) / 100
+    print("12-kernel chain: %.1f us direct, %.1f us as a graph" % (t_direct * 1e6, t_graph * 1e6))
