@@ -54,8 +54,13 @@ size_t conv_fft_len(size_t) { return CONV_L; }
 //     complex transform pair as real and imaginary part (convolution with a real filter is
 //     real-linear, so they come out separated) -- half the butterflies and 8 B of traffic per sample
 //     instead of complexify -> convolve -> project (40 B per sample).
+// Experiment switch: -DBDSP_CONV_HL2=1 re-reads H from L2 per block and builds for 4 workgroups per CU
+// (128 VGPRs).  Measured 96 us against 80 us with H in registers at 3 per CU -- kept for reference.
+#ifndef BDSP_CONV_HL2
+#define BDSP_CONV_HL2 0
+#endif
 template <typename T, bool FAST, bool REAL>
-__global__ __launch_bounds__(256, sizeof(T) == 4 ? 3 : 2) void k_overlap_save(
+__global__ __launch_bounds__(256, sizeof(T) == 4 ? (BDSP_CONV_HL2 ? 4 : 3) : 2) void k_overlap_save(
     const void* __restrict__ x_, void* __restrict__ y_, const cpx<T>* __restrict__ hs,
     const cpx<T>* __restrict__ wtab, unsigned n, int m_taps, long long in_off, long long out_off,
     unsigned blocks_per_vec, unsigned out_limit, int store_all)
@@ -76,14 +81,17 @@ __global__ __launch_bounds__(256, sizeof(T) == 4 ? 3 : 2) void k_overlap_save(
     const T hscale = (T)1 / (T)L; // the inverse transform below is unnormalised
     auto tw = [&](int mm) { return wtab[mm]; };
 
-    cpx<T> tw3a[FAST ? 3 : 1], tw3b[FAST ? 3 : 1], hreg[FAST ? 16 : 1];
+    constexpr bool HREG = FAST && !BDSP_CONV_HL2;
+    cpx<T> tw3a[FAST ? 3 : 1], tw3b[FAST ? 3 : 1], hreg[HREG ? 16 : 1];
     cpx<T>* tw2l = lds + F::LDS_ELEMS;
     if constexpr (FAST) {
         F::template load_twiddles16_split<256>(tw3a, tw3b, t, tw);
+        if constexpr (HREG) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            cpx<T> hv = hs[ut + 256u * r];
-            hreg[r] = cpx<T>{hv.x * hscale, hv.y * hscale};
+            for (int r = 0; r < 16; ++r) {
+                cpx<T> hv = hs[ut + 256u * r];
+                hreg[r] = cpx<T>{hv.x * hscale, hv.y * hscale};
+            }
         }
     }
     // stage-2 twiddles (16 distinct rows of 15) in LDS for both builds
@@ -162,7 +170,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 4 ? 3 : 2) void k_overlap_save(
     auto process = [&](cpx<T> (&v)[16], unsigned b) {
         const cpx<T>* hp = hs + t;
         const cpx<T>* wt = wtab;
-        if constexpr (!FAST) {
+        if constexpr (!HREG) {
             // keep the spectrum / twiddle loads inside the loop (hoisted they would pin > 150 VGPRs)
             asm volatile("" : "+v"(hp));
             asm volatile("" : "+s"(wt));
@@ -186,7 +194,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 4 ? 3 : 2) void k_overlap_save(
         // ---- spectrum product
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            if constexpr (FAST) v[r] = cmul(v[r], hreg[r]);
+            if constexpr (HREG) v[r] = cmul(v[r], hreg[r]);
             else {
                 cpx<T> hv = hp[256 * r];
                 v[r] = cmul(v[r], cpx<T>{hv.x * hscale, hv.y * hscale});
@@ -355,7 +363,7 @@ int conv_run_blocks(const T* in, T* out, size_t points, size_t batch, const T* h
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     // persistent-ish grid: enough workgroups to fill every CU at the occupancy LDS/VGPRs allow,
     // each walking blocks with a grid stride so the register-resident twiddles are loaded once
-    int per_cu = sizeof(T) == 4 ? 3 : 2;
+    int per_cu = sizeof(T) == 4 ? (BDSP_CONV_HL2 ? 4 : 3) : 2;
     long long want = (long long)num_cus() * per_cu;
     long long gx = (want + (long long)batch - 1) / (long long)batch;
     if (gx > per_vec) gx = per_vec;
