@@ -831,3 +831,39 @@ def test_hip_graph_capture_and_replay():
     lib.bdsp_hip_synchronize(None)
     t_graph = (time.perf_counter() - t0) / 100
     print("12-kernel chain: %.1f us direct, %.1f us as a graph" % (t_direct * 1e6, t_graph * 1e6))
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_empty_and_tiny_vectors_through_every_operation(dtype):
+    # the reference's tests run every operation on empty and 1..3-point vectors too (tests/tools/mod.rs);
+    # nothing may crash, lengths and metadata must stay consistent
+    ops = [
+        ("scale", (2.0,)), ("offset", (1.0,)), ("conj", ()), ("magnitude", ()), ("magnitude_squared", ()),
+        ("to_real", ()), ("to_imag", ()), ("phase", ()), ("reverse", ()), ("swap_halves", ()), ("fft_shift", ()),
+        ("ifft_shift", ()), ("mirror", ()), ("apply_window", (V.WINDOW_HAMMING,)), ("plain_fft", ()), ("fft", ()),
+        ("windowed_fft", (V.WINDOW_HANN,)), ("zero_interleave", (3,)), ("zero_pad", (7, V.PAD_CENTER)),
+        ("interpolatef", (V.CONV_SINC, 2.0, 0.0, 4)), ("interpolatei", (V.CONV_SINC, 2)),
+        ("decimatei", (2, 0)), ("multiply_complex_exponential", (0.5, 0.25)),
+        ("convolve", (V.CONV_SINC, 0.5, 3)), ("prepare_argument", ()),
+    ]
+    for cplx in (True, False):
+        e = 2 if cplx else 1
+        for points in (0, 1, 2, 3):
+            x = orc.fill_uniform(points * e, 9, -1, 1, dtype)
+            for name, args in ops:
+                v = DspVec(x, is_complex=cplx) if points else DspVec(is_complex=cplx, dtype=dtype, length=0)
+                code = getattr(v, name)(*args)
+                assert isinstance(code, int) and code > -100, (name, cplx, points, code)
+                d = v.data()
+                assert d.size == len(v) and np.all(np.isfinite(d) | np.isnan(d))
+            # frequency-domain entry points
+            for name, args in (("plain_ifft", ()), ("ifft", ()), ("multiply_frequency_response", (V.CONV_SINC, 1.0)),
+                               ("plain_sifft", ())):
+                v = DspVec(x, is_complex=True, domain=V.FREQ) if points and cplx else \
+                    DspVec(is_complex=True, dtype=dtype, length=0, domain=V.FREQ)
+                code = getattr(v, name)(*args)
+                assert isinstance(code, int) and code > -100, (name, points, code)
+            # binary operations and convolution with tiny operands
+            a = DspVec(x, is_complex=cplx) if points else DspVec(is_complex=cplx, dtype=dtype, length=0)
+            b = DspVec(x, is_complex=cplx) if points else DspVec(is_complex=cplx, dtype=dtype, length=0)
+            assert a.mul(b) > -100 and a.convolve_signal(b) > -100 and len(a) == points * e
