@@ -36,15 +36,16 @@ template size_t interpolatef_new_len<double>(size_t, double);
 template <typename T>
 __global__ void k_interp_taps(T* __restrict__ taps, int fid, T rolloff, int conv_len, int factor, T delay)
 {
-    int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= factor) return;
-    int ntaps = 2 * conv_len + 1;
+    // one thread per tap; each repeats the reference's own accumulation j = j + 1 up to its index, so the
+    // arguments are bit-identical to the sequential loop (the serial version took 9-14 us for 100 taps)
+    const int ntaps = 2 * conv_len + 1;
+    const int id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= factor * ntaps) return;
+    const int s = id / ntaps, m = id % ntaps;
     T offset = (T)s / (T)factor;
     T j = -((T)conv_len - (T)1) + delay;
-    for (int m = 0; m < ntaps; ++m) {
-        taps[s * ntaps + m] = conv_time_value<T>(fid, rolloff, j - offset);
-        j = j + (T)1;
-    }
+    for (int k = 0; k < m; ++k) j = j + (T)1;
+    taps[id] = conv_time_value<T>(fid, rolloff, j - offset);
 }
 
 template <typename T, bool CPLX>
@@ -105,60 +106,95 @@ __global__ __launch_bounds__(256) void k_interp_table(const T* __restrict__ x, T
 // and measured 14 % of the HBM roofline on config C4).  Results cross threads through LDS so the
 // stores are contiguous.  The workgroup covers q in [q0, q0+256) of the inner region
 // [q_lo, q_hi) = positions whose FACTOR outputs are all inner outputs.
-template <typename T, bool CPLX, int FACTOR>
+// QB consecutive positions per thread: a tap read from LDS (a broadcast, but still an LDS instruction) then
+// feeds QB * FACTOR multiply-adds instead of FACTOR -- with one position per thread the kernel was bound
+// by LDS instruction issue (39 LDS reads per output point; *measured* 98 us for config C4b).
+template <typename T, bool CPLX, int FACTOR, int QB>
 __global__ __launch_bounds__(256) void k_interp_inner(const T* __restrict__ x, T* __restrict__ y,
                                                       const T* __restrict__ taps, long long q_lo,
                                                       long long q_hi, int conv_len, long long points)
 {
     constexpr int E = CPLX ? 2 : 1;
+    constexpr int TILE = 256 * QB;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int ntaps = 2 * conv_len + 1;
-    T* lt = reinterpret_cast<T*>(smem_raw);                 // [FACTOR][ntaps]
-    T* lx = lt + ((FACTOR * ntaps + 1) & ~1);               // [256 + 2L + 2][E]
-    T* lo = lx + (256 + 2 * conv_len + 2) * E;              // [256 * FACTOR][E] output staging
+    T* lt = reinterpret_cast<T*>(smem_raw);                 // [ntaps + 1][FACTOR]
+    T* lx = lt + ((FACTOR * (ntaps + 1) + 3) & ~3);         // [TILE + 2L + 2][E]
+    T* lo = lx + ((TILE + 2 * conv_len + 2) * E + 3 & ~3);  // [TILE * FACTOR][E] output staging
     const int t = threadIdx.x;
-    const long long q0 = q_lo + (long long)blockIdx.x * 256;
-    for (int k = t; k < ntaps * FACTOR; k += 256) lt[k] = taps[k];
-    // x[q0 - L - 1 .. q0 + 255 + L]  (always in range: the inner region starts (2L+1) positions in)
-    const int span = 256 + 2 * conv_len + 2;
+    const long long q0 = q_lo + (long long)blockIdx.x * TILE;
+    // tap table re-laid out per step j of the walk below: lt[j*FACTOR + s] is the tap that x[q-L-1+j] carries
+    // into output s (0 where it carries none), so one wide LDS read per step fetches all FACTOR taps:
+    //   s = 0: m = 2L - j (j <= 2L)          s > 0: m = 2L + 1 - j (j >= 1), tap vector f - s
+    for (int k = t; k < (ntaps + 1) * FACTOR; k += 256) {
+        const int j = k / FACTOR, sidx = k % FACTOR;
+        T w = (T)0;
+        if (sidx == 0) { if (j <= 2 * conv_len) w = taps[2 * conv_len - j]; }
+        else if (j >= 1) w = taps[(FACTOR - sidx) * ntaps + 2 * conv_len + 1 - j];
+        lt[k] = w;
+    }
+    // x[q0 - L - 1 .. q0 + TILE - 1 + L]  (always in range below: the inner region starts (2L+1) positions in)
+    const int span = TILE + 2 * conv_len + 2;
     const long long xbase = q0 - conv_len - 1;
     for (int k = t; k < span * E; k += 256) {
         long long g = xbase * E + k;
         lx[k] = g < points * E ? x[g] : (T)0; // the last workgroup's tile may overhang the vector
     }
     __syncthreads();
-    T ar[FACTOR], ai[FACTOR];
+    T ar[QB][FACTOR], ai[QB][FACTOR];
 #pragma unroll
-    for (int s = 0; s < FACTOR; ++s) { ar[s] = 0; ai[s] = 0; }
-    // local index of x[n] in lx: n - xbase = (q - q0) + (n - q) + L + 1 = t + j, j = 0 .. 2L+1
+    for (int k = 0; k < QB; ++k)
+#pragma unroll
+        for (int s = 0; s < FACTOR; ++s) { ar[k][s] = 0; ai[k][s] = 0; }
+    // position q = q0 + QB*t + k; local index of x[n] in lx: n - xbase = QB*t + k + j, j = 0 .. 2L+1
+    T wr[QB], wi[QB]; // sliding window x[QB*t + k + j], k = 0..QB-1
+#pragma unroll
+    for (int k = 0; k < QB; ++k) {
+        wr[k] = lx[(QB * t + k) * E];
+        wi[k] = CPLX ? lx[(QB * t + k) * E + 1] : (T)0;
+    }
+#pragma unroll 2
     for (int j = 0; j <= 2 * conv_len + 1; ++j) {
-        T xr = lx[(t + j) * E], xi = CPLX ? lx[(t + j) * E + 1] : (T)0;
-        // n = q - L - 1 + j.  s = 0: m = q+L-1-n = 2L - j (valid for j <= 2L)
-        if (j <= 2 * conv_len) {
-            T w = lt[2 * conv_len - j];
-            ar[0] = ar[0] + xr * w;
-            if (CPLX) ai[0] = ai[0] + xi * w;
-        }
-        // s > 0: m = q+L-n = 2L + 1 - j (valid for j >= 1), tap vector f - s
-        if (j >= 1) {
+        T w[FACTOR];
 #pragma unroll
-            for (int s = 1; s < FACTOR; ++s) {
-                T w = lt[(FACTOR - s) * ntaps + 2 * conv_len + 1 - j];
-                ar[s] = ar[s] + xr * w;
-                if (CPLX) ai[s] = ai[s] + xi * w;
+        for (int s = 0; s < FACTOR; ++s) w[s] = lt[j * FACTOR + s];
+#pragma unroll
+        for (int s = 0; s < FACTOR; ++s)
+#pragma unroll
+            for (int k = 0; k < QB; ++k) {
+                ar[k][s] = ar[k][s] + wr[k] * w[s];
+                if (CPLX) ai[k][s] = ai[k][s] + wi[k] * w[s];
             }
+        // slide the window by one sample
+#pragma unroll
+        for (int k = 0; k + 1 < QB; ++k) { wr[k] = wr[k + 1]; wi[k] = wi[k + 1]; }
+        const int nx = (QB * t + QB + j) * E; // < span*E for every j <= 2L+1 except the last step's read
+        if (j <= 2 * conv_len) {
+            wr[QB - 1] = lx[nx];
+            wi[QB - 1] = CPLX ? lx[nx + 1] : (T)0;
         }
     }
 #pragma unroll
-    for (int s = 0; s < FACTOR; ++s) {
-        lo[(t * FACTOR + s) * E] = ar[s];
-        if (CPLX) lo[(t * FACTOR + s) * E + 1] = ai[s];
-    }
+    for (int k = 0; k < QB; ++k)
+#pragma unroll
+        for (int s = 0; s < FACTOR; ++s) {
+            lo[((QB * t + k) * FACTOR + s) * E] = ar[k][s];
+            if (CPLX) lo[((QB * t + k) * FACTOR + s) * E + 1] = ai[k][s];
+        }
     __syncthreads();
     long long nq = q_hi - q0;
-    if (nq > 256) nq = 256;
+    if (nq > TILE) nq = TILE;
     const long long out0 = q0 * FACTOR * E, nout = nq * FACTOR * E;
-    for (long long k = t; k < nout; k += 256) y[out0 + k] = lo[k];
+    constexpr int VN = 16 / sizeof(T); // scalars per 16-byte packet
+    if constexpr ((FACTOR * E) % VN == 0) {
+        // every position contributes whole 16-byte packets and out0 is a multiple of FACTOR*E scalars
+        typedef T vecT __attribute__((ext_vector_type(VN)));
+        const vecT* lov = reinterpret_cast<const vecT*>(lo);
+        vecT* yv = reinterpret_cast<vecT*>(y + out0);
+        for (long long k = t; k < nout / VN; k += 256) yv[k] = lov[k];
+    } else {
+        for (long long k = t; k < nout; k += 256) y[out0 + k] = lo[k];
+    }
 }
 
 template <typename T, bool CPLX>
@@ -213,7 +249,7 @@ int interpolatef_dev(const T* in, T* out, size_t len, bool is_complex, int fid, 
         int ntaps = 2 * (int)conv_len + 1;
         WsBlock tb;
         BDSP_TRY(tb.alloc(sizeof(T) * (size_t)ntaps * f, s));
-        hipLaunchKernelGGL((k_interp_taps<T>), dim3((f + 63) / 64), dim3(64), 0, s, tb.as<T>(), fid,
+        hipLaunchKernelGGL((k_interp_taps<T>), dim3((f * ntaps + 63) / 64), dim3(64), 0, s, tb.as<T>(), fid,
                            rolloff, (int)conv_len, f, delay);
         BDSP_LAUNCH_CHECK();
         size_t lds = sizeof(T) * (size_t)ntaps * f;
@@ -238,18 +274,26 @@ int interpolatef_dev(const T* in, T* out, size_t len, bool is_complex, int fid, 
         if (blocked) {
             BDSP_LAUNCH_CHECK();
             const int e = is_complex ? 2 : 1;
-            size_t lds2 = sizeof(T) * (((size_t)f * ntaps + 1) / 2 * 2 + (256 + 2 * conv_len + 2) * e + 256 * (size_t)f * e);
-            unsigned g = (unsigned)((q_hi - q_lo + 255) / 256);
+            // positions per thread: as many as keep the output staging buffer at 32 KB
+            constexpr int QB = 1;
+            const int qb = is_complex ? QB : (sizeof(T) == 4 ? 4 : 1);
+            const size_t tile = 256 * (size_t)qb;
+            size_t lds2 = sizeof(T) * ((((size_t)f * (ntaps + 1) + 3) & ~(size_t)3) + (((tile + 2 * conv_len + 2) * e + 3) & ~(size_t)3) + tile * (size_t)f * e);
+            unsigned g = (unsigned)((q_hi - q_lo + (long long)tile - 1) / (long long)tile);
+#define BDSP_INNER2(FV, CP, QV)                                                                    \
+    do {                                                                                           \
+        auto kk = k_interp_inner<T, CP, FV, QV>;                                                   \
+        if (lds2 > 64 * 1024)                                                                      \
+            BDSP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2)); \
+        hipLaunchKernelGGL(kk, dim3(g), dim3(256), lds2, s, in, out, tb.as<T>(), q_lo, q_hi, (int)conv_len, (long long)points); \
+    } while (0)
 #define BDSP_INNER(FV)                                                                             \
     do {                                                                                           \
-        if (is_complex)                                                                            \
-            hipLaunchKernelGGL((k_interp_inner<T, true, FV>), dim3(g), dim3(256), lds2, s, in, out, \
-                               tb.as<T>(), q_lo, q_hi, (int)conv_len, (long long)points);          \
-        else                                                                                       \
-            hipLaunchKernelGGL((k_interp_inner<T, false, FV>), dim3(g), dim3(256), lds2, s, in, out, \
-                               tb.as<T>(), q_lo, q_hi, (int)conv_len, (long long)points);          \
+        if (is_complex) BDSP_INNER2(FV, true, QB);                                                 \
+        else BDSP_INNER2(FV, false, (sizeof(T) == 4 ? 4 : 1));                                     \
     } while (0)
             if (f == 2) BDSP_INNER(2); else if (f == 3) BDSP_INNER(3); else if (f == 4) BDSP_INNER(4); else BDSP_INNER(8);
+#undef BDSP_INNER2
 #undef BDSP_INNER
         }
     } else {
