@@ -79,6 +79,10 @@ def test_fft_16m_bins_parseval_roundtrip():
         ph = (idx * k) % n
         ref = np.sum(xc * np.exp(-2j * np.pi * ph / n))
         assert abs(X[k] - ref) / scale < 2e-6, k
+    # the whole spectrum against the f64 oracle transform (north_star tolerance 1e-6 rel-L2)
+    ref = orc.fft(x.astype(np.float64))
+    assert rel_l2(X.view(np.float64), ref) < 1e-6
+    del ref
     # Parseval
     e_t, e_f = np.sum(np.abs(xc) ** 2), np.sum(np.abs(X) ** 2) / n
     assert abs(e_f - e_t) / e_t < 1e-6
