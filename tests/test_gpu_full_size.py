@@ -45,6 +45,11 @@ def test_c3_convolution_16m_windows_and_identities():
     for first in (0, 3072 - 8, 5_000_000, 11_184_810, n - 4096):
         ref = orc.convolve_direct(x64, h64, True, first, 4096)
         assert rel_l2(y[2 * first:2 * (first + 4096)], ref) < 1e-6, first
+    # (i') the whole vector against the oracle's own overlap-save schedule in f64 (the tail-free variant;
+    # the oracle tests pin it to the direct form and to the reference's schedule on small sizes)
+    code, ref = orc.overlap_discard(x64, h64, orc.next_power_of_two(m), fair=True)
+    assert code == 0 and rel_l2(y, ref) < 1e-6
+    del ref
     # (ii) linearity on the full vector: conv(2.5 x + z) == 2.5 conv(x) + conv(z)
     z = orc.fill_uniform(2 * n, SEED_C3_X + 7, -10, 10, np.float32)
     vz = DspVec(z, is_complex=True)
