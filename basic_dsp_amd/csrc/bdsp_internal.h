@@ -119,6 +119,7 @@ template <typename T> int ew_linear_phase(T* x, size_t len, T delay, hipStream_t
 
 // reorg.hip
 template <typename T> int rg_rotate(const T* in, T* out, size_t points, size_t elem, size_t shift, hipStream_t s);
+template <typename T> int rg_wrap_copy(const T* in, T* out, size_t points, size_t elem, size_t total, long long start, hipStream_t s);
 template <typename T> int rg_reverse(const T* in, T* out, size_t points, size_t elem, hipStream_t s);
 template <typename T> int rg_zero_pad(const T* in, T* out, size_t len_before, bool is_complex, size_t points, int option, hipStream_t s);
 template <typename T> int rg_zero_interleave(const T* in, T* out, size_t len, size_t elem, size_t factor, hipStream_t s);

@@ -187,6 +187,54 @@ int b1_fft(int is_complex, T* signal, size_t len, int inverse)
     return BDSP_OK;
 }
 
+// Long filters (more than 1025 taps): overlap-save with blocks of L = next_pow2(4 (M-1)) points -- the
+// reference's own block length rule (convolution.rs:296-302) -- on the batched multi-pass FFT:
+//   circular extension of the signal -> FFT_L of the overlapping windows (row stride V = L-(M-1)) ->
+//   x H / L -> IFFT_L -> valid parts to the output,     O(N log L) instead of the direct form's O(N M).
+// The windows of one chunk (at most ~1 GiB of spectra) are transformed together.
+template <typename T>
+int conv_long_dev(const T* in, T* out, size_t points, const T* taps, size_t ntaps, hipStream_t s)
+{
+    size_t L = 8192;
+    while (L < 4 * (ntaps - 1)) L <<= 1;
+    const size_t ov = ntaps - 1, V = L - ov;
+    const size_t nb_total = (points + V - 1) / V;
+    size_t nb_chunk = (size_t(1) << 27) / L; // 2^27 complex points of spectra per chunk
+    if (nb_chunk < 1) nb_chunk = 1;
+    if (nb_chunk > nb_total) nb_chunk = nb_total;
+    WsBlock hb, hs2, xe, z1, z2;
+    BDSP_TRY(hb.alloc(sizeof(T) * 2 * L, s));
+    BDSP_TRY(hs2.alloc(sizeof(T) * 2 * L, s));
+    BDSP_TRY(xe.alloc(sizeof(T) * 2 * ((nb_chunk - 1) * V + L), s));
+    BDSP_TRY(z1.alloc(sizeof(T) * 2 * L * nb_chunk, s));
+    BDSP_TRY(z2.alloc(sizeof(T) * 2 * L * nb_chunk, s));
+    // H = FFT_L(zero-padded taps)
+    BDSP_HIP_TRY(hipMemsetAsync(hb.p, 0, sizeof(T) * 2 * L, s));
+    BDSP_HIP_TRY(hipMemcpyAsync(hb.p, taps, sizeof(T) * 2 * ntaps, hipMemcpyDeviceToDevice, s));
+    bool rh = false;
+    BDSP_TRY(fft_two_buffers<T>(hb.as<T>(), hs2.as<T>(), L, 1, false, 0, (T)1, -1, (T)0, &rh, s));
+    const T* H = rh ? hs2.as<T>() : hb.as<T>();
+    for (size_t b0 = 0; b0 < nb_total; b0 += nb_chunk) {
+        const size_t nb = nb_total - b0 < nb_chunk ? nb_total - b0 : nb_chunk;
+        // block b reads x[(b V - floor(M/2) + i) mod N], i < L, and yields outputs b V .. b V + V - 1
+        BDSP_TRY(rg_wrap_copy<T>(in, xe.as<T>(), points, 2, (nb - 1) * V + L,
+                                 (long long)(b0 * V) - (long long)(ntaps / 2), s));
+        FftIo<T> io{};
+        io.n = L; io.in = xe.p; io.in_stride = V; io.out_stride = L; io.flags = 0;
+        io.in_scale = (T)1; io.window_id = -1; io.window_alpha = (T)0;
+        bool r1 = false;
+        if (L <= (size_t(1) << 20)) { io.out = z1.p; BDSP_TRY(fft_pow2<T>(io, z2.as<T>(), nullptr, nb, false, s)); }
+        else { io.out = z2.p; r1 = true; BDSP_TRY(fft_pow2<T>(io, z2.as<T>(), z1.as<T>(), nb, false, s)); }
+        T* spec = r1 ? z2.as<T>() : z1.as<T>();
+        T* scr = r1 ? z1.as<T>() : z2.as<T>();
+        BDSP_TRY(mul_bcast<T>(spec, H, L, nb, (T)1 / (T)L, s));
+        bool r2 = false;
+        BDSP_TRY(fft_two_buffers<T>(spec, scr, L, nb, true, 0, (T)1, -1, (T)0, &r2, s));
+        BDSP_TRY(scatter_valid<T>(r2 ? scr : spec, out, L, ov, V, b0 * V, nb, points, s));
+    }
+    return BDSP_OK;
+}
+
 // complex convolution of device vectors; picks the block kernel whenever it applies
 template <typename T>
 int conv_complex_dev(const T* in, T* out, size_t points, size_t batch, const T* taps, size_t ntaps,
@@ -195,6 +243,11 @@ int conv_complex_dev(const T* in, T* out, size_t points, size_t batch, const T* 
     if (ntaps >= 1 && ntaps - 1 <= 1024 && ntaps <= points && points >= 1)
         return convolve_overlap_save<T>(in, out, points, batch, taps, ntaps, -(long long)(ntaps / 2), 0, 0,
                                         nullptr, nullptr, s);
+    if (ntaps > 1025 && ntaps <= points && 4 * (ntaps - 1) <= (size_t(1) << 24)) {
+        for (size_t v = 0; v < batch; ++v)
+            BDSP_TRY(conv_long_dev<T>(in + 2 * points * v, out + 2 * points * v, points, taps, ntaps, s));
+        return BDSP_OK;
+    }
     return convolve_direct<T>(in, out, points, batch, taps, ntaps, true, s);
 }
 
@@ -202,6 +255,17 @@ int conv_complex_dev(const T* in, T* out, size_t points, size_t batch, const T* 
 template <typename T>
 int conv_real_dev(const T* in, T* out, size_t points, const T* taps, size_t ntaps, hipStream_t s, size_t batch = 1)
 {
+    if (ntaps > 1025 && ntaps <= points && 4 * (ntaps - 1) <= (size_t(1) << 24)) {
+        // long real filters: complexify, run the long-filter path, keep the real parts
+        WsBlock xc, yc, hc2;
+        BDSP_TRY(xc.alloc(sizeof(T) * 2 * points * batch, s));
+        BDSP_TRY(yc.alloc(sizeof(T) * 2 * points * batch, s));
+        BDSP_TRY(hc2.alloc(sizeof(T) * 2 * ntaps, s));
+        BDSP_TRY(rg_zero_interleave<T>(in, xc.as<T>(), points * batch, 1, 2, s));
+        BDSP_TRY(rg_zero_interleave<T>(taps, hc2.as<T>(), ntaps, 1, 2, s));
+        BDSP_TRY(conv_complex_dev<T>(xc.as<T>(), yc.as<T>(), points, batch, hc2.as<T>(), ntaps, s));
+        return ew_complex_to_real<T>(yc.as<T>(), out, 2 * points * batch, 2, s);
+    }
     if (!(ntaps >= 1 && ntaps - 1 <= 1024 && ntaps <= points))
         return convolve_direct<T>(in, out, points, batch, taps, ntaps, false, s);
     WsBlock hc, hsb;

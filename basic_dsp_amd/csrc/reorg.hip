@@ -106,6 +106,27 @@ template <typename T> int rg_decimate(const T* in, T* out, size_t out_points, si
     return BDSP_OK;
 }
 
+// out[i] = in[(start + i) mod points], i < total (total may exceed points): the circular extension the
+// long-filter overlap-save path transforms its overlapping windows from
+template <typename T>
+__global__ __launch_bounds__(256) void k_wrap_copy(const T* __restrict__ in, T* __restrict__ out, size_t points,
+                                                    size_t elem, size_t total, size_t start)
+{
+    for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < total * elem;
+         g += (size_t)gridDim.x * blockDim.x) {
+        size_t i = g / elem, e = g % elem;
+        out[g] = in[((start + i) % points) * elem + e];
+    }
+}
+template <typename T> int rg_wrap_copy(const T* in, T* out, size_t points, size_t elem, size_t total, long long start, hipStream_t s)
+{
+    if (points == 0 || total == 0) return BDSP_OK;
+    long long st = start % (long long)points;
+    if (st < 0) st += (long long)points;
+    hipLaunchKernelGGL((k_wrap_copy<T>), dim3(rg_grid(total * elem)), dim3(256), 0, s, in, out, points, elem, total, (size_t)st);
+    BDSP_LAUNCH_CHECK();
+    return BDSP_OK;
+}
 template <typename T> int rg_rotate(const T* in, T* out, size_t points, size_t elem, size_t shift, hipStream_t s)
 {
     if (points == 0) return BDSP_OK;
@@ -158,6 +179,7 @@ template <typename T> int rg_mirror(const T* in, T* out, size_t len, hipStream_t
 
 #define BDSP_INST(T)                                                                               \
     template int rg_rotate<T>(const T*, T*, size_t, size_t, size_t, hipStream_t);                  \
+    template int rg_wrap_copy<T>(const T*, T*, size_t, size_t, size_t, long long, hipStream_t);    \
     template int rg_reverse<T>(const T*, T*, size_t, size_t, hipStream_t);                         \
     template int rg_zero_pad<T>(const T*, T*, size_t, bool, size_t, int, hipStream_t);             \
     template int rg_zero_interleave<T>(const T*, T*, size_t, size_t, size_t, hipStream_t);         \

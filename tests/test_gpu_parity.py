@@ -867,3 +867,29 @@ def test_empty_and_tiny_vectors_through_every_operation(dtype):
             a = DspVec(x, is_complex=cplx) if points else DspVec(is_complex=cplx, dtype=dtype, length=0)
             b = DspVec(x, is_complex=cplx) if points else DspVec(is_complex=cplx, dtype=dtype, length=0)
             assert a.mul(b) > -100 and a.convolve_signal(b) > -100 and len(a) == points * e
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_convolve_signal_long_filters(dtype):
+    # more than 1025 taps: overlap-save with L = next_pow2(4 (M-1)) on the batched FFT (the reference's
+    # overlap_discard takes any imp_len, convolution.rs:292-462)
+    tol = 2e-6 if dtype == np.float32 else 1e-11
+    for cplx, n, m in ((True, 200000, 1026), (True, 200000, 5000), (True, 300000, 65537), (False, 150000, 3000),
+                       (True, 40000, 40000)):
+        e = 2 if cplx else 1
+        x = orc.fill_uniform(n * e, 77 + m, -10, 10, dtype)
+        h = orc.fill_uniform(m * e, 78 + m, -1, 1, dtype) / dtype(np.sqrt(m))
+        v = DspVec(x, is_complex=cplx)
+        assert v.convolve_signal(DspVec(h, is_complex=cplx)) == 0
+        got = v.data()
+        x64, h64 = x.astype(np.float64), h.astype(np.float64)
+        xc = x64 if cplx else np.stack([x64, np.zeros_like(x64)], -1).reshape(-1)
+        hc = h64 if cplx else np.stack([h64, np.zeros_like(h64)], -1).reshape(-1)
+        code, ref = orc.overlap_discard(xc, hc, orc.next_power_of_two(m), fair=True)
+        assert code == 0
+        ref = ref if cplx else ref[0::2]
+        assert rel_l2(got, ref) < tol, (cplx, n, m)
+        # and two windows against the direct form (start incl. wrap-around, end)
+        for first in (0, n - 300):
+            d = orc.convolve_direct(x64, h64, cplx, first, 300)
+            assert rel_l2(got[first * e:(first + 300) * e], d) < tol, (cplx, n, m, first)
