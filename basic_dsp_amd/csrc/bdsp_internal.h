@@ -139,6 +139,7 @@ template <typename T> int interpolate_real_dev(const T* in, T* out, size_t len, 
 // bluestein.hip
 template <typename T> int bs_chirp(T* c, size_t n, bool inverse, hipStream_t s);
 template <typename T> int bs_kernel(const T* c, T* b, size_t n, size_t m, hipStream_t s);
+template <typename T> int bs_fused(const T* x, T* y, const T* c, const T* bspec, size_t n, size_t m, size_t batch, hipStream_t s);
 template <typename T>
 int bs_pre(const T* x, T* a, const T* c, size_t n, size_t m, size_t batch, bool in_real, T in_scale, size_t rot,
            int window_id, T alpha, hipStream_t s);

@@ -12,6 +12,7 @@
 // input, magnitude) cost no extra pass here either.
 #include "bdsp_internal.h"
 #include "dsp_funcs.h"
+#include <type_traits>
 
 namespace bdsp {
 
@@ -96,6 +97,118 @@ __global__ __launch_bounds__(256) void k_bs_post(const cpx<T>* __restrict__ conv
     }
 }
 
+// Whole chirp-z transform in ONE workgroup-resident kernel for m <= 4096 (n <= 2048), plain complex I/O:
+//   load x[i] conj(c[i]) (zero padded) -> FFT_m -> x B/m -> IFFT_m -> X[k] = z[k] conj(c[k]), k < n
+// exactly the shape of the fused overlap-save block.  The forward transform leaves the spectrum in the
+// registers the inverse transform's first stage reads (up to a compile-time renaming), so nothing but the
+// four stage exchanges touches LDS.  256/(m/16) transforms per workgroup.
+template <typename T, int M>
+__global__ __launch_bounds__(256) void k_bluestein_wg(const cpx<T>* __restrict__ x, cpx<T>* __restrict__ y,
+                                                      const cpx<T>* __restrict__ c, const cpx<T>* __restrict__ bspec,
+                                                      const cpx<T>* __restrict__ wtab, unsigned n, size_t batch)
+{
+    constexpr int NT = M / 16, B = 256 / NT;
+    using F = WgFft<T, M, NT>;
+    using P = Radix16Plan<M>;
+    constexpr int R2 = P::R2, R3 = P::R3;
+    constexpr int RL = R3 > 1 ? R3 : R2; // radix of the last stage (M >= 256: R2 = 16)
+    constexpr int NSL = M / RL;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int tid = threadIdx.x, col = tid / NT, t = tid % NT;
+    cpx<T>* l = reinterpret_cast<cpx<T>*>(smem_raw) + (size_t)col * (F::LDS_ELEMS + 1);
+    const size_t vec = (size_t)blockIdx.x * B + col;
+    const bool active = vec < batch;
+    auto tw = [&](int mm) { return wtab[mm]; };
+    const T inv_m = (T)1 / (T)M;
+
+    cpx<T> v[16];
+    const cpx<T>* xv = x + vec * (size_t)n;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const unsigned idx = (unsigned)(t + r * NT);
+        cpx<T> a{(T)0, (T)0};
+        if (active && idx < n) {
+            const cpx<T> xx = xv[idx], cc = c[idx];
+            a = cpx<T>{xx.x * cc.x + xx.y * cc.y, xx.y * cc.x - xx.x * cc.y};
+        }
+        v[r] = a;
+    }
+    auto fft3 = [&](auto dir) {
+        constexpr int DIR = decltype(dir)::value;
+        F::template compute<16, 1, DIR>(v, t, tw);
+        F::template scatter<16, 1>(v, t, l);
+        __syncthreads();
+        F::template gather<R2>(v, t, l);
+        F::template compute<R2, 16, DIR>(v, t, tw);
+        if constexpr (R3 > 1) {
+            __syncthreads();
+            F::template scatter<R2, 16>(v, t, l);
+            __syncthreads();
+            F::template gather<R3>(v, t, l);
+            F::template compute<R3, 16 * R2, DIR>(v, t, tw);
+        }
+    };
+    fft3(std::integral_constant<int, -1>{});
+    // register b*RL + r holds spectrum index k = t + b*NT + r*NSL = t + NT*(b + r*(16/RL)); the inverse
+    // transform's first stage wants index t + NT*r' in register r': rename, and multiply by B/m on the way
+    cpx<T> u[16];
+#pragma unroll
+    for (int b = 0; b < 16 / RL; ++b)
+#pragma unroll
+        for (int r = 0; r < RL; ++r) {
+            const int rp = b + r * (16 / RL);
+            const cpx<T> hv = bspec[t + NT * rp];
+            u[rp] = cmul(v[b * RL + r], cpx<T>{hv.x * inv_m, hv.y * inv_m});
+        }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] = u[r];
+    __syncthreads(); // the forward transform's last gather is done
+    fft3(std::integral_constant<int, 1>{});
+    if (!active) return;
+    cpx<T>* yv = y + vec * (size_t)n;
+#pragma unroll
+    for (int b = 0; b < 16 / RL; ++b)
+#pragma unroll
+        for (int r = 0; r < RL; ++r) {
+            const unsigned k = (unsigned)F::template out_index<RL, NSL>(t, b, r);
+            if (k < n) {
+                const cpx<T> z = v[b * RL + r], cc = c[k];
+                yv[k] = cpx<T>{z.x * cc.x + z.y * cc.y, z.y * cc.x - z.x * cc.y};
+            }
+        }
+}
+
+template <typename T, int M>
+static int launch_bs_wg(const T* x, T* y, const T* c, const T* bspec, size_t n, size_t batch, hipStream_t s)
+{
+    const cpx<T>* wtab;
+    BDSP_TRY(twiddle_table<T>(M, &wtab));
+    constexpr int B = 256 / (M / 16);
+    using F = WgFft<T, M, M / 16>;
+    const size_t lds = (size_t)B * (F::LDS_ELEMS + 1) * sizeof(cpx<T>);
+    auto k = k_bluestein_wg<T, M>;
+    if (lds > 64 * 1024)
+        BDSP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k, dim3((unsigned)((batch + B - 1) / B)), dim3(256), lds, s, reinterpret_cast<const cpx<T>*>(x),
+                       reinterpret_cast<cpx<T>*>(y), reinterpret_cast<const cpx<T>*>(c),
+                       reinterpret_cast<const cpx<T>*>(bspec), wtab, (unsigned)n, batch);
+    BDSP_LAUNCH_CHECK();
+    return BDSP_OK;
+}
+
+// x -> y (may alias) for m in {512, 1024, 2048, 4096}; anything else: BDSP_ERR_UNSUPPORTED
+template <typename T>
+int bs_fused(const T* x, T* y, const T* c, const T* bspec, size_t n, size_t m, size_t batch, hipStream_t s)
+{
+    switch (m) {
+    case 512: return launch_bs_wg<T, 512>(x, y, c, bspec, n, batch, s);
+    case 1024: return launch_bs_wg<T, 1024>(x, y, c, bspec, n, batch, s);
+    case 2048: return launch_bs_wg<T, 2048>(x, y, c, bspec, n, batch, s);
+    case 4096: return launch_bs_wg<T, 4096>(x, y, c, bspec, n, batch, s);
+    default: return BDSP_ERR_UNSUPPORTED;
+    }
+}
+
 static inline unsigned bs_grid(size_t items)
 {
     size_t g = (items + 255) / 256, cap = (size_t)num_cus() * 16;
@@ -152,6 +265,7 @@ int bs_post(const T* conv, T* out, const T* c, size_t n, size_t m, size_t batch,
 
 #define BDSP_INST(T)                                                                                          \
     template int bs_chirp<T>(T*, size_t, bool, hipStream_t);                                                  \
+    template int bs_fused<T>(const T*, T*, const T*, const T*, size_t, size_t, size_t, hipStream_t);          \
     template int bs_kernel<T>(const T*, T*, size_t, size_t, hipStream_t);                                     \
     template int bs_pre<T>(const T*, T*, const T*, size_t, size_t, size_t, bool, T, size_t, int, T, hipStream_t); \
     template int bs_post<T>(const T*, T*, const T*, size_t, size_t, size_t, int, size_t, int, T, hipStream_t);

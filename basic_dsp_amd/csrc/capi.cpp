@@ -134,10 +134,13 @@ int fft_any_len(T* a, T* b, size_t n, size_t batch, bool inverse, unsigned flags
     *in_b = false; // the epilogue writes the result back over the (consumed) input buffer
     size_t m = 1;
     while (m < 2 * n - 1) m <<= 1;
+    if (m < 512) m = 512; // the single-kernel path starts at 512-point workgroup transforms
     if (m > (size_t(1) << 30)) { set_last_error("Bluestein length above 2^30"); return BDSP_ERR_UNSUPPORTED; }
     std::lock_guard<std::mutex> lk(g_bs_mu); // plans cannot be evicted between lookup and launch
     const T *chirp = nullptr, *bspec = nullptr;
     BDSP_TRY(bs_plan<T>(n, m, inverse, s, &chirp, &bspec));
+    if (m <= 4096 && flags == 0 && window_id < 0 && in_scale == (T)1 && n >= 2)
+        return bs_fused<T>(a, a, chirp, bspec, n, m, batch, s); // one kernel, in place
     WsBlock wa, wt;
     BDSP_TRY(wa.alloc(sizeof(T) * 2 * m * batch, s));
     BDSP_TRY(wt.alloc(sizeof(T) * 2 * m * batch, s));
