@@ -238,15 +238,20 @@ int conv_long_dev(const T* in, T* out, size_t points, const T* taps, size_t ntap
     return BDSP_OK;
 }
 
+// The fused 4096-point block kernel takes filters of up to FUSED_MAX_TAPS taps: with M-1 discarded points
+// per block its cost grows like 4096/(4096-(M-1)) -- 2x at 2049 taps, 4x at 3073 -- and stays below the
+// generic long-filter path (about 6x the 1024-tap time) up to there.
+constexpr size_t FUSED_MAX_TAPS = 3073;
+
 // complex convolution of device vectors; picks the block kernel whenever it applies
 template <typename T>
 int conv_complex_dev(const T* in, T* out, size_t points, size_t batch, const T* taps, size_t ntaps,
                      hipStream_t s)
 {
-    if (ntaps >= 1 && ntaps - 1 <= 1024 && ntaps <= points && points >= 1)
+    if (ntaps >= 1 && ntaps <= FUSED_MAX_TAPS && ntaps <= points && points >= 1)
         return convolve_overlap_save<T>(in, out, points, batch, taps, ntaps, -(long long)(ntaps / 2), 0, 0,
                                         nullptr, nullptr, s);
-    if (ntaps > 1025 && ntaps <= points && 4 * (ntaps - 1) <= (size_t(1) << 24)) {
+    if (ntaps > FUSED_MAX_TAPS && ntaps <= points && 4 * (ntaps - 1) <= (size_t(1) << 24)) {
         for (size_t v = 0; v < batch; ++v)
             BDSP_TRY(conv_long_dev<T>(in + 2 * points * v, out + 2 * points * v, points, taps, ntaps, s));
         return BDSP_OK;
@@ -258,7 +263,7 @@ int conv_complex_dev(const T* in, T* out, size_t points, size_t batch, const T* 
 template <typename T>
 int conv_real_dev(const T* in, T* out, size_t points, const T* taps, size_t ntaps, hipStream_t s, size_t batch = 1)
 {
-    if (ntaps > 1025 && ntaps <= points && 4 * (ntaps - 1) <= (size_t(1) << 24)) {
+    if (ntaps > FUSED_MAX_TAPS && ntaps <= points && 4 * (ntaps - 1) <= (size_t(1) << 24)) {
         // long real filters: complexify, run the long-filter path, keep the real parts
         WsBlock xc, yc, hc2;
         BDSP_TRY(xc.alloc(sizeof(T) * 2 * points * batch, s));
@@ -269,7 +274,7 @@ int conv_real_dev(const T* in, T* out, size_t points, const T* taps, size_t ntap
         BDSP_TRY(conv_complex_dev<T>(xc.as<T>(), yc.as<T>(), points, batch, hc2.as<T>(), ntaps, s));
         return ew_complex_to_real<T>(yc.as<T>(), out, 2 * points * batch, 2, s);
     }
-    if (!(ntaps >= 1 && ntaps - 1 <= 1024 && ntaps <= points))
+    if (!(ntaps >= 1 && ntaps <= FUSED_MAX_TAPS && ntaps <= points))
         return convolve_direct<T>(in, out, points, batch, taps, ntaps, false, s);
     WsBlock hc, hsb;
     BDSP_TRY(hc.alloc(sizeof(T) * 2 * ntaps, s));

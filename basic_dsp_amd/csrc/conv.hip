@@ -337,7 +337,7 @@ int conv_run_blocks(const T* in, T* out, size_t points, size_t batch, const T* h
                     hipStream_t s, bool real_data)
 {
     constexpr int L = CONV_L;
-    if (taps == 0 || taps - 1 > (size_t)L / 4 || points == 0) {
+    if (taps == 0 || taps - 1 > 3 * (size_t)L / 4 || points == 0) {
         set_last_error("convolve_overlap_save: taps out of range for the block kernel");
         return BDSP_ERR_UNSUPPORTED;
     }

@@ -32,7 +32,7 @@ def timeit(fn):
     ms = C.c_float(0); lib.bdsp_hip_event_elapsed_ms(e0, e1, C.byref(ms))
     return ms.value / a.iters * 1e3
 esz = 8 if a.elem == 0 else 16
-if "conv" in a.what and m > 1025:
+if "conv" in a.what and m > 3073:
     us = timeit(lambda i: bd._lib.check(lib.bdsp_hip_dev_convolve(a.elem, xs[i % 3].data_ptr(), y.data_ptr(), n, b, taps.data_ptr(), m, sp)))
     print("conv  n=%d b=%d m=%d (long-filter path): %.1f us  %.1f Gsamples/s" % (n, b, m, us, n * b / us / 1e3))
 elif "conv" in a.what:
