@@ -268,7 +268,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 4 ? (BDSP_CONV_HL2 ? 4 : 3) : 2) 
     }
 }
 
-// Direct form for everything the block kernel cannot take (taps > 1025, real vectors handled by
+// Direct form for everything the block kernel cannot take (taps longer than the vector, tiny vectors; real vectors are handled by
 // the caller through complexification, tiny vectors): one output per thread, taps streamed from
 // L2, wrap-around by modular indexing.  O(N*M): a correctness net, not a fast path.
 template <typename T, bool CPLX>

@@ -513,7 +513,7 @@ int bdsp_hip_dev_convolve(int elem, const void *in, void *out, size_t points, si
 /* The same convolution split in two, so a caller that reuses one filter (the batch driver, the
  * benchmark) builds its spectrum once: prepare writes bdsp_hip_conv_spectrum_points() complex
  * points (FFT of the zero-padded taps, pre-divided by the block length) to spectrum_dev;
- * convolve_prepared is the single fused overlap-save launch (taps <= 1025). */
+ * convolve_prepared is the single fused overlap-save launch (taps <= 3073). */
 size_t bdsp_hip_conv_spectrum_points(void);
 int bdsp_hip_dev_conv_prepare(int elem, const void *taps_dev, size_t taps, void *spectrum_dev,
                               void *stream);
