@@ -268,9 +268,9 @@ __global__ __launch_bounds__(256, sizeof(T) == 4 ? (BDSP_CONV_HL2 ? 4 : 3) : 2) 
     }
 }
 
-// Direct form for everything the block kernel cannot take (taps longer than the vector, tiny vectors; real vectors are handled by
-// the caller through complexification, tiny vectors): one output per thread, taps streamed from
-// L2, wrap-around by modular indexing.  O(N*M): a correctness net, not a fast path.
+// Direct form for what neither the block kernel nor the long-filter path takes (taps longer than the
+// vector, where the reference uses the centre taps only, time_freq/mod.rs:284-288): one output per
+// thread, taps streamed from L2, wrap-around by modular indexing.  O(N*M): a correctness net.
 template <typename T, bool CPLX>
 __global__ __launch_bounds__(256) void k_conv_direct(const T* __restrict__ x, T* __restrict__ y,
                                                      const T* __restrict__ h, long long n,
