@@ -370,22 +370,33 @@ template <> __device__ __forceinline__ float dev_atan2<float>(float a, float b) 
 template <> __device__ __forceinline__ double dev_atan2<double>(double a, double b) { return atan2(a, b); }
 
 template <typename T>
+__device__ __forceinline__ T c2r_one(cpx<T> z, int kind)
+{
+    switch (kind) {
+    case 0: return dev_hypot2<T>(z.x, z.y);
+    case 1: return z.x * z.x + z.y * z.y;
+    case 2: return z.x;
+    case 3: return z.y;
+    default: return dev_atan2<T>(z.y, z.x);
+    }
+}
+
+// two points per lane: one 2-element load, one 2-scalar store
+template <typename T>
 __global__ __launch_bounds__(256) void k_complex_to_real(const cpx<T>* __restrict__ x, T* __restrict__ out,
                                                           size_t points, int kind)
 {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < points;
+    struct alignas(2 * sizeof(cpx<T>)) C2 { cpx<T> a, b; };
+    struct alignas(2 * sizeof(T)) R2 { T a, b; };
+    const size_t pairs = points / 2;
+    const C2* x2 = reinterpret_cast<const C2*>(x);
+    R2* o2 = reinterpret_cast<R2*>(out);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < pairs;
          i += (size_t)gridDim.x * blockDim.x) {
-        cpx<T> z = x[i];
-        T r;
-        switch (kind) {
-        case 0: r = dev_hypot2<T>(z.x, z.y); break;
-        case 1: r = z.x * z.x + z.y * z.y; break;
-        case 2: r = z.x; break;
-        case 3: r = z.y; break;
-        default: r = dev_atan2<T>(z.y, z.x); break;
-        }
-        out[i] = r;
+        C2 z = x2[i];
+        o2[i] = R2{c2r_one<T>(z.a, kind), c2r_one<T>(z.b, kind)};
     }
+    if ((points & 1) && blockIdx.x == 0 && threadIdx.x == 0) out[points - 1] = c2r_one<T>(x[points - 1], kind);
 }
 
 template <typename T> int ew_complex_to_real(const T* x, T* out, size_t len, int kind, hipStream_t s)
