@@ -33,6 +33,8 @@ struct DeviceCtx {
     std::map<hipStream_t, std::multimap<size_t, void*>> free_blocks;
     std::map<void*, size_t> block_size;
     std::map<std::pair<int, int>, void*> twiddles; // (n, sizeof(T)) -> device table
+    size_t cached_bytes = 0; // sum of the free blocks' capacities
+    size_t cache_limit = 0;  // a quarter of the device memory: beyond it blocks go back to the driver
 };
 
 std::mutex g_mu;
@@ -73,6 +75,7 @@ int ctx_locked(DeviceCtx** out)
             return BDSP_ERR_NO_DEVICE;
         }
         ctx.cus = prop.multiProcessorCount;
+        ctx.cache_limit = (size_t)prop.totalGlobalMem / 4;
         BDSP_HIP_TRY(hipStreamCreateWithFlags(&ctx.stream, hipStreamNonBlocking));
         it = g_ctx.emplace(dev, ctx).first;
     }
@@ -119,6 +122,7 @@ int ws_alloc(void** p, size_t bytes, hipStream_t stream)
     auto it = fl.lower_bound(cap);
     if (it != fl.end() && it->first <= cap + cap / 2 + (1u << 16)) {
         *p = it->second;
+        c->cached_bytes -= it->first;
         fl.erase(it);
         return BDSP_OK;
     }
@@ -134,6 +138,7 @@ int ws_alloc(void** p, size_t bytes, hipStream_t stream)
             }
             kv.second.clear();
         }
+        c->cached_bytes = 0;
         e = hipMalloc(&q, cap);
         if (e != hipSuccess) return hip_fail(e, "hipMalloc(workspace)", __FILE__, __LINE__);
     }
@@ -150,6 +155,14 @@ void ws_free(void* p, hipStream_t stream)
     if (ctx_locked(&c) != BDSP_OK) return;
     auto it = c->block_size.find(p);
     if (it == c->block_size.end()) return;
+    if (c->cache_limit && c->cached_bytes + it->second > c->cache_limit) {
+        // the cache is full: hand the block back (hipFree waits for the device, so work that still uses
+        // the block has finished) instead of letting the cache grow without bound
+        (void)hipFree(p);
+        c->block_size.erase(it);
+        return;
+    }
+    c->cached_bytes += it->second;
     c->free_blocks[stream].emplace(it->second, p);
 }
 
