@@ -71,3 +71,15 @@ def test_host_sim_of_workgroup_fft(tmp_path):
                            os.path.join(ROOT, "tests", "host_sim", "sim_fft.cpp")])
     out = subprocess.run([exe], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout
+
+
+def test_header_is_plain_c_and_a_c_client_links():
+    """include/basic_dsp_hip.h must be consumable by a C compiler (the reference's foreign callers are C
+    and ctypes), and a plain-C client must link against the library without a GPU present."""
+    import subprocess
+    import tempfile
+    src = os.path.join(ROOT, "tests", "c_abi", "facade_demo.c")
+    libdir = os.path.join(ROOT, "basic_dsp_amd", "lib")
+    with tempfile.TemporaryDirectory() as d:
+        subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Werror", "-D_GNU_SOURCE", "-I", os.path.join(ROOT, "include"),
+                               src, "-L", libdir, "-lbasic_dsp_hip", "-lm", "-o", os.path.join(d, "demo")])

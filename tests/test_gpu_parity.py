@@ -4,6 +4,8 @@ compared with the CPU oracle on the same seeded inputs.
 Tolerances (BASELINE.json north_star): bit-exact for index moves and single-rounding elementwise
 ops; rel-L2 <= 1e-6 for f32 FFT/convolution against the f64 oracle; 1e-12 for f64.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -893,3 +895,17 @@ def test_convolve_signal_long_filters(dtype):
         for first in (0, n - 300):
             d = orc.convolve_direct(x64, h64, cplx, first, 300)
             assert rel_l2(got[first * e:(first + 300) * e], d) < tol, (cplx, n, m, first)
+
+
+def test_c_client_of_the_abi(tmp_path):
+    # the boundary is a C ABI: build a plain-C client against include/basic_dsp_hip.h and run it
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "facade_demo")
+    libdir = os.path.join(root, "basic_dsp_amd", "lib")
+    subprocess.check_call(["gcc", "-std=c11", "-O1", "-D_GNU_SOURCE", "-I", os.path.join(root, "include"),
+                           os.path.join(root, "tests", "c_abi", "facade_demo.c"), "-L", libdir,
+                           "-lbasic_dsp_hip", "-lm", "-Wl,-rpath," + libdir, "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "c abi demo ok" in out.stdout
