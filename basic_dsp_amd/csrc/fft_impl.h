@@ -259,6 +259,62 @@ __global__ __launch_bounds__(256) void k_fft_wg_batch(FftIo<T> io, const cpx<T>*
     }
 }
 
+// 8192-point transforms in ONE workgroup (f32, plain I/O): 512 threads x 16 points,
+// four stages 16 x 16 x 16 x 2 (the template also covers 16384 = ... x 4 with 1024 threads), three LDS exchanges -- one trip through HBM (16 B per point) where the
+// two-pass plan makes two, and one launch instead of two for a single transform.  Persistent over the batch;
+// second-stage twiddles in an LDS table, last-stage twiddles in registers, third-stage twiddles from L2.
+template <typename T, int N, int DIR>
+__global__ __launch_bounds__(N / 16) void k_fft_wg4(FftIo<T> io, const cpx<T>* __restrict__ wtab, size_t batch)
+{
+    constexpr int NT = N / 16, R4 = N / 4096, NTW4 = (16 / R4) * (R4 - 1);
+    static_assert(R4 == 2 || R4 == 4, "N in {8192, 16384}");
+    using F = WgFft<T, N, NT>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    cpx<T>* l = reinterpret_cast<cpx<T>*>(smem_raw);
+    cpx<T>* tw2l = l + F::LDS_ELEMS;
+    const int t = threadIdx.x;
+    auto tw = [&](int m) { return wtab[m]; };
+    cpx<T> tw4[NTW4];
+    F::template load_twiddles<R4, 4096>(tw4, t, tw);
+    if (t < 240) {
+        int k = t / 15, r = t % 15 + 1;
+        tw2l[k * 17 + r - 1] = wtab[r * k * (N / 256)];
+    }
+    __syncthreads();
+    const cpx<T>* tw2p = tw2l + (t & 15) * 17;
+    const int nvalid = io.in_valid ? (int)io.in_valid : N;
+    for (size_t vec = blockIdx.x; vec < batch; vec += gridDim.x) {
+        const cpx<T>* in = reinterpret_cast<const cpx<T>*>(io.in) + vec * io.in_stride;
+        cpx<T> v[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int idx = t + r * NT;
+            v[r] = idx < nvalid ? in[idx] : cpx<T>{0, 0};
+        }
+        F::template compute<16, 1, DIR>(v, t, tw);
+        __syncthreads(); // the previous transform's last gather is done
+        F::template scatter<16, 1>(v, t, l);
+        __syncthreads();
+        F::template gather<16>(v, t, l);
+        F::template compute_pre<16, 16, DIR>(v, tw2p);
+        __syncthreads();
+        F::template scatter<16, 16>(v, t, l);
+        __syncthreads();
+        F::template gather<16>(v, t, l);
+        F::template compute<16, 256, DIR>(v, t, tw);
+        __syncthreads();
+        F::template scatter<16, 256>(v, t, l);
+        __syncthreads();
+        F::template gather<R4>(v, t, l);
+        F::template compute_pre<R4, 4096, DIR>(v, tw4);
+        cpx<T>* out = reinterpret_cast<cpx<T>*>(io.out) + vec * io.out_stride;
+#pragma unroll
+        for (int b = 0; b < 16 / R4; ++b)
+#pragma unroll
+            for (int r = 0; r < R4; ++r) out[F::template out_index<R4, N / R4>(t, b, r)] = v[b * R4 + r];
+    }
+}
+
 // ------------------------------------------------------------------------------ n > 4096
 // exp(-2*pi*i*e/n) for an exact integer e < n (n a power of two): the argument 2e/n is exact in
 // float for n <= 2^24 and always exact in double, so the only error is sincospi's own.
@@ -442,6 +498,26 @@ static int set_lds(K kernel, size_t bytes)
 }
 
 template <typename T, int N>
+static int launch_wg4(const FftIo<T>& io, size_t batch, bool inverse, hipStream_t s)
+{
+    const cpx<T>* wtab;
+    BDSP_TRY(twiddle_table<T>(N, &wtab));
+    using F = WgFft<T, N, N / 16>;
+    const size_t lds = (size_t)(F::LDS_ELEMS + 16 * 17) * sizeof(cpx<T>);
+    const size_t slots = (size_t)num_cus() * (N == 8192 ? 2 : 1);
+    const unsigned grid = (unsigned)(batch < slots ? batch : slots);
+    if (inverse) {
+        BDSP_TRY(set_lds(k_fft_wg4<T, N, 1>, lds));
+        hipLaunchKernelGGL((k_fft_wg4<T, N, 1>), dim3(grid), dim3(N / 16), lds, s, io, wtab, batch);
+    } else {
+        BDSP_TRY(set_lds(k_fft_wg4<T, N, -1>, lds));
+        hipLaunchKernelGGL((k_fft_wg4<T, N, -1>), dim3(grid), dim3(N / 16), lds, s, io, wtab, batch);
+    }
+    BDSP_LAUNCH_CHECK();
+    return BDSP_OK;
+}
+
+template <typename T, int N>
 static int launch_wg(const FftIo<T>& io, size_t batch, bool inverse, hipStream_t s)
 {
     const cpx<T>* wtab;
@@ -611,6 +687,13 @@ int fft_pow2(const FftIo<T>& io, T* scratch_a, T* scratch_b, size_t batch, bool 
     case 2048: return launch_wg<T, 2048>(io, batch, inverse, s);
     case 4096: return launch_wg<T, 4096>(io, batch, inverse, s);
     default: break;
+    }
+    if constexpr (sizeof(T) == 4) {
+        // *measured*: 8192 points, batch 2048: 94.8 us as two passes, 73.3 us in one workgroup each (batch 256:
+        // 19.8 -> 13.2 us, a single transform 7.7 vs 7.9 us); the 16384-point instantiation (1024 threads, one
+        // workgroup per CU) measured SLOWER than two passes at every batch size and is not built
+        static const bool no_wg4 = getenv("BDSP_FFT_NO_WG4") != nullptr;
+        if (!no_wg4 && n == 8192 && !io_is_generic(io)) return launch_wg4<T, 8192>(io, batch, inverse, s);
     }
     int rp[3], w[3];
     int passes = plan_passes(n, batch, rp, w);

@@ -32,16 +32,30 @@ def timeit(fn):
     ms = C.c_float(0); lib.bdsp_hip_event_elapsed_ms(e0, e1, C.byref(ms))
     return ms.value / a.iters * 1e3
 esz = 8 if a.elem == 0 else 16
-if "conv" in a.what and m > 3073:
+if "conv" in a.what.split(",") and m > 3073:
     us = timeit(lambda i: bd._lib.check(lib.bdsp_hip_dev_convolve(a.elem, xs[i % 3].data_ptr(), y.data_ptr(), n, b, taps.data_ptr(), m, sp)))
     print("conv  n=%d b=%d m=%d (long-filter path): %.1f us  %.1f Gsamples/s" % (n, b, m, us, n * b / us / 1e3))
-elif "conv" in a.what:
+elif "conv" in a.what.split(","):
     bd._lib.check(lib.bdsp_hip_dev_conv_prepare(a.elem, taps.data_ptr(), m, spec.data_ptr(), sp))
     us = timeit(lambda i: bd._lib.check(lib.bdsp_hip_dev_convolve_prepared(a.elem, xs[i % 3].data_ptr(), y.data_ptr(), n, b, spec.data_ptr(), m, sp)))
     print("conv  n=%d b=%d m=%d: %.1f us  %.1f Gsamples/s  %.0f GB/s algorithmic" % (n, b, m, us, n * b / us / 1e3, 2 * esz * n * b / us / 1e3))
-if "fft" in a.what:
+if "prepconv" in a.what:
+    def f(i):
+        bd._lib.check(lib.bdsp_hip_dev_conv_prepare(a.elem, taps.data_ptr(), m, spec.data_ptr(), sp))
+        bd._lib.check(lib.bdsp_hip_dev_convolve_prepared(a.elem, xs[i % 3].data_ptr(), y.data_ptr(), n, b, spec.data_ptr(), m, sp))
+    us = timeit(f)
+    print("prep+conv n=%d m=%d: %.1f us" % (n, m, us))
+if "convfft" in a.what:
+    scr = torch.empty_like(y)
+    def g(i):
+        bd._lib.check(lib.bdsp_hip_dev_convolve_prepared(a.elem, xs[i % 3].data_ptr(), y.data_ptr(), n, b, spec.data_ptr(), m, sp))
+        bd._lib.check(lib.bdsp_hip_dev_fft(a.elem, y.data_ptr(), scr.data_ptr(), n, b, 0, 1.0, -1, 0.0, C.byref(flag), sp))
+    bd._lib.check(lib.bdsp_hip_dev_conv_prepare(a.elem, taps.data_ptr(), m, spec.data_ptr(), sp))
+    us = timeit(g)
+    print("conv+fft (no prepare) n=%d m=%d: %.1f us" % (n, m, us))
+if "fft" in a.what.split(","):
     us = timeit(lambda i: bd._lib.check(lib.bdsp_hip_dev_fft(a.elem, xs[i % 3].data_ptr(), y.data_ptr(), n, b, 0, 1.0, -1, 0.0, C.byref(flag), sp)))
     print("fft   n=%d b=%d: %.1f us  %.1f Gsamples/s  %.0f GB/s algorithmic" % (n, b, us, n * b / us / 1e3, 2 * esz * n * b / us / 1e3))
-if "prep" in a.what:
+if "prep" in a.what.split(","):
     us = timeit(lambda i: bd._lib.check(lib.bdsp_hip_dev_conv_prepare(a.elem, taps.data_ptr(), m, spec.data_ptr(), sp)))
     print("prep  m=%d: %.1f us" % (m, us))
