@@ -111,71 +111,83 @@ __global__ __launch_bounds__(256) void k_bluestein_wg(const cpx<T>* __restrict__
     using F = WgFft<T, M, NT>;
     using P = Radix16Plan<M>;
     constexpr int R2 = P::R2, R3 = P::R3;
-    constexpr int RL = R3 > 1 ? R3 : R2; // radix of the last stage (M >= 256: R2 = 16)
-    constexpr int NSL = M / RL;
+    static_assert(R2 == 16 && R3 >= 2, "512 <= M <= 4096");
+    constexpr int NSL = M / R3, NTW3 = (16 / R3) * (R3 - 1);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int tid = threadIdx.x, col = tid / NT, t = tid % NT;
     cpx<T>* l = reinterpret_cast<cpx<T>*>(smem_raw) + (size_t)col * (F::LDS_ELEMS + 1);
-    const size_t vec = (size_t)blockIdx.x * B + col;
-    const bool active = vec < batch;
+    cpx<T>* tw2l = reinterpret_cast<cpx<T>*>(smem_raw) + (size_t)B * (F::LDS_ELEMS + 1);
     auto tw = [&](int mm) { return wtab[mm]; };
     const T inv_m = (T)1 / (T)M;
+    // persistent over the batch: last-stage twiddles in registers, second-stage twiddles in an LDS table
+    cpx<T> tw3[NTW3];
+    F::template load_twiddles<R3, 256>(tw3, t, tw);
+    if (tid < 240) {
+        int k = tid / 15, r = tid % 15 + 1;
+        tw2l[k * 17 + r - 1] = wtab[r * k * (M / 256)];
+    }
+    __syncthreads();
+    const cpx<T>* tw2p = tw2l + (t & 15) * 17;
 
     cpx<T> v[16];
-    const cpx<T>* xv = x + vec * (size_t)n;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const unsigned idx = (unsigned)(t + r * NT);
-        cpx<T> a{(T)0, (T)0};
-        if (active && idx < n) {
-            const cpx<T> xx = xv[idx], cc = c[idx];
-            a = cpx<T>{xx.x * cc.x + xx.y * cc.y, xx.y * cc.x - xx.x * cc.y};
-        }
-        v[r] = a;
-    }
     auto fft3 = [&](auto dir) {
         constexpr int DIR = decltype(dir)::value;
         F::template compute<16, 1, DIR>(v, t, tw);
+        __syncthreads(); // the previous exchange's gather is done
         F::template scatter<16, 1>(v, t, l);
         __syncthreads();
-        F::template gather<R2>(v, t, l);
-        F::template compute<R2, 16, DIR>(v, t, tw);
-        if constexpr (R3 > 1) {
-            __syncthreads();
-            F::template scatter<R2, 16>(v, t, l);
-            __syncthreads();
-            F::template gather<R3>(v, t, l);
-            F::template compute<R3, 16 * R2, DIR>(v, t, tw);
-        }
+        F::template gather<16>(v, t, l);
+        F::template compute_pre<16, 16, DIR>(v, tw2p);
+        __syncthreads();
+        F::template scatter<16, 16>(v, t, l);
+        __syncthreads();
+        F::template gather<R3>(v, t, l);
+        F::template compute_pre<R3, 256, DIR>(v, tw3);
     };
-    fft3(std::integral_constant<int, -1>{});
-    // register b*RL + r holds spectrum index k = t + b*NT + r*NSL = t + NT*(b + r*(16/RL)); the inverse
-    // transform's first stage wants index t + NT*r' in register r': rename, and multiply by B/m on the way
-    cpx<T> u[16];
+    const size_t groups = (batch + B - 1) / B;
+    for (size_t gi = blockIdx.x; gi < groups; gi += gridDim.x) {
+        const size_t vec = gi * B + col;
+        const bool active = vec < batch;
+        const cpx<T>* xv = x + vec * (size_t)n;
 #pragma unroll
-    for (int b = 0; b < 16 / RL; ++b)
-#pragma unroll
-        for (int r = 0; r < RL; ++r) {
-            const int rp = b + r * (16 / RL);
-            const cpx<T> hv = bspec[t + NT * rp];
-            u[rp] = cmul(v[b * RL + r], cpx<T>{hv.x * inv_m, hv.y * inv_m});
-        }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) v[r] = u[r];
-    __syncthreads(); // the forward transform's last gather is done
-    fft3(std::integral_constant<int, 1>{});
-    if (!active) return;
-    cpx<T>* yv = y + vec * (size_t)n;
-#pragma unroll
-    for (int b = 0; b < 16 / RL; ++b)
-#pragma unroll
-        for (int r = 0; r < RL; ++r) {
-            const unsigned k = (unsigned)F::template out_index<RL, NSL>(t, b, r);
-            if (k < n) {
-                const cpx<T> z = v[b * RL + r], cc = c[k];
-                yv[k] = cpx<T>{z.x * cc.x + z.y * cc.y, z.y * cc.x - z.x * cc.y};
+        for (int r = 0; r < 16; ++r) {
+            const unsigned idx = (unsigned)(t + r * NT);
+            cpx<T> a{(T)0, (T)0};
+            if (active && idx < n) {
+                const cpx<T> xx = xv[idx], cc = c[idx];
+                a = cpx<T>{xx.x * cc.x + xx.y * cc.y, xx.y * cc.x - xx.x * cc.y};
             }
+            v[r] = a;
         }
+        fft3(std::integral_constant<int, -1>{});
+        // register b*R3 + r holds spectrum index k = t + b*NT + r*NSL = t + NT*(b + r*(16/R3)); the inverse
+        // transform's first stage wants index t + NT*r' in register r': rename, and multiply by B/m on the way
+        cpx<T> u[16];
+#pragma unroll
+        for (int b = 0; b < 16 / R3; ++b)
+#pragma unroll
+            for (int r = 0; r < R3; ++r) {
+                const int rp = b + r * (16 / R3);
+                const cpx<T> hv = bspec[t + NT * rp];
+                u[rp] = cmul(v[b * R3 + r], cpx<T>{hv.x * inv_m, hv.y * inv_m});
+            }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = u[r];
+        fft3(std::integral_constant<int, 1>{});
+        if (active) {
+            cpx<T>* yv = y + vec * (size_t)n;
+#pragma unroll
+            for (int b = 0; b < 16 / R3; ++b)
+#pragma unroll
+                for (int r = 0; r < R3; ++r) {
+                    const unsigned k = (unsigned)F::template out_index<R3, NSL>(t, b, r);
+                    if (k < n) {
+                        const cpx<T> z = v[b * R3 + r], cc = c[k];
+                        yv[k] = cpx<T>{z.x * cc.x + z.y * cc.y, z.y * cc.x - z.x * cc.y};
+                    }
+                }
+        }
+    }
 }
 
 template <typename T, int M>
@@ -185,11 +197,12 @@ static int launch_bs_wg(const T* x, T* y, const T* c, const T* bspec, size_t n, 
     BDSP_TRY(twiddle_table<T>(M, &wtab));
     constexpr int B = 256 / (M / 16);
     using F = WgFft<T, M, M / 16>;
-    const size_t lds = (size_t)B * (F::LDS_ELEMS + 1) * sizeof(cpx<T>);
+    const size_t lds = ((size_t)B * (F::LDS_ELEMS + 1) + 16 * 17) * sizeof(cpx<T>);
     auto k = k_bluestein_wg<T, M>;
     if (lds > 64 * 1024)
         BDSP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k, dim3((unsigned)((batch + B - 1) / B)), dim3(256), lds, s, reinterpret_cast<const cpx<T>*>(x),
+    size_t groups = (batch + B - 1) / B, slots = (size_t)num_cus() * 4;
+    hipLaunchKernelGGL(k, dim3((unsigned)(groups < slots ? groups : slots)), dim3(256), lds, s, reinterpret_cast<const cpx<T>*>(x),
                        reinterpret_cast<cpx<T>*>(y), reinterpret_cast<const cpx<T>*>(c),
                        reinterpret_cast<const cpx<T>*>(bspec), wtab, (unsigned)n, batch);
     BDSP_LAUNCH_CHECK();
