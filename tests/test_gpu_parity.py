@@ -909,3 +909,24 @@ def test_c_client_of_the_abi(tmp_path):
     out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "c abi demo ok" in out.stdout
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("n,rows", [(1024, 17000), (2048, 8300), (4096, 4200), (8192, 600), (1000, 3000)])
+def test_large_batches_take_the_persistent_kernels(n, rows, dtype):
+    # many rows: k_fft_wg_batch (n = 1024..4096), k_fft_wg4 (8192, f32), the fused Bluestein kernel (1000);
+    # every row is checked against numpy's f64 transform
+    from basic_dsp_amd import DspMat
+    if dtype == np.float64 and rows * n > 20_000_000:
+        rows //= 2
+    rng = np.random.default_rng(n + rows)
+    a = (rng.standard_normal((rows, 2 * n)) * 3).astype(dtype)
+    m = DspMat(a, is_complex=True)
+    assert m.plain_fft() == 0
+    got = m.data().astype(np.float64).view(np.complex128)
+    ref = np.fft.fft(a.astype(np.float64).view(np.complex128), axis=1)
+    err = np.linalg.norm(got - ref, axis=1) / np.linalg.norm(ref, axis=1)
+    assert err.max() < (2e-6 if dtype == np.float32 else 1e-12), (n, rows, float(err.max()), int(err.argmax()))
+    assert m.plain_ifft() == 0
+    back = m.data().astype(np.float64) / n
+    assert rel_l2(back, a) < (2e-6 if dtype == np.float32 else 1e-12)
