@@ -877,7 +877,7 @@ def test_convolve_signal_long_filters(dtype):
     # overlap_discard takes any imp_len, convolution.rs:292-462)
     tol = 2e-6 if dtype == np.float32 else 1e-11
     for cplx, n, m in ((True, 200000, 1026), (True, 200000, 5000), (True, 300000, 65537), (False, 150000, 3000),
-                       (True, 40000, 40000)):
+                       (False, 120000, 5000), (True, 40000, 40000)):
         e = 2 if cplx else 1
         x = orc.fill_uniform(n * e, 77 + m, -10, 10, dtype)
         h = orc.fill_uniform(m * e, 78 + m, -1, 1, dtype) / dtype(np.sqrt(m))
@@ -930,3 +930,16 @@ def test_large_batches_take_the_persistent_kernels(n, rows, dtype):
     assert m.plain_ifft() == 0
     back = m.data().astype(np.float64) / n
     assert rel_l2(back, a) < (2e-6 if dtype == np.float32 else 1e-12)
+
+
+def test_three_pass_fft_with_a_batch():
+    from basic_dsp_amd import DspMat
+    n, rows = 1 << 21, 3
+    rng = np.random.default_rng(5)
+    a = (rng.standard_normal((rows, 2 * n)) * 3).astype(np.float32)
+    m = DspMat(a, is_complex=True)
+    assert m.fft() == 0  # fused fft_shift on the last pass
+    got = m.data().astype(np.float64).view(np.complex128)
+    ref = np.fft.fftshift(np.fft.fft(a.astype(np.float64).view(np.complex128), axis=1), axes=1)
+    err = np.linalg.norm(got - ref, axis=1) / np.linalg.norm(ref, axis=1)
+    assert err.max() < 2e-6
