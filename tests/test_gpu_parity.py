@@ -242,7 +242,7 @@ def test_golden_fft_vector64_on_gpu():
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
-@pytest.mark.parametrize("n", [64, 1000, 4096, 16384, 1 << 20])
+@pytest.mark.parametrize("n", [64, 1000, 4096, 8192, 16384, 1 << 20, 1 << 21])
 def test_fft_ifft_with_fused_shift_window_scale(n, dtype):
     x = orc.fill_uniform(2 * n, 5 + n, -10, 10, dtype)
     xd = x.astype(np.float64)
