@@ -147,10 +147,16 @@ __global__ __launch_bounds__(256) void k_fft_wg(FftIo<T> io, const cpx<T>* __res
     } else {
         const cpx<T>* in = reinterpret_cast<const cpx<T>*>(io.in) + vec * io.in_stride;
         const int nvalid = io.in_valid ? (int)io.in_valid : N;
+        // ifft_shift of the input (even n): in[(i + n/2) mod n] with i = t + r*NT is register r ^ 8's address
+        const int rx = (io.flags & BDSP_FFT_SHIFT_IN) ? 8 : 0;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int idx = F::template in_index<16>(t, 0, r);
+            const int idx = F::template in_index<16>(t, 0, r ^ rx);
             v[r] = (active && idx < nvalid) ? in[idx] : cpx<T>{0, 0};
+        }
+        if (io.in_scale != (T)1) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = cpx<T>{v[r].x * io.in_scale, v[r].y * io.in_scale};
         }
     }
     F::template compute<16, 1, DIR>(v, t, tw);
@@ -185,10 +191,12 @@ __global__ __launch_bounds__(256) void k_fft_wg(FftIo<T> io, const cpx<T>* __res
     } else {
         if (!active) return;
         cpx<T>* out = reinterpret_cast<cpx<T>*>(io.out) + vec * io.out_stride;
+        // fft_shift of the output (even n): the last stage's digit r is the top digit of the output index
+        const int sx = (io.flags & BDSP_FFT_SHIFT_OUT) ? RL / 2 : 0;
 #pragma unroll
         for (int b = 0; b < 16 / RL; ++b)
 #pragma unroll
-            for (int r = 0; r < RL; ++r) out[F::template out_index<RL, NSL>(t, b, r)] = v[b * RL + r];
+            for (int r = 0; r < RL; ++r) out[F::template out_index<RL, NSL>(t, b, r ^ sx)] = v[b * RL + r];
     }
 }
 
@@ -232,10 +240,15 @@ __global__ __launch_bounds__(256) void k_fft_wg_batch(FftIo<T> io, const cpx<T>*
         const bool active = vec < batch;
         const cpx<T>* in = reinterpret_cast<const cpx<T>*>(io.in) + vec * io.in_stride;
         cpx<T> v[16];
+        const int rx = (io.flags & BDSP_FFT_SHIFT_IN) ? 8 : 0;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int idx = t + r * NT;
+            const int idx = t + (r ^ rx) * NT;
             v[r] = (active && idx < nvalid) ? in[idx] : cpx<T>{0, 0};
+        }
+        if (io.in_scale != (T)1) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = cpx<T>{v[r].x * io.in_scale, v[r].y * io.in_scale};
         }
         F::template compute<16, 1, DIR>(v, t, tw);
         __syncthreads(); // the previous transform's last gather is done
@@ -251,10 +264,11 @@ __global__ __launch_bounds__(256) void k_fft_wg_batch(FftIo<T> io, const cpx<T>*
         else F::template compute_pre<R3, 256, DIR>(v, tw3);
         if (active) {
             cpx<T>* out = reinterpret_cast<cpx<T>*>(io.out) + vec * io.out_stride;
+            const int sx = (io.flags & BDSP_FFT_SHIFT_OUT) ? R3 / 2 : 0;
 #pragma unroll
             for (int b = 0; b < 16 / R3; ++b)
 #pragma unroll
-                for (int r = 0; r < R3; ++r) out[F::template out_index<R3, N / R3>(t, b, r)] = v[b * R3 + r];
+                for (int r = 0; r < R3; ++r) out[F::template out_index<R3, N / R3>(t, b, r ^ sx)] = v[b * R3 + r];
         }
     }
 }
@@ -286,10 +300,15 @@ __global__ __launch_bounds__(N / 16) void k_fft_wg4(FftIo<T> io, const cpx<T>* _
     for (size_t vec = blockIdx.x; vec < batch; vec += gridDim.x) {
         const cpx<T>* in = reinterpret_cast<const cpx<T>*>(io.in) + vec * io.in_stride;
         cpx<T> v[16];
+        const int rx = (io.flags & BDSP_FFT_SHIFT_IN) ? 8 : 0;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int idx = t + r * NT;
+            const int idx = t + (r ^ rx) * NT;
             v[r] = idx < nvalid ? in[idx] : cpx<T>{0, 0};
+        }
+        if (io.in_scale != (T)1) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = cpx<T>{v[r].x * io.in_scale, v[r].y * io.in_scale};
         }
         F::template compute<16, 1, DIR>(v, t, tw);
         __syncthreads(); // the previous transform's last gather is done
@@ -308,10 +327,11 @@ __global__ __launch_bounds__(N / 16) void k_fft_wg4(FftIo<T> io, const cpx<T>* _
         F::template gather<R4>(v, t, l);
         F::template compute_pre<R4, 4096, DIR>(v, tw4);
         cpx<T>* out = reinterpret_cast<cpx<T>*>(io.out) + vec * io.out_stride;
+        const int sx = (io.flags & BDSP_FFT_SHIFT_OUT) ? R4 / 2 : 0;
 #pragma unroll
         for (int b = 0; b < 16 / R4; ++b)
 #pragma unroll
-            for (int r = 0; r < R4; ++r) out[F::template out_index<R4, N / R4>(t, b, r)] = v[b * R4 + r];
+            for (int r = 0; r < R4; ++r) out[F::template out_index<R4, N / R4>(t, b, r ^ sx)] = v[b * R4 + r];
     }
 }
 
@@ -390,8 +410,14 @@ __global__ __launch_bounds__(W * (RP / 16)) void k_fft_pass(FftIo<T> io, const c
         __syncthreads();
     } else {
         const cpx<T>* in = src + vec * n + j;
+        // first pass (ROWMAP): ifft_shift = the row index's top bit flipped = register r ^ 8's address
+        const int rx = (ROWMAP && (io.flags & BDSP_FFT_SHIFT_IN)) ? 8 : 0;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) v[r] = in[(size_t)(ti + r * NT) * stride_in];
+        for (int r = 0; r < 16; ++r) v[r] = in[(size_t)(ti + (r ^ rx) * NT) * stride_in];
+        if (ROWMAP && io.in_scale != (T)1) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = cpx<T>{v[r].x * io.in_scale, v[r].y * io.in_scale};
+        }
     }
     if (nsg > 1) {
         // inter-pass twiddle w_n^{row*q}, q = k * n/(nsg*RP); row = ti + r*NT
@@ -452,11 +478,13 @@ __global__ __launch_bounds__(W * (RP / 16)) void k_fft_pass(FftIo<T> io, const c
         }
     } else {
         cpx<T>* out = dst + vec * n + base;
+        // last pass: fft_shift = the row index's top bit flipped; the last inner stage's digit r is that top digit
+        const int sx = (last && !ROWMAP && (io.flags & BDSP_FFT_SHIFT_OUT)) ? RL / 2 : 0;
 #pragma unroll
         for (int b = 0; b < 16 / RL; ++b)
 #pragma unroll
             for (int r = 0; r < RL; ++r)
-                out[(size_t)F::template out_index<RL, NSL>(t2, b, r) * nsg] = v[b * RL + r];
+                out[(size_t)F::template out_index<RL, NSL>(t2, b, r ^ sx) * nsg] = v[b * RL + r];
     }
 }
 
@@ -467,15 +495,15 @@ __global__ __launch_bounds__(W * (RP / 16)) void k_fft_pass(FftIo<T> io, const c
 template <typename T>
 static bool io_in_generic(const FftIo<T>& io)
 {
-    return (io.flags & (BDSP_FFT_SHIFT_IN | FFT_IN_REAL)) != 0 ||
-           (io.window_id >= 0 && !(io.flags & FFT_WINDOW_OUT_DIV)) || io.in_scale != (T)1 ||
+    // ifft_shift (a register renaming for even n) and the input scale are handled by the plain path
+    return (io.flags & FFT_IN_REAL) != 0 || (io.window_id >= 0 && !(io.flags & FFT_WINDOW_OUT_DIV)) ||
            io.in_stride != io.n || (io.in_valid != 0 && io.n > 4096);
 }
 template <typename T>
 static bool io_out_generic(const FftIo<T>& io)
 {
-    return (io.flags & (BDSP_FFT_SHIFT_OUT | BDSP_FFT_MAGNITUDE | FFT_OUT_REAL | FFT_WINDOW_OUT_DIV)) != 0 ||
-           io.out_stride != io.n;
+    // fft_shift is handled by the plain path
+    return (io.flags & (BDSP_FFT_MAGNITUDE | FFT_OUT_REAL | FFT_WINDOW_OUT_DIV)) != 0 || io.out_stride != io.n;
 }
 template <typename T>
 static bool io_is_generic(const FftIo<T>& io) { return io_in_generic(io) || io_out_generic(io); }
