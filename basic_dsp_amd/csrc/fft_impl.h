@@ -418,6 +418,19 @@ __global__ __launch_bounds__(W * (RP / 16)) void k_fft_pass(FftIo<T> io, const c
 #pragma unroll
             for (int r = 0; r < 16; ++r) v[r] = cpx<T>{v[r].x * io.in_scale, v[r].y * io.in_scale};
         }
+        if (ROWMAP && io.window_id == 1 && !(io.flags & FFT_WINDOW_OUT_DIV)) {
+            // generalised Hamming (Hamming, Hann) on the input, in registers: w = alpha - beta cos(2 pi i/(n-1)),
+            // symmetric evaluation like the reference (vector_types/mod.rs:567-594)
+            const T beta = (T)1 - io.window_alpha, two_over = (T)2 / ((T)n - (T)1);
+            const size_t half = n - n / 2;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                size_t i = j + (size_t)(ti + (r ^ rx) * NT) * stride_in;
+                i = i < half ? i : n - 1 - i;
+                const T w = io.window_alpha - beta * dev_cospi<T>((T)i * two_over);
+                v[r] = cpx<T>{v[r].x * w, v[r].y * w};
+            }
+        }
     }
     if (nsg > 1) {
         // inter-pass twiddle w_n^{row*q}, q = k * n/(nsg*RP); row = ti + r*NT
@@ -496,8 +509,9 @@ template <typename T>
 static bool io_in_generic(const FftIo<T>& io)
 {
     // ifft_shift (a register renaming for even n) and the input scale are handled by the plain path
-    return (io.flags & FFT_IN_REAL) != 0 || (io.window_id >= 0 && !(io.flags & FFT_WINDOW_OUT_DIV)) ||
-           io.in_stride != io.n || (io.in_valid != 0 && io.n > 4096);
+    // ... and so is a generalised Hamming window on the first global pass (n > 4096)
+    const bool win = io.window_id >= 0 && !(io.flags & FFT_WINDOW_OUT_DIV) && !(io.window_id == 1 && io.n > 4096);
+    return (io.flags & FFT_IN_REAL) != 0 || win || io.in_stride != io.n || (io.in_valid != 0 && io.n > 4096);
 }
 template <typename T>
 static bool io_out_generic(const FftIo<T>& io)
@@ -721,7 +735,7 @@ int fft_pow2(const FftIo<T>& io, T* scratch_a, T* scratch_b, size_t batch, bool 
         // 19.8 -> 13.2 us, a single transform 7.7 vs 7.9 us); the 16384-point instantiation (1024 threads, one
         // workgroup per CU) measured SLOWER than two passes at every batch size and is not built
         static const bool no_wg4 = getenv("BDSP_FFT_NO_WG4") != nullptr;
-        if (!no_wg4 && n == 8192 && !io_is_generic(io)) return launch_wg4<T, 8192>(io, batch, inverse, s);
+        if (!no_wg4 && n == 8192 && !io_is_generic(io) && io.window_id < 0) return launch_wg4<T, 8192>(io, batch, inverse, s);
     }
     int rp[3], w[3];
     int passes = plan_passes(n, batch, rp, w);
