@@ -193,6 +193,18 @@ __global__ __launch_bounds__(256) void k_fft_wg(FftIo<T> io, const cpx<T>* __res
         cpx<T>* out = reinterpret_cast<cpx<T>*>(io.out) + vec * io.out_stride;
         // fft_shift of the output (even n): the last stage's digit r is the top digit of the output index
         const int sx = (io.flags & BDSP_FFT_SHIFT_OUT) ? RL / 2 : 0;
+        if (io.flags & (BDSP_FFT_MAGNITUDE | FFT_OUT_REAL)) {
+            T* outr = reinterpret_cast<T*>(io.out) + vec * io.out_stride;
+            const bool mag = (io.flags & BDSP_FFT_MAGNITUDE) != 0;
+#pragma unroll
+            for (int b = 0; b < 16 / RL; ++b)
+#pragma unroll
+                for (int r = 0; r < RL; ++r) {
+                    const cpx<T> z = v[b * RL + r];
+                    outr[F::template out_index<RL, NSL>(t, b, r ^ sx)] = mag ? dev_hypot<T>(z.x, z.y) : z.x;
+                }
+            return;
+        }
 #pragma unroll
         for (int b = 0; b < 16 / RL; ++b)
 #pragma unroll
@@ -493,6 +505,19 @@ __global__ __launch_bounds__(W * (RP / 16)) void k_fft_pass(FftIo<T> io, const c
         cpx<T>* out = dst + vec * n + base;
         // last pass: fft_shift = the row index's top bit flipped; the last inner stage's digit r is that top digit
         const int sx = (last && !ROWMAP && (io.flags & BDSP_FFT_SHIFT_OUT)) ? RL / 2 : 0;
+        if (last && !ROWMAP && (io.flags & (BDSP_FFT_MAGNITUDE | FFT_OUT_REAL))) {
+            // magnitude / real part straight from the registers: `points` reals per vector
+            T* outr = reinterpret_cast<T*>(io.out) + vec * io.out_stride + base;
+            const bool mag = (io.flags & BDSP_FFT_MAGNITUDE) != 0;
+#pragma unroll
+            for (int b = 0; b < 16 / RL; ++b)
+#pragma unroll
+                for (int r = 0; r < RL; ++r) {
+                    const cpx<T> z = v[b * RL + r];
+                    outr[(size_t)F::template out_index<RL, NSL>(t2, b, r ^ sx) * nsg] = mag ? dev_hypot<T>(z.x, z.y) : z.x;
+                }
+            return;
+        }
 #pragma unroll
         for (int b = 0; b < 16 / RL; ++b)
 #pragma unroll
@@ -517,7 +542,8 @@ template <typename T>
 static bool io_out_generic(const FftIo<T>& io)
 {
     // fft_shift is handled by the plain path
-    return (io.flags & (BDSP_FFT_MAGNITUDE | FFT_OUT_REAL | FFT_WINDOW_OUT_DIV)) != 0 || io.out_stride != io.n;
+    // ... and magnitude / real-part outputs are written straight from the registers
+    return (io.flags & FFT_WINDOW_OUT_DIV) != 0 || io.out_stride != io.n;
 }
 template <typename T>
 static bool io_is_generic(const FftIo<T>& io) { return io_in_generic(io) || io_out_generic(io); }
@@ -580,7 +606,7 @@ static int launch_wg(const FftIo<T>& io, size_t batch, bool inverse, hipStream_t
             occ = o;
         }
         const size_t slots = (size_t)num_cus() * (size_t)occ;
-        if (!gen && grid >= 4 * slots) {
+        if (!gen && grid >= 4 * slots && !(io.flags & (BDSP_FFT_MAGNITUDE | FFT_OUT_REAL))) {
             if (inverse) {
                 BDSP_TRY(set_lds(k_fft_wg_batch<T, N, 1>, lds2));
                 hipLaunchKernelGGL((k_fft_wg_batch<T, N, 1>), dim3((unsigned)slots), dim3(256), lds2, s, io, wtab, batch);
@@ -735,7 +761,8 @@ int fft_pow2(const FftIo<T>& io, T* scratch_a, T* scratch_b, size_t batch, bool 
         // 19.8 -> 13.2 us, a single transform 7.7 vs 7.9 us); the 16384-point instantiation (1024 threads, one
         // workgroup per CU) measured SLOWER than two passes at every batch size and is not built
         static const bool no_wg4 = getenv("BDSP_FFT_NO_WG4") != nullptr;
-        if (!no_wg4 && n == 8192 && !io_is_generic(io) && io.window_id < 0) return launch_wg4<T, 8192>(io, batch, inverse, s);
+        if (!no_wg4 && n == 8192 && !io_is_generic(io) && io.window_id < 0 &&
+            !(io.flags & (BDSP_FFT_MAGNITUDE | FFT_OUT_REAL))) return launch_wg4<T, 8192>(io, batch, inverse, s);
     }
     int rp[3], w[3];
     int passes = plan_passes(n, batch, rp, w);
