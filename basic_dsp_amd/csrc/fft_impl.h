@@ -149,10 +149,19 @@ __global__ __launch_bounds__(256) void k_fft_wg(FftIo<T> io, const cpx<T>* __res
         const int nvalid = io.in_valid ? (int)io.in_valid : N;
         // ifft_shift of the input (even n): in[(i + n/2) mod n] with i = t + r*NT is register r ^ 8's address
         const int rx = (io.flags & BDSP_FFT_SHIFT_IN) ? 8 : 0;
+        if (io.flags & FFT_IN_REAL) {
+            const T* inr = reinterpret_cast<const T*>(io.in) + vec * io.in_stride;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int idx = F::template in_index<16>(t, 0, r ^ rx);
-            v[r] = (active && idx < nvalid) ? in[idx] : cpx<T>{0, 0};
+            for (int r = 0; r < 16; ++r) {
+                const int idx = F::template in_index<16>(t, 0, r ^ rx);
+                v[r] = cpx<T>{(active && idx < nvalid) ? inr[idx] : (T)0, (T)0};
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int idx = F::template in_index<16>(t, 0, r ^ rx);
+                v[r] = (active && idx < nvalid) ? in[idx] : cpx<T>{0, 0};
+            }
         }
         if (io.in_scale != (T)1) {
 #pragma unroll
@@ -424,8 +433,15 @@ __global__ __launch_bounds__(W * (RP / 16)) void k_fft_pass(FftIo<T> io, const c
         const cpx<T>* in = src + vec * n + j;
         // first pass (ROWMAP): ifft_shift = the row index's top bit flipped = register r ^ 8's address
         const int rx = (ROWMAP && (io.flags & BDSP_FFT_SHIFT_IN)) ? 8 : 0;
+        if (ROWMAP && (io.flags & FFT_IN_REAL)) {
+            // real input: `points` scalars per vector, imaginary parts are zero (time_to_freq.rs:147-150)
+            const T* inr = reinterpret_cast<const T*>(io.in) + vec * io.in_stride + j;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) v[r] = in[(size_t)(ti + (r ^ rx) * NT) * stride_in];
+            for (int r = 0; r < 16; ++r) v[r] = cpx<T>{inr[(size_t)(ti + (r ^ rx) * NT) * stride_in], (T)0};
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = in[(size_t)(ti + (r ^ rx) * NT) * stride_in];
+        }
         if (ROWMAP && io.in_scale != (T)1) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) v[r] = cpx<T>{v[r].x * io.in_scale, v[r].y * io.in_scale};
@@ -536,7 +552,8 @@ static bool io_in_generic(const FftIo<T>& io)
     // ifft_shift (a register renaming for even n) and the input scale are handled by the plain path
     // ... and so is a generalised Hamming window on the first global pass (n > 4096)
     const bool win = io.window_id >= 0 && !(io.flags & FFT_WINDOW_OUT_DIV) && !(io.window_id == 1 && io.n > 4096);
-    return (io.flags & FFT_IN_REAL) != 0 || win || io.in_stride != io.n || (io.in_valid != 0 && io.n > 4096);
+    // ... and real input (zero imaginary parts)
+    return win || io.in_stride != io.n || (io.in_valid != 0 && io.n > 4096);
 }
 template <typename T>
 static bool io_out_generic(const FftIo<T>& io)
@@ -606,7 +623,7 @@ static int launch_wg(const FftIo<T>& io, size_t batch, bool inverse, hipStream_t
             occ = o;
         }
         const size_t slots = (size_t)num_cus() * (size_t)occ;
-        if (!gen && grid >= 4 * slots && !(io.flags & (BDSP_FFT_MAGNITUDE | FFT_OUT_REAL))) {
+        if (!gen && grid >= 4 * slots && !(io.flags & (BDSP_FFT_MAGNITUDE | FFT_OUT_REAL | FFT_IN_REAL))) {
             if (inverse) {
                 BDSP_TRY(set_lds(k_fft_wg_batch<T, N, 1>, lds2));
                 hipLaunchKernelGGL((k_fft_wg_batch<T, N, 1>), dim3((unsigned)slots), dim3(256), lds2, s, io, wtab, batch);
@@ -762,7 +779,7 @@ int fft_pow2(const FftIo<T>& io, T* scratch_a, T* scratch_b, size_t batch, bool 
         // workgroup per CU) measured SLOWER than two passes at every batch size and is not built
         static const bool no_wg4 = getenv("BDSP_FFT_NO_WG4") != nullptr;
         if (!no_wg4 && n == 8192 && !io_is_generic(io) && io.window_id < 0 &&
-            !(io.flags & (BDSP_FFT_MAGNITUDE | FFT_OUT_REAL))) return launch_wg4<T, 8192>(io, batch, inverse, s);
+            !(io.flags & (BDSP_FFT_MAGNITUDE | FFT_OUT_REAL | FFT_IN_REAL))) return launch_wg4<T, 8192>(io, batch, inverse, s);
     }
     int rp[3], w[3];
     int passes = plan_passes(n, batch, rp, w);
