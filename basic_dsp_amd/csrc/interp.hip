@@ -289,7 +289,6 @@ int interpolatef_dev(const T* in, T* out, size_t len, bool is_complex, int fid, 
         long long q_hi = ((long long)new_points - scalar_len) / f;   // f*q + f - 1 < new_points - scalar_len
         const bool blocked = (f == 2 || f == 3 || f == 4 || f == 8) && q_hi > q_lo &&
                              (long long)new_points >= 2 * scalar_len;
-        long long edge_points = blocked ? 0 : (long long)new_points;
         if (is_complex)
             hipLaunchKernelGGL((k_interp_table<T, true>), dim3((unsigned)blocks), dim3(256), lds, s, in, out,
                                tb.as<T>(), (long long)points, (long long)new_points, (int)conv_len, f,
@@ -298,7 +297,6 @@ int interpolatef_dev(const T* in, T* out, size_t len, bool is_complex, int fid, 
             hipLaunchKernelGGL((k_interp_table<T, false>), dim3((unsigned)blocks), dim3(256), lds, s, in, out,
                                tb.as<T>(), (long long)points, (long long)new_points, (int)conv_len, f,
                                blocked ? q_lo * f : -1LL, blocked ? q_hi * f : -1LL);
-        (void)edge_points;
         if (blocked) {
             BDSP_LAUNCH_CHECK();
             const int e = is_complex ? 2 : 1;
