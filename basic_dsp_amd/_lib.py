@@ -129,6 +129,8 @@ for _s, _t, _R in (("32", _F, VectorInteropResult32), ("64", _D, VectorInteropRe
     for _n in ("prepare_argument", "prepare_argument_padded"):
         _proto(_n + _s, _R, _P)
     _proto("convolve" + _s, _R, _P, C.c_int32, _t, _t, _SZ)
+    for _n in ("get_real", "get_imag", "get_magnitude", "get_magnitude_squared", "get_phase"):
+        _proto(_n + _s, C.c_int32, _P, _P)
     for _n in ("interpolate_lin", "interpolate_hermite"):
         _proto(_n + _s, _R, _P, _t, _t)
     # callback variants: the callbacks run on the host (sampled into a table), see the header

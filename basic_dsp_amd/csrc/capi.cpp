@@ -882,6 +882,26 @@ int op_interpolate_real(DevVec<T>* v, T factor, T delay, bool hermite)
     return BDSP_OK;
 }
 
+// get_real / get_imag / get_magnitude / get_magnitude_squared / get_phase (complex_to_real.rs:620-700): the
+// result goes into `dst` (resized to `points` reals); a real source or a complex destination empties dst.
+// The facade passes the source by value (it is consumed) and returns convert_void(Ok(())) = 9, whatever
+// happened (interop/src/lib.rs:100-105) -- kept for link compatibility.
+template <typename T>
+int op_get_complex_to_real(DevVec<T>* v, DevVec<T>* dst, int kind)
+{
+    int rc = BDSP_OK;
+    if (!v->complex_ || dst->complex_) {
+        dst->valid_len = 0;
+    } else {
+        const size_t points = v->points();
+        rc = dst->reserve(points ? points : 1);
+        if (rc == BDSP_OK && points) rc = ew_complex_to_real<T>(v->data, dst->data, v->valid_len, kind, lib_stream());
+        if (rc == BDSP_OK) dst->valid_len = points;
+    }
+    delete v;
+    return rc == BDSP_OK ? 9 : rc;
+}
+
 template <typename T>
 int op_binary_smaller(DevVec<T>* v, const DevVec<T>* o, int op)
 {
@@ -1402,6 +1422,11 @@ size_t bdsp_hip_overlap_discard_f64(double* x_time, size_t x_len, double* tmp, s
     RES multiply_frequency_response_real##SFX(VB* vector, T (*frequency_response)(const void*, T),          \
                                               const void* frequency_response_data, bool is_symmetric, T ratio) \
     { DevVec<T>* v = H<T>(vector); return finish<T>(v, op_custom_frequency_response<T>(v, frequency_response, frequency_response_data, is_symmetric, ratio)); } \
+    int32_t get_real##SFX(VB* vector, VB* destination) { return op_get_complex_to_real<T>(H<T>(vector), H<T>(destination), 2); } \
+    int32_t get_imag##SFX(VB* vector, VB* destination) { return op_get_complex_to_real<T>(H<T>(vector), H<T>(destination), 3); } \
+    int32_t get_magnitude##SFX(VB* vector, VB* destination) { return op_get_complex_to_real<T>(H<T>(vector), H<T>(destination), 0); } \
+    int32_t get_magnitude_squared##SFX(VB* vector, VB* destination) { return op_get_complex_to_real<T>(H<T>(vector), H<T>(destination), 1); } \
+    int32_t get_phase##SFX(VB* vector, VB* destination) { return op_get_complex_to_real<T>(H<T>(vector), H<T>(destination), 4); } \
     RES interpolate_lin##SFX(VB* vector, T interpolation_factor, T delay)                                   \
     { DevVec<T>* v = H<T>(vector); return finish<T>(v, op_interpolate_real<T>(v, interpolation_factor, delay, false)); } \
     RES interpolate_hermite##SFX(VB* vector, T interpolation_factor, T delay)                               \

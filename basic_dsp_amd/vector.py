@@ -157,6 +157,28 @@ class DspVec:
     def phase(self):
         return self._call("phase")
 
+    def _get_into(self, name, destination):
+        """The facade getters consume their source handle: they run on a clone, so `self` stays usable."""
+        src = self.clone()
+        code = self._fn(name)(src._h, destination._h)
+        src._h = None  # consumed by the call
+        return _lib.check(code, name + self._sfx)
+
+    def get_real(self, destination):
+        return self._get_into("get_real", destination)
+
+    def get_imag(self, destination):
+        return self._get_into("get_imag", destination)
+
+    def get_magnitude(self, destination):
+        return self._get_into("get_magnitude", destination)
+
+    def get_magnitude_squared(self, destination):
+        return self._get_into("get_magnitude_squared", destination)
+
+    def get_phase(self, destination):
+        return self._get_into("get_phase", destination)
+
     def to_complex(self):
         return self._call("to_complex")
 

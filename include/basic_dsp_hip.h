@@ -244,6 +244,14 @@ VectorInteropResult32 convolve_real32(VecBuf32 *vector, bdsp_real_fn32 impulse_r
 VectorInteropResult32 multiply_frequency_response_real32(VecBuf32 *vector, bdsp_real_fn32 frequency_response,
                                       const void *frequency_response_data, bool is_symmetric,
                                       float ratio);                                   /* facade32.rs:1247-1262 */
+/* Getters into a second vector (facade32.rs:564-668).  The source handle is CONSUMED (the reference takes it
+ * by value), the destination is resized to `points` reals; like the reference these return 9 on success
+ * (convert_void, interop/src/lib.rs:100-105) -- a quirk kept for link compatibility. */
+int32_t get_real32(VecBuf32 *vector, VecBuf32 *destination);              /* facade32.rs:652-654 */
+int32_t get_imag32(VecBuf32 *vector, VecBuf32 *destination);              /* facade32.rs:657-659 */
+int32_t get_magnitude32(VecBuf32 *vector, VecBuf32 *destination);         /* facade32.rs:564-566 */
+int32_t get_magnitude_squared32(VecBuf32 *vector, VecBuf32 *destination); /* facade32.rs:569-571 */
+int32_t get_phase32(VecBuf32 *vector, VecBuf32 *destination);             /* facade32.rs:667-669 */
 VectorInteropResult32 interpolate_lin32(VecBuf32 *vector, float interpolation_factor, float delay);     /* facade32.rs:1437-1443 */
 VectorInteropResult32 interpolate_hermite32(VecBuf32 *vector, float interpolation_factor, float delay); /* facade32.rs:1446-1452 */
 VectorInteropResult32 apply_custom_window32(VecBuf32 *vector, bdsp_window_fn32 window, const void *window_data,
@@ -358,6 +366,14 @@ VectorInteropResult64 convolve_real64(VecBuf64 *vector, bdsp_real_fn64 impulse_r
 VectorInteropResult64 multiply_frequency_response_real64(VecBuf64 *vector, bdsp_real_fn64 frequency_response,
                                       const void *frequency_response_data, bool is_symmetric,
                                       double ratio);                                   /* facade32.rs:1247-1262 */
+/* Getters into a second vector (facade32.rs:564-668).  The source handle is CONSUMED (the reference takes it
+ * by value), the destination is resized to `points` reals; like the reference these return 9 on success
+ * (convert_void, interop/src/lib.rs:100-105) -- a quirk kept for link compatibility. */
+int32_t get_real64(VecBuf64 *vector, VecBuf64 *destination);              /* facade32.rs:652-654 */
+int32_t get_imag64(VecBuf64 *vector, VecBuf64 *destination);              /* facade32.rs:657-659 */
+int32_t get_magnitude64(VecBuf64 *vector, VecBuf64 *destination);         /* facade32.rs:564-566 */
+int32_t get_magnitude_squared64(VecBuf64 *vector, VecBuf64 *destination); /* facade32.rs:569-571 */
+int32_t get_phase64(VecBuf64 *vector, VecBuf64 *destination);             /* facade32.rs:667-669 */
 VectorInteropResult64 interpolate_lin64(VecBuf64 *vector, double interpolation_factor, double delay);     /* facade32.rs:1437-1443 */
 VectorInteropResult64 interpolate_hermite64(VecBuf64 *vector, double interpolation_factor, double delay); /* facade32.rs:1446-1452 */
 VectorInteropResult64 apply_custom_window64(VecBuf64 *vector, bdsp_window_fn64 window, const void *window_data,

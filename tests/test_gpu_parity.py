@@ -943,3 +943,22 @@ def test_three_pass_fft_with_a_batch():
     ref = np.fft.fftshift(np.fft.fft(a.astype(np.float64).view(np.complex128), axis=1), axes=1)
     err = np.linalg.norm(got - ref, axis=1) / np.linalg.norm(ref, axis=1)
     assert err.max() < 2e-6
+
+
+def test_getters_into_a_destination_vector():
+    # facade32.rs:564-668: source consumed, destination resized to `points` reals, 9 on success (convert_void)
+    x = orc.fill_uniform(2 * 1000, 21, -10, 10, np.float32)
+    v = DspVec(x, is_complex=True)
+    for name, kind in (("get_real", 2), ("get_imag", 3), ("get_magnitude", 0), ("get_magnitude_squared", 1),
+                       ("get_phase", 4)):
+        d = DspVec(np.zeros(5, np.float32))
+        assert getattr(v, name)(d) == 9
+        assert len(d) == 1000 and not d.is_complex()
+        ref = orc.complex_to_real(x, kind)
+        if kind in (1, 2, 3):
+            assert np.array_equal(d.data(), ref)
+        else:
+            np.testing.assert_allclose(d.data(), ref, rtol=2e-6, atol=2e-6)
+    assert np.array_equal(v.data(), x)  # the Python mirror works on a clone
+    d = DspVec(np.zeros(4, np.float32), is_complex=True)
+    assert v.get_real(d) == 9 and len(d) == 0  # a complex destination is emptied
