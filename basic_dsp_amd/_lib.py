@@ -22,6 +22,37 @@ class VectorInteropResult64(C.Structure):
     _fields_ = [("result_code", C.c_int32), ("vector", C.c_void_p)]
 
 
+class Complex32(C.Structure):
+    _fields_ = [("re", C.c_float), ("im", C.c_float)]
+
+
+class Complex64(C.Structure):
+    _fields_ = [("re", C.c_double), ("im", C.c_double)]
+
+
+def _stats_struct(name, scalar):
+    """#[repr(C)] Statistics<T> (vector/src/vector_types/general/statistics.rs:11-31)."""
+    return type(name, (C.Structure,), {"_fields_": [
+        ("sum", scalar), ("count", C.c_size_t), ("average", scalar), ("rms", scalar), ("min", scalar),
+        ("min_index", C.c_size_t), ("max", scalar), ("max_index", C.c_size_t)]})
+
+
+Statistics32 = _stats_struct("Statistics32", C.c_float)
+Statistics64 = _stats_struct("Statistics64", C.c_double)
+ComplexStatistics32 = _stats_struct("ComplexStatistics32", Complex32)
+ComplexStatistics64 = _stats_struct("ComplexStatistics64", Complex64)
+
+
+def _scalar_result(name, scalar):
+    return type(name, (C.Structure,), {"_fields_": [("result_code", C.c_int32), ("result", scalar)]})
+
+
+ScalarInteropResult32 = _scalar_result("ScalarInteropResult32", C.c_float)
+ScalarInteropResult64 = _scalar_result("ScalarInteropResult64", C.c_double)
+ComplexScalarInteropResult32 = _scalar_result("ComplexScalarInteropResult32", Complex32)
+ComplexScalarInteropResult64 = _scalar_result("ComplexScalarInteropResult64", Complex64)
+
+
 def _preload_shared_hip_runtime():
     """One process must hold ONE copy of the HIP runtime.  PyTorch-ROCm wheels bundle their own
     libamdhip64.so (file name without version, soname libamdhip64.so.7); if this library pulls in
@@ -140,6 +171,32 @@ for _s, _t, _R in (("32", _F, VectorInteropResult32), ("64", _D, VectorInteropRe
                "windowed_custom_sfft", "windowed_custom_ifft", "windowed_custom_sifft"):
         _proto(_n + _s, _R, _P, _P, _P, C.c_bool)
 
+    # statistics, sums, dot products
+    _ST = Statistics32 if _s == "32" else Statistics64
+    _CST = ComplexStatistics32 if _s == "32" else ComplexStatistics64
+    _CX = Complex32 if _s == "32" else Complex64
+    _SR = ScalarInteropResult32 if _s == "32" else ScalarInteropResult64
+    _CSR = ComplexScalarInteropResult32 if _s == "32" else ComplexScalarInteropResult64
+    _proto("real_statistics" + _s, _ST, _P)
+    _proto("complex_statistics" + _s, _CST, _P)
+    _proto("real_statistics_prec" + _s, Statistics64, _P)
+    _proto("complex_statistics_prec" + _s, ComplexStatistics64, _P)
+    _proto("real_sum" + _s, _t, _P)
+    _proto("real_sum_sq" + _s, _t, _P)
+    _proto("real_sum_prec" + _s, _D, _P)
+    _proto("real_sum_sq_prec" + _s, _D, _P)
+    _proto("complex_sum" + _s, _CX, _P)
+    _proto("complex_sum_sq" + _s, _CX, _P)
+    _proto("complex_sum_prec" + _s, Complex64, _P)
+    _proto("complex_sum_sq_prec" + _s, Complex64, _P)
+    _proto("real_dot_product" + _s, _SR, _P, _P)
+    _proto("complex_dot_product" + _s, _CSR, _P, _P)
+    _proto("real_dot_product_prec" + _s, ScalarInteropResult64, _P, _P)
+    _proto("complex_dot_product_prec" + _s, ComplexScalarInteropResult64, _P, _P)
+    _proto("real_statistics_split" + _s, C.c_int32, _P, C.POINTER(_ST), _SZ)
+    _proto("complex_statistics_split" + _s, C.c_int32, _P, C.POINTER(_CST), _SZ)
+    _proto("real_statistics_split_prec" + _s, C.c_int32, _P, C.POINTER(Statistics64), _SZ)
+    _proto("complex_statistics_split_prec" + _s, C.c_int32, _P, C.POINTER(ComplexStatistics64), _SZ)
     # matrix / batch API
     _m = "bdsp_hip_mat_"
     _proto(_m + "new" + _s, _P, C.c_int32, C.c_int32, _SZ, _SZ, _t)

@@ -136,6 +136,18 @@ template <typename T> int conv_function_direct(const T* in, T* out, size_t point
 template <typename T> size_t interpolate_real_len(size_t len, T factor);
 template <typename T> int interpolate_real_dev(const T* in, T* out, size_t len, T factor, T delay, bool hermite, hipStream_t s);
 
+// reduce.hip: what one walk over a vector accumulates (sums in double; min / max with their keys and indices)
+struct StatPartial {
+    double sr, si, qr, qi;       // sum, sum of squares (complex: z*z, not |z|^2 -- statistics.rs:344)
+    double mn_key, mx_key;       // ordering keys: the value (real) or its norm (complex)
+    double mnr, mni, mxr, mxi;   // the extreme elements themselves
+    unsigned long long imn, imx, cnt;
+};
+template <typename T>
+int red_stats(const T* x, size_t count, size_t first, size_t step, bool is_complex, bool minmax, StatPartial* partials, hipStream_t s);
+template <typename T>
+int red_dot(const T* x, const T* y, size_t count, bool is_complex, StatPartial* partials, hipStream_t s);
+
 // bluestein.hip
 template <typename T> int bs_chirp(T* c, size_t n, bool inverse, hipStream_t s);
 template <typename T> int bs_kernel(const T* c, T* b, size_t n, size_t m, hipStream_t s);

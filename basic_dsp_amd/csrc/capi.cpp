@@ -1014,6 +1014,125 @@ const T* vec_download(DevVec<T>* v)
 }
 
 // ----------------------------------------------------------------------------------------------
+// Statistics, sums, dot products: the device folds the vector into one StatPartial (reduce.hip), the host
+// turns it into the reference's result structs.
+// ----------------------------------------------------------------------------------------------
+static void stat_empty(StatPartial& p, bool cplx)
+{
+    std::memset(&p, 0, sizeof(p));
+    const double inf = std::numeric_limits<double>::infinity();
+    if (cplx) { p.mnr = p.mni = inf; p.mn_key = inf; }
+    else { p.mnr = inf; p.mn_key = inf; p.mxr = -inf; p.mx_key = -inf; }
+}
+
+template <typename T>
+int stats_run(const DevVec<T>* v, bool cplx, bool minmax, size_t first, size_t step, StatPartial* host)
+{
+    const size_t units = cplx ? v->valid_len / 2 : v->valid_len;
+    const size_t count = first < units ? (units - first + step - 1) / step : 0;
+    stat_empty(*host, cplx);
+    if (count == 0) return BDSP_OK;
+    hipStream_t s = lib_stream();
+    WsBlock pb;
+    BDSP_TRY(pb.alloc(sizeof(StatPartial) * 1024, s));
+    BDSP_TRY(red_stats<T>(v->data, count, first, step, cplx, minmax, pb.as<StatPartial>(), s));
+    BDSP_HIP_TRY(hipMemcpyAsync(host, pb.p, sizeof(StatPartial), hipMemcpyDeviceToHost, s));
+    BDSP_HIP_TRY(hipStreamSynchronize(s));
+    return BDSP_OK;
+}
+
+template <typename S, typename R>
+void stat_fill_real(S* out, const StatPartial& p)
+{
+    const double n = (double)p.cnt;
+    out->sum = (R)p.sr; out->count = (size_t)p.cnt;
+    out->average = (R)(p.sr / n); out->rms = (R)std::sqrt(p.qr / n);
+    out->min = (R)p.mnr; out->min_index = (size_t)p.imn; out->max = (R)p.mxr; out->max_index = (size_t)p.imx;
+}
+
+template <typename S, typename R>
+void stat_fill_complex(S* out, const StatPartial& p)
+{
+    const double n = (double)p.cnt;
+    // sqrt of the COMPLEX mean of z*z (principal branch), like (sum_squared / count).sqrt() in the reference
+    const double qr = p.qr / n, qi = p.qi / n;
+    const double r = std::hypot(qr, qi);
+    double rr, ri;
+    if (r != r) { rr = ri = std::numeric_limits<double>::quiet_NaN(); }
+    else if (qi == 0.0 && qr >= 0.0) { rr = std::sqrt(qr); ri = qi; }
+    else if (qi == 0.0) { rr = 0.0; ri = std::signbit(qi) ? -std::sqrt(-qr) : std::sqrt(-qr); }
+    else { const double th = std::atan2(qi, qr) / 2; rr = std::sqrt(r) * std::cos(th); ri = std::sqrt(r) * std::sin(th); }
+    out->sum.re = (R)p.sr; out->sum.im = (R)p.si; out->count = (size_t)p.cnt;
+    out->average.re = (R)(p.sr / n); out->average.im = (R)(p.si / n);
+    out->rms.re = (R)rr; out->rms.im = (R)ri;
+    out->min.re = (R)p.mnr; out->min.im = (R)p.mni; out->min_index = (size_t)p.imn;
+    out->max.re = (R)p.mxr; out->max.im = (R)p.mxi; out->max_index = (size_t)p.imx;
+}
+
+template <typename T, typename S, typename R>
+S stats_real(const DevVec<T>* v)
+{
+    StatPartial p;
+    S out;
+    if (stats_run<T>(v, false, true, 0, 1, &p) != BDSP_OK) stat_empty(p, false);
+    stat_fill_real<S, R>(&out, p);
+    return out;
+}
+template <typename T, typename S, typename R>
+S stats_complex(const DevVec<T>* v)
+{
+    StatPartial p;
+    S out;
+    if (stats_run<T>(v, true, true, 0, 1, &p) != BDSP_OK) stat_empty(p, true);
+    stat_fill_complex<S, R>(&out, p);
+    return out;
+}
+template <typename T, typename S, typename R, bool CPLX>
+int stats_split(const DevVec<T>* v, S* data, size_t len)
+{
+    if (len == 0) return BDSP_OK;
+    if (len > 16) return BDSP_ERR_ARG_LENGTH; // STATS_VEC_CAPACTIY (statistics.rs:34, 403-405)
+    for (size_t b = 0; b < len; ++b) {
+        StatPartial p;
+        BDSP_TRY(stats_run<T>(v, CPLX, true, b, len, &p));
+        if constexpr (CPLX) stat_fill_complex<S, R>(&data[b], p); else stat_fill_real<S, R>(&data[b], p);
+    }
+    return BDSP_OK;
+}
+// sums: which = 0 sum, 1 sum of squares; returns (re, im) in double
+template <typename T>
+void sums(const DevVec<T>* v, bool cplx, int which, double* re, double* im)
+{
+    StatPartial p;
+    if (stats_run<T>(v, cplx, false, 0, 1, &p) != BDSP_OK) stat_empty(p, cplx);
+    *re = which ? p.qr : p.sr;
+    *im = which ? p.qi : p.si;
+}
+// dot products (dot_products.rs:67-165): code 4 / 3 / 2 for the number-space and metadata errors, else the
+// vector's error marker (0 or -1)
+template <typename T>
+int dot(const DevVec<T>* v, const DevVec<T>* o, bool cplx, double* re, double* im)
+{
+    *re = *im = 0.0;
+    if (!cplx && v->complex_) return BDSP_ERR_MUST_BE_REAL;
+    if (cplx && !v->complex_) return BDSP_ERR_MUST_BE_COMPLEX;
+    if (cplx && (!o->complex_ || o->freq != v->freq)) return BDSP_ERR_META_DATA;
+    const size_t len = v->valid_len < o->valid_len ? v->valid_len : o->valid_len;
+    const size_t count = cplx ? len / 2 : len;
+    if (count) {
+        hipStream_t s = lib_stream();
+        WsBlock pb;
+        BDSP_TRY(pb.alloc(sizeof(StatPartial) * 1024, s));
+        BDSP_TRY(red_dot<T>(v->data, o->data, count, cplx, pb.as<StatPartial>(), s));
+        StatPartial p;
+        BDSP_HIP_TRY(hipMemcpyAsync(&p, pb.p, sizeof(StatPartial), hipMemcpyDeviceToHost, s));
+        BDSP_HIP_TRY(hipStreamSynchronize(s));
+        *re = p.sr; *im = p.si;
+    }
+    return v->erroneous() ? BDSP_ERR_POISONED : BDSP_OK;
+}
+
+// ----------------------------------------------------------------------------------------------
 // Matrix / batch API: `rows` equally long vectors back to back in ONE allocation, every operation a
 // batched launch over all rows.  Mirrors the matrix crate (matrix/src/lib.rs:195-208 applies an
 // operation to the rows one after the other; matrix/src/time_freq.rs:49-530 forwards the
@@ -1447,6 +1566,41 @@ size_t bdsp_hip_overlap_discard_f64(double* x_time, size_t x_len, double* tmp, s
 BDSP_FACADE(32, float, VecBuf32, VectorInteropResult32)
 BDSP_FACADE(64, double, VecBuf64, VectorInteropResult64)
 #undef BDSP_FACADE
+
+// ---------------------------------------------------------------------------------------------- statistics
+#define BDSP_STATS(SFX, T, VB)                                                                              \
+    Statistics##SFX real_statistics##SFX(const VB* vector) { return stats_real<T, Statistics##SFX, T>(H<T>(vector)); } \
+    ComplexStatistics##SFX complex_statistics##SFX(const VB* vector) { return stats_complex<T, ComplexStatistics##SFX, T>(H<T>(vector)); } \
+    Statistics64 real_statistics_prec##SFX(const VB* vector) { return stats_real<T, Statistics64, double>(H<T>(vector)); } \
+    ComplexStatistics64 complex_statistics_prec##SFX(const VB* vector) { return stats_complex<T, ComplexStatistics64, double>(H<T>(vector)); } \
+    T real_sum##SFX(const VB* vector) { double a, b; sums<T>(H<T>(vector), false, 0, &a, &b); return (T)a; } \
+    T real_sum_sq##SFX(const VB* vector) { double a, b; sums<T>(H<T>(vector), false, 1, &a, &b); return (T)a; } \
+    double real_sum_prec##SFX(const VB* vector) { double a, b; sums<T>(H<T>(vector), false, 0, &a, &b); return a; } \
+    double real_sum_sq_prec##SFX(const VB* vector) { double a, b; sums<T>(H<T>(vector), false, 1, &a, &b); return a; } \
+    bdsp_complex##SFX complex_sum##SFX(const VB* vector) { double a, b; sums<T>(H<T>(vector), true, 0, &a, &b); return bdsp_complex##SFX{(T)a, (T)b}; } \
+    bdsp_complex##SFX complex_sum_sq##SFX(const VB* vector) { double a, b; sums<T>(H<T>(vector), true, 1, &a, &b); return bdsp_complex##SFX{(T)a, (T)b}; } \
+    bdsp_complex64 complex_sum_prec##SFX(const VB* vector) { double a, b; sums<T>(H<T>(vector), true, 0, &a, &b); return bdsp_complex64{a, b}; } \
+    bdsp_complex64 complex_sum_sq_prec##SFX(const VB* vector) { double a, b; sums<T>(H<T>(vector), true, 1, &a, &b); return bdsp_complex64{a, b}; } \
+    ScalarInteropResult##SFX real_dot_product##SFX(const VB* vector, const VB* operand)                     \
+    { double a, b; int c = dot<T>(H<T>(vector), H<T>(operand), false, &a, &b); return ScalarInteropResult##SFX{c, (T)a}; } \
+    ComplexScalarInteropResult##SFX complex_dot_product##SFX(const VB* vector, const VB* operand)           \
+    { double a, b; int c = dot<T>(H<T>(vector), H<T>(operand), true, &a, &b); return ComplexScalarInteropResult##SFX{c, bdsp_complex##SFX{(T)a, (T)b}}; } \
+    ScalarInteropResult64 real_dot_product_prec##SFX(const VB* vector, const VB* operand)                   \
+    { double a, b; int c = dot<T>(H<T>(vector), H<T>(operand), false, &a, &b); return ScalarInteropResult64{c, a}; } \
+    ComplexScalarInteropResult64 complex_dot_product_prec##SFX(const VB* vector, const VB* operand)         \
+    { double a, b; int c = dot<T>(H<T>(vector), H<T>(operand), true, &a, &b); return ComplexScalarInteropResult64{c, bdsp_complex64{a, b}}; } \
+    int32_t real_statistics_split##SFX(const VB* vector, Statistics##SFX* data, size_t len)                 \
+    { return stats_split<T, Statistics##SFX, T, false>(H<T>(vector), data, len); }                         \
+    int32_t complex_statistics_split##SFX(const VB* vector, ComplexStatistics##SFX* data, size_t len)       \
+    { return stats_split<T, ComplexStatistics##SFX, T, true>(H<T>(vector), data, len); }                   \
+    int32_t real_statistics_split_prec##SFX(const VB* vector, Statistics64* data, size_t len)               \
+    { return stats_split<T, Statistics64, double, false>(H<T>(vector), data, len); }                       \
+    int32_t complex_statistics_split_prec##SFX(const VB* vector, ComplexStatistics64* data, size_t len)     \
+    { return stats_split<T, ComplexStatistics64, double, true>(H<T>(vector), data, len); }
+
+BDSP_STATS(32, float, VecBuf32)
+BDSP_STATS(64, double, VecBuf64)
+#undef BDSP_STATS
 
 // ---------------------------------------------------------------------------------------------- matrix / batch
 #define BDSP_MAT(SFX, T, MB, VB)                                                                            \

@@ -269,6 +269,47 @@ class DspVec:
     def windowed_sifft(self, window):
         return self._call("windowed_sifft", int(window))
 
+    # ------------------------------------------------------------------ statistics, sums, dot products
+    @staticmethod
+    def _stats_dict(st, cplx):
+        c = (lambda z: complex(z.re, z.im)) if cplx else (lambda z: z)
+        return dict(sum=c(st.sum), count=st.count, average=c(st.average), rms=c(st.rms), min=c(st.min),
+                    min_index=st.min_index, max=c(st.max), max_index=st.max_index)
+
+    def statistics(self, prec=False):
+        """StatisticsOps::statistics / PreciseStatisticsOps::statistics_prec as a dict."""
+        cplx = self.is_complex()
+        name = ("complex" if cplx else "real") + "_statistics" + ("_prec" if prec else "")
+        return self._stats_dict(self._fn(name)(self._h), cplx)
+
+    def statistics_split(self, length, prec=False):
+        cplx = self.is_complex()
+        kind = (_lib.ComplexStatistics64 if cplx else _lib.Statistics64) if (prec or self._sfx == "64") else \
+            (_lib.ComplexStatistics32 if cplx else _lib.Statistics32)
+        arr = (kind * max(length, 1))()
+        name = ("complex" if cplx else "real") + "_statistics_split" + ("_prec" if prec else "")
+        code = _lib.check(self._fn(name)(self._h, arr, int(length)), name)
+        return code, [self._stats_dict(arr[i], cplx) for i in range(length if code == 0 else 0)]
+
+    def sum(self, prec=False):
+        if self.is_complex():
+            z = self._fn("complex_sum" + ("_prec" if prec else ""))(self._h)
+            return complex(z.re, z.im)
+        return self._fn("real_sum" + ("_prec" if prec else ""))(self._h)
+
+    def sum_sq(self, prec=False):
+        if self.is_complex():
+            z = self._fn("complex_sum_sq" + ("_prec" if prec else ""))(self._h)
+            return complex(z.re, z.im)
+        return self._fn("real_sum_sq" + ("_prec" if prec else ""))(self._h)
+
+    def dot_product(self, other, prec=False):
+        """returns (result_code, value): codes as in dot_products.rs (4 / 3 / 2), 0 ok, -1 poisoned"""
+        cplx = self.is_complex()
+        r = self._fn(("complex" if cplx else "real") + "_dot_product" + ("_prec" if prec else ""))(self._h, other._h)
+        _lib.check(r.result_code, "dot_product")
+        return r.result_code, (complex(r.result.re, r.result.im) if cplx else r.result)
+
     # ------------------------------------------------------------------ correlation, function convolution
     def prepare_argument(self):
         return self._call("prepare_argument")

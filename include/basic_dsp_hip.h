@@ -394,6 +394,68 @@ VectorInteropResult64 windowed_custom_sifft64(VecBuf64 *vector, bdsp_window_fn64
 void *bdsp_hip_vec_device_ptr32(VecBuf32 *vector);
 void *bdsp_hip_vec_device_ptr64(VecBuf64 *vector);
 
+/* Statistics, sums and dot products (interop/src/facade32.rs:193-327, 846-931; vector/src/vector_types/general/
+ * statistics.rs, dot_products.rs).  One pass over the vector on the device (sums accumulate in double), the small
+ * result comes back by value.  Minimum / maximum: first occurrence, complex values ordered by norm(); the complex
+ * `rms` is sqrt(sum(z*z)/n) -- a complex number, as in the reference (statistics.rs:331, 344).  The `real_*` entry
+ * points walk all interleaved scalars of a complex vector, the `complex_*` ones walk pairs.  `*_prec*` variants
+ * return double-precision results (the reference uses compensated summation there). */
+typedef struct { float re, im; } bdsp_complex32;   /* num_complex::Complex32, #[repr(C)] */
+typedef struct { double re, im; } bdsp_complex64;
+/* #[repr(C)] Statistics<T>  (statistics.rs:11-31) */
+typedef struct { float sum; size_t count; float average, rms, min; size_t min_index; float max; size_t max_index; } Statistics32;
+typedef struct { double sum; size_t count; double average, rms, min; size_t min_index; double max; size_t max_index; } Statistics64;
+typedef struct { bdsp_complex32 sum; size_t count; bdsp_complex32 average, rms, min; size_t min_index; bdsp_complex32 max; size_t max_index; } ComplexStatistics32;
+typedef struct { bdsp_complex64 sum; size_t count; bdsp_complex64 average, rms, min; size_t min_index; bdsp_complex64 max; size_t max_index; } ComplexStatistics64;
+/* #[repr(C)] ScalarInteropResult<T> { result_code, result }  (interop/src/lib.rs:229-242) */
+typedef struct { int32_t result_code; float result; } ScalarInteropResult32;
+typedef struct { int32_t result_code; double result; } ScalarInteropResult64;
+typedef struct { int32_t result_code; bdsp_complex32 result; } ComplexScalarInteropResult32;
+typedef struct { int32_t result_code; bdsp_complex64 result; } ComplexScalarInteropResult64;
+Statistics32 real_statistics32(const VecBuf32 *vector);                          /* facade32.rs:223-226 */
+ComplexStatistics32 complex_statistics32(const VecBuf32 *vector);                /* facade32.rs:229-232 */
+float real_sum32(const VecBuf32 *vector);                                          /* facade32.rs:235-237 */
+float real_sum_sq32(const VecBuf32 *vector);                                       /* facade32.rs:240-242 */
+bdsp_complex32 complex_sum32(const VecBuf32 *vector);                            /* facade32.rs:245-247 */
+bdsp_complex32 complex_sum_sq32(const VecBuf32 *vector);                         /* facade32.rs:250-252 */
+ScalarInteropResult32 real_dot_product32(const VecBuf32 *vector, const VecBuf32 *operand);             /* facade32.rs:193-201 */
+ComplexScalarInteropResult32 complex_dot_product32(const VecBuf32 *vector, const VecBuf32 *operand);   /* facade32.rs:204-220 */
+Statistics64 real_statistics_prec32(const VecBuf32 *vector);                     /* facade32.rs:292-295 */
+ComplexStatistics64 complex_statistics_prec32(const VecBuf32 *vector);           /* facade32.rs:298-301 */
+double real_sum_prec32(const VecBuf32 *vector);                                  /* facade32.rs:304-306 */
+double real_sum_sq_prec32(const VecBuf32 *vector);                               /* facade32.rs:309-311 */
+bdsp_complex64 complex_sum_prec32(const VecBuf32 *vector);                       /* facade32.rs:314-316 */
+bdsp_complex64 complex_sum_sq_prec32(const VecBuf32 *vector);                    /* facade32.rs:319-321 */
+ScalarInteropResult64 real_dot_product_prec32(const VecBuf32 *vector, const VecBuf32 *operand);            /* facade32.rs:254-270 */
+ComplexScalarInteropResult64 complex_dot_product_prec32(const VecBuf32 *vector, const VecBuf32 *operand);  /* facade32.rs:273-289 */
+/* statistics_split (statistics.rs:389-426): element j goes to bucket j % len with index j / len; len <= 16, else code 7 */
+int32_t real_statistics_split32(const VecBuf32 *vector, Statistics32 *data, size_t len);               /* facade32.rs:848-864 */
+int32_t complex_statistics_split32(const VecBuf32 *vector, ComplexStatistics32 *data, size_t len);     /* facade32.rs:867-886 */
+int32_t real_statistics_split_prec32(const VecBuf32 *vector, Statistics64 *data, size_t len);          /* facade32.rs:889-907 */
+int32_t complex_statistics_split_prec32(const VecBuf32 *vector, ComplexStatistics64 *data, size_t len);/* facade32.rs:910-931 */
+
+Statistics64 real_statistics64(const VecBuf64 *vector);                          /* facade32.rs:223-226 */
+ComplexStatistics64 complex_statistics64(const VecBuf64 *vector);                /* facade32.rs:229-232 */
+double real_sum64(const VecBuf64 *vector);                                          /* facade32.rs:235-237 */
+double real_sum_sq64(const VecBuf64 *vector);                                       /* facade32.rs:240-242 */
+bdsp_complex64 complex_sum64(const VecBuf64 *vector);                            /* facade32.rs:245-247 */
+bdsp_complex64 complex_sum_sq64(const VecBuf64 *vector);                         /* facade32.rs:250-252 */
+ScalarInteropResult64 real_dot_product64(const VecBuf64 *vector, const VecBuf64 *operand);             /* facade32.rs:193-201 */
+ComplexScalarInteropResult64 complex_dot_product64(const VecBuf64 *vector, const VecBuf64 *operand);   /* facade32.rs:204-220 */
+Statistics64 real_statistics_prec64(const VecBuf64 *vector);                     /* facade32.rs:292-295 */
+ComplexStatistics64 complex_statistics_prec64(const VecBuf64 *vector);           /* facade32.rs:298-301 */
+double real_sum_prec64(const VecBuf64 *vector);                                  /* facade32.rs:304-306 */
+double real_sum_sq_prec64(const VecBuf64 *vector);                               /* facade32.rs:309-311 */
+bdsp_complex64 complex_sum_prec64(const VecBuf64 *vector);                       /* facade32.rs:314-316 */
+bdsp_complex64 complex_sum_sq_prec64(const VecBuf64 *vector);                    /* facade32.rs:319-321 */
+ScalarInteropResult64 real_dot_product_prec64(const VecBuf64 *vector, const VecBuf64 *operand);            /* facade32.rs:254-270 */
+ComplexScalarInteropResult64 complex_dot_product_prec64(const VecBuf64 *vector, const VecBuf64 *operand);  /* facade32.rs:273-289 */
+/* statistics_split (statistics.rs:389-426): element j goes to bucket j % len with index j / len; len <= 16, else code 7 */
+int32_t real_statistics_split64(const VecBuf64 *vector, Statistics64 *data, size_t len);               /* facade32.rs:848-864 */
+int32_t complex_statistics_split64(const VecBuf64 *vector, ComplexStatistics64 *data, size_t len);     /* facade32.rs:867-886 */
+int32_t real_statistics_split_prec64(const VecBuf64 *vector, Statistics64 *data, size_t len);          /* facade32.rs:889-907 */
+int32_t complex_statistics_split_prec64(const VecBuf64 *vector, ComplexStatistics64 *data, size_t len);/* facade32.rs:910-931 */
+
 /* ========================================================================================
  * B2m -- matrix / batch API: `rows` equally long vectors in one allocation, every operation a
  *        batched launch.  The reference's matrix crate has no C facade; these entry points mirror

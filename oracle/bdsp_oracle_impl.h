@@ -1029,3 +1029,94 @@ void SFX(orc_interpolate_hermite)(const REAL *x, size_t len, REAL factor, REAL d
         i = i + (REAL)1;
     }
 }
+
+/* ------------------------------------------------------------------------------------------
+ * Statistics, sums and dot products (vector/src/vector_types/general/statistics.rs:181-530,
+ * dot_products.rs:67-165), single chunk (the default MultiCoreSettings).
+ * out[0..7] real: sum, count, average, rms, min, min_index, max, max_index
+ * complex: sum.re, sum.im, count, avg.re, avg.im, rms.re, rms.im, min.re, min.im, min_index,
+ *          max.re, max.im, max_index                                    (13 doubles)
+ * Element j of the walk is x[first + j*step]; indices reported are j (statistics_split uses
+ * first = bucket, step = len, :399-426).
+ * ---------------------------------------------------------------------------------------- */
+void SFX(orc_real_statistics)(const REAL *x, size_t len, size_t first, size_t step, double *out)
+{
+    REAL sum = 0, sq = 0, mn = (REAL)INFINITY, mx = -(REAL)INFINITY;
+    size_t cnt = 0, imn = 0, imx = 0;
+    for (size_t i = first, j = 0; i < len; i += step, ++j) {
+        REAL e = x[i];
+        sum = sum + e; cnt += 1; sq = sq + e * e;
+        if (e > mx) { mx = e; imx = j; }
+        if (e < mn) { mn = e; imn = j; }
+    }
+    out[0] = sum; out[1] = (double)cnt; out[2] = sum / (REAL)cnt; out[3] = R_SQRT(sq / (REAL)cnt);
+    out[4] = mn; out[5] = (double)imn; out[6] = mx; out[7] = (double)imx;
+}
+
+static void SFX(csqrt_polar)(REAL re, REAL im, REAL *ore, REAL *oim)
+{
+    /* num-complex 0.4 Complex::sqrt for finite inputs: principal root; purely real / imaginary inputs are special
+     * cased there, the general branch is from_polar(sqrt(r), theta / 2) */
+    if (im == 0) {
+        if (re >= 0) { *ore = R_SQRT(re); *oim = im; } else { *ore = 0; *oim = im < 0 || (1 / im) < 0 ? -R_SQRT(-re) : R_SQRT(-re); }
+        return;
+    }
+    if (re == 0) {
+        REAL x = R_SQRT(R_FABS(im) / (REAL)2);
+        *ore = x; *oim = im > 0 ? x : -x;
+        return;
+    }
+    REAL r = R_HYPOT(re, im), th = R_ATAN2(im, re);
+    *ore = R_SQRT(r) * R_COS(th / (REAL)2);
+    *oim = R_SQRT(r) * R_SIN(th / (REAL)2);
+}
+
+void SFX(orc_complex_statistics)(const REAL *x, size_t len, size_t first, size_t step, double *out)
+{
+    size_t points = len / 2;
+    REAL sr = 0, si = 0, qr = 0, qi = 0;
+    REAL mnr = (REAL)INFINITY, mni = (REAL)INFINITY, mxr = 0, mxi = 0;
+    size_t cnt = 0, imn = 0, imx = 0;
+    for (size_t i = first, j = 0; i < points; i += step, ++j) {
+        REAL re = x[2 * i], im = x[2 * i + 1];
+        sr = sr + re; si = si + im; cnt += 1;
+        qr = qr + (re * re - im * im); qi = qi + (re * im + im * re);
+        if (R_HYPOT(re, im) > R_HYPOT(mxr, mxi)) { mxr = re; mxi = im; imx = j; }
+        if (R_HYPOT(re, im) < R_HYPOT(mnr, mni)) { mnr = re; mni = im; imn = j; }
+    }
+    REAL rr, ri;
+    SFX(csqrt_polar)(qr / (REAL)cnt, qi / (REAL)cnt, &rr, &ri);
+    out[0] = sr; out[1] = si; out[2] = (double)cnt; out[3] = sr / (REAL)cnt; out[4] = si / (REAL)cnt;
+    out[5] = rr; out[6] = ri; out[7] = mnr; out[8] = mni; out[9] = (double)imn; out[10] = mxr; out[11] = mxi;
+    out[12] = (double)imx;
+}
+
+/* sum / sum_sq: out[0..1] (real: out[0]); dot: over min(len) scalars (real) or pairs (complex, no conjugation) */
+void SFX(orc_sum)(const REAL *x, size_t len, int is_complex, int squared, double *out)
+{
+    REAL a = 0, b = 0;
+    if (!is_complex) {
+        for (size_t i = 0; i < len; ++i) a = a + (squared ? x[i] * x[i] : x[i]);
+    } else {
+        for (size_t i = 0; i + 1 < len; i += 2) {
+            REAL re = x[i], im = x[i + 1];
+            if (squared) { a = a + (re * re - im * im); b = b + (re * im + im * re); }
+            else { a = a + re; b = b + im; }
+        }
+    }
+    out[0] = a; out[1] = b;
+}
+
+void SFX(orc_dot)(const REAL *x, const REAL *y, size_t len, int is_complex, double *out)
+{
+    REAL a = 0, b = 0;
+    if (!is_complex) {
+        for (size_t i = 0; i < len; ++i) a = a + x[i] * y[i];
+    } else {
+        for (size_t i = 0; i + 1 < len; i += 2) {
+            a = a + (x[i] * y[i] - x[i + 1] * y[i + 1]);
+            b = b + (x[i] * y[i + 1] + x[i + 1] * y[i]);
+        }
+    }
+    out[0] = a; out[1] = b;
+}

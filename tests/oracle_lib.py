@@ -315,3 +315,35 @@ def interpolate_lin(x, factor, delay=0.0):
 
 def interpolate_hermite(x, factor, delay=0.0):
     return _interp_real("orc_interpolate_hermite", x, factor, delay)
+
+
+def real_statistics(x, first=0, step=1):
+    x = np.ascontiguousarray(x); out = np.zeros(8); fn = _fn("orc_real_statistics", x.dtype)
+    fn.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p]; fn.restype = None
+    fn(_p(x), x.size, first, step, _p(out))
+    return dict(sum=out[0], count=int(out[1]), average=out[2], rms=out[3], min=out[4], min_index=int(out[5]),
+                max=out[6], max_index=int(out[7]))
+
+
+def complex_statistics(x, first=0, step=1):
+    x = np.ascontiguousarray(x); out = np.zeros(13); fn = _fn("orc_complex_statistics", x.dtype)
+    fn.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p]; fn.restype = None
+    fn(_p(x), x.size, first, step, _p(out))
+    return dict(sum=complex(out[0], out[1]), count=int(out[2]), average=complex(out[3], out[4]),
+                rms=complex(out[5], out[6]), min=complex(out[7], out[8]), min_index=int(out[9]),
+                max=complex(out[10], out[11]), max_index=int(out[12]))
+
+
+def vec_sum(x, is_complex, squared=False):
+    x = np.ascontiguousarray(x); out = np.zeros(2); fn = _fn("orc_sum", x.dtype)
+    fn.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p]; fn.restype = None
+    fn(_p(x), x.size, int(is_complex), int(squared), _p(out))
+    return complex(out[0], out[1]) if is_complex else out[0]
+
+
+def dot(x, y, is_complex):
+    x = np.ascontiguousarray(x); y = np.ascontiguousarray(y, dtype=x.dtype); out = np.zeros(2)
+    fn = _fn("orc_dot", x.dtype)
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]; fn.restype = None
+    fn(_p(x), _p(y), min(x.size, y.size), int(is_complex), _p(out))
+    return complex(out[0], out[1]) if is_complex else out[0]

@@ -962,3 +962,59 @@ def test_getters_into_a_destination_vector():
     assert np.array_equal(v.data(), x)  # the Python mirror works on a clone
     d = DspVec(np.zeros(4, np.float32), is_complex=True)
     assert v.get_real(d) == 9 and len(d) == 0  # a complex destination is emptied
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_statistics_sums_dot_products(dtype):
+    # KATs: statistics.rs:44-65, :84-91, :113-128, dot_products.rs:338-388
+    z = DspVec(np.array([1, 2, 3, 4, 5, 6], dtype), is_complex=True)
+    s = z.statistics()
+    assert s["sum"] == 9 + 12j and s["count"] == 3 and s["average"] == 3 + 4j
+    assert abs(s["rms"] - (3.4027193 + 4.3102784j)) < 1e-4
+    assert (s["min"], s["min_index"], s["max"], s["max_index"]) == (1 + 2j, 0, 5 + 6j, 2)
+    code, parts = z.statistics_split(2)
+    assert code == 0 and parts[0]["sum"] == 6 + 8j and parts[1]["sum"] == 3 + 4j
+    assert z.statistics_split(17)[0] == 7
+    assert z.sum() == 9 + 12j and z.sum_sq() == -21 + 88j
+    r = DspVec(np.array([1, 2, 3], dtype))
+    assert r.dot_product(DspVec(np.array([1, 2, 3], dtype))) == (0, 14.0)
+    c = DspVec(np.array([1, 0, 3, 0], dtype), is_complex=True)
+    assert c.dot_product(DspVec(np.array([1, 0, 3, 0], dtype), is_complex=True)) == (0, 10 + 0j)
+    assert c.dot_product(r)[0] == 2 and r.dot_product(r)[0] == 0
+    # large vectors against the oracle (sequential sums in T there, double accumulation here)
+    tol = 2e-5 if dtype == np.float32 else 1e-12
+    for cplx, n in ((False, 1_000_003), (True, 700_001)):
+        e = 2 if cplx else 1
+        x = orc.fill_uniform(n * e, 5 + n, -10, 10, dtype)
+        x[e * 123456] = 77.0   # a unique maximum
+        if not cplx:
+            x[654321] = -88.0  # and a unique minimum
+        v = DspVec(x, is_complex=cplx)
+        got = v.statistics()
+        ref = (orc.complex_statistics if cplx else orc.real_statistics)(x.astype(np.float64))
+        assert got["count"] == ref["count"] == n
+        for k in ("sum", "average", "rms"):
+            assert abs(got[k] - ref[k]) <= tol * max(1.0, abs(ref[k])) * 50, (k, got[k], ref[k])
+        for k in ("min", "max", "min_index", "max_index"):
+            assert got[k] == ref[k], (k, got[k], ref[k])
+        p = v.statistics(prec=True)
+        assert abs(p["sum"] - ref["sum"]) <= 1e-9 * max(1.0, abs(ref["sum"])) * (1e3 if dtype == np.float32 else 1)
+        ssum, ssq = v.sum(), v.sum_sq()
+        rsum, rsq = orc.vec_sum(x.astype(np.float64), cplx), orc.vec_sum(x.astype(np.float64), cplx, True)
+        assert abs(ssum - rsum) <= tol * 50 * max(1.0, abs(rsum)) and abs(ssq - rsq) <= tol * abs(rsq) * 50
+        y = orc.fill_uniform(n * e, 9, -1, 1, dtype)
+        code, d = v.dot_product(DspVec(y, is_complex=cplx))
+        rd = orc.dot(x.astype(np.float64), y.astype(np.float64), cplx)
+        assert code == 0 and abs(d - rd) <= tol * 50 * max(1.0, abs(rd))
+        code, parts = v.statistics_split(3)
+        assert code == 0
+        for b in range(3):
+            rb = (orc.complex_statistics if cplx else orc.real_statistics)(x.astype(np.float64), b, 3)
+            assert parts[b]["count"] == rb["count"] and parts[b]["max_index"] == rb["max_index"]
+            assert parts[b]["min_index"] == rb["min_index"]
+            assert abs(parts[b]["sum"] - rb["sum"]) <= tol * 50 * max(1.0, abs(rb["sum"]))
+    # first occurrence wins ties; an empty vector reports count 0 and NaN averages
+    t = DspVec(np.array([2, 7, 7, -3, -3, 0], dtype)).statistics()
+    assert (t["max_index"], t["min_index"]) == (1, 3)
+    e0 = DspVec(dtype=dtype, length=0).statistics()
+    assert e0["count"] == 0 and np.isnan(e0["average"]) and e0["min"] == np.inf and e0["max"] == -np.inf

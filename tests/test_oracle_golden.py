@@ -453,3 +453,20 @@ def test_real_interpolation_kats():
                                atol=5e-3)
     x = kat("linear_test", 0).astype(np.float32)
     np.testing.assert_allclose(orc.interpolate_lin(x, 4.0), kat("linear_test", 1), atol=0.1)
+
+
+def test_statistics_sums_dot_products_kats():
+    # statistics.rs:44-65 (doc example), :84-91 (split), :113-128 (sum, sum_sq), dot_products.rs:338-388
+    z = np.array([1, 2, 3, 4, 5, 6], np.float32)
+    s = orc.complex_statistics(z)
+    assert s["sum"] == 9 + 12j and s["count"] == 3 and s["average"] == 3 + 4j
+    assert abs(s["rms"] - (3.4027193 + 4.3102784j)) < 1e-4
+    assert (s["min"], s["min_index"], s["max"], s["max_index"]) == (1 + 2j, 0, 5 + 6j, 2)
+    assert orc.complex_statistics(z, 0, 2)["sum"] == 6 + 8j and orc.complex_statistics(z, 1, 2)["sum"] == 3 + 4j
+    assert orc.vec_sum(z, True) == 9 + 12j
+    assert orc.vec_sum(z.astype(np.float64), True, squared=True) == -21 + 88j
+    assert orc.dot(np.array([1, 2, 3], np.float32), np.array([1, 2, 3], np.float32), False) == 14.0
+    assert orc.dot(np.array([1, 0, 3, 0], np.float32), np.array([1, 0, 3, 0], np.float32), True) == 10 + 0j
+    r = orc.real_statistics(np.array([3, -1, 4, -1, 5], np.float32))
+    assert (r["sum"], r["count"], r["min"], r["min_index"], r["max"], r["max_index"]) == (10, 5, -1, 1, 5, 4)
+    assert r["average"] == 2 and abs(r["rms"] - np.sqrt(52 / 5)) < 1e-6
