@@ -144,9 +144,9 @@ struct StatPartial {
     unsigned long long imn, imx, cnt;
 };
 template <typename T>
-int red_stats(const T* x, size_t count, size_t first, size_t step, bool is_complex, bool minmax, StatPartial* partials, hipStream_t s);
+int red_stats(const T* x, size_t total, size_t buckets, bool is_complex, bool minmax, StatPartial* partials, StatPartial* out, hipStream_t s);
 template <typename T>
-int red_dot(const T* x, const T* y, size_t count, bool is_complex, StatPartial* partials, hipStream_t s);
+int red_dot(const T* x, const T* y, size_t count, bool is_complex, StatPartial* partials, StatPartial* out, hipStream_t s);
 
 // bluestein.hip
 template <typename T> int bs_chirp(T* c, size_t n, bool inverse, hipStream_t s);

@@ -1025,19 +1025,29 @@ static void stat_empty(StatPartial& p, bool cplx)
     else { p.mnr = inf; p.mn_key = inf; p.mxr = -inf; p.mx_key = -inf; }
 }
 
+// 16 results in pinned host memory per calling thread: the folding kernel writes them directly, no copy is queued
+static StatPartial* stat_pinned()
+{
+    static thread_local StatPartial* pin = nullptr;
+    if (!pin && hipHostMalloc((void**)&pin, sizeof(StatPartial) * 16, hipHostMallocDefault) != hipSuccess) pin = nullptr;
+    return pin;
+}
+
+// statistics of `buckets` interleaved sub-sequences (1 = the whole vector) into host[0 .. buckets)
 template <typename T>
-int stats_run(const DevVec<T>* v, bool cplx, bool minmax, size_t first, size_t step, StatPartial* host)
+int stats_run(const DevVec<T>* v, bool cplx, bool minmax, size_t buckets, StatPartial* host)
 {
     const size_t units = cplx ? v->valid_len / 2 : v->valid_len;
-    const size_t count = first < units ? (units - first + step - 1) / step : 0;
-    stat_empty(*host, cplx);
-    if (count == 0) return BDSP_OK;
+    for (size_t b = 0; b < buckets; ++b) stat_empty(host[b], cplx);
+    if (units == 0) return BDSP_OK;
     hipStream_t s = lib_stream();
     WsBlock pb;
-    BDSP_TRY(pb.alloc(sizeof(StatPartial) * 1024, s));
-    BDSP_TRY(red_stats<T>(v->data, count, first, step, cplx, minmax, pb.as<StatPartial>(), s));
-    BDSP_HIP_TRY(hipMemcpyAsync(host, pb.p, sizeof(StatPartial), hipMemcpyDeviceToHost, s));
+    BDSP_TRY(pb.alloc(sizeof(StatPartial) * 1024 * buckets, s));
+    StatPartial* pin = stat_pinned();
+    if (!pin) return BDSP_ERR_HIP;
+    BDSP_TRY(red_stats<T>(v->data, units, buckets, cplx, minmax, pb.as<StatPartial>(), pin, s));
     BDSP_HIP_TRY(hipStreamSynchronize(s));
+    std::memcpy(host, pin, sizeof(StatPartial) * buckets);
     return BDSP_OK;
 }
 
@@ -1074,7 +1084,7 @@ S stats_real(const DevVec<T>* v)
 {
     StatPartial p;
     S out;
-    if (stats_run<T>(v, false, true, 0, 1, &p) != BDSP_OK) stat_empty(p, false);
+    if (stats_run<T>(v, false, true, 1, &p) != BDSP_OK) stat_empty(p, false);
     stat_fill_real<S, R>(&out, p);
     return out;
 }
@@ -1083,7 +1093,7 @@ S stats_complex(const DevVec<T>* v)
 {
     StatPartial p;
     S out;
-    if (stats_run<T>(v, true, true, 0, 1, &p) != BDSP_OK) stat_empty(p, true);
+    if (stats_run<T>(v, true, true, 1, &p) != BDSP_OK) stat_empty(p, true);
     stat_fill_complex<S, R>(&out, p);
     return out;
 }
@@ -1092,10 +1102,10 @@ int stats_split(const DevVec<T>* v, S* data, size_t len)
 {
     if (len == 0) return BDSP_OK;
     if (len > 16) return BDSP_ERR_ARG_LENGTH; // STATS_VEC_CAPACTIY (statistics.rs:34, 403-405)
+    StatPartial p[16];
+    BDSP_TRY(stats_run<T>(v, CPLX, true, len, p));
     for (size_t b = 0; b < len; ++b) {
-        StatPartial p;
-        BDSP_TRY(stats_run<T>(v, CPLX, true, b, len, &p));
-        if constexpr (CPLX) stat_fill_complex<S, R>(&data[b], p); else stat_fill_real<S, R>(&data[b], p);
+        if constexpr (CPLX) stat_fill_complex<S, R>(&data[b], p[b]); else stat_fill_real<S, R>(&data[b], p[b]);
     }
     return BDSP_OK;
 }
@@ -1104,7 +1114,7 @@ template <typename T>
 void sums(const DevVec<T>* v, bool cplx, int which, double* re, double* im)
 {
     StatPartial p;
-    if (stats_run<T>(v, cplx, false, 0, 1, &p) != BDSP_OK) stat_empty(p, cplx);
+    if (stats_run<T>(v, cplx, false, 1, &p) != BDSP_OK) stat_empty(p, cplx);
     *re = which ? p.qr : p.sr;
     *im = which ? p.qi : p.si;
 }
@@ -1123,11 +1133,11 @@ int dot(const DevVec<T>* v, const DevVec<T>* o, bool cplx, double* re, double* i
         hipStream_t s = lib_stream();
         WsBlock pb;
         BDSP_TRY(pb.alloc(sizeof(StatPartial) * 1024, s));
-        BDSP_TRY(red_dot<T>(v->data, o->data, count, cplx, pb.as<StatPartial>(), s));
-        StatPartial p;
-        BDSP_HIP_TRY(hipMemcpyAsync(&p, pb.p, sizeof(StatPartial), hipMemcpyDeviceToHost, s));
+        StatPartial* pin = stat_pinned();
+        if (!pin) return BDSP_ERR_HIP;
+        BDSP_TRY(red_dot<T>(v->data, o->data, count, cplx, pb.as<StatPartial>(), pin, s));
         BDSP_HIP_TRY(hipStreamSynchronize(s));
-        *re = p.sr; *im = p.si;
+        *re = pin->sr; *im = pin->si;
     }
     return v->erroneous() ? BDSP_ERR_POISONED : BDSP_OK;
 }

@@ -63,3 +63,19 @@ bench("zero_pad (x2, surround)", cv, lambda v: v.zero_pad(2 * n, V.PAD_SURROUND)
 bench("zero_interleave (x2)", cv, lambda v: v.zero_interleave(2), 3 * B)
 bench("to_complex (real 16M)", rv, lambda v: v.to_complex(), B // 2 + B)
 bench("decimatei (/2)", cv, lambda v: v.decimatei(2, 0), B + B // 2)
+# reductions: read-only passes (the vector is not modified, the handle is reused)
+def bench_ro(name, v, op, bytes_moved, reps=10):
+    op(v)
+    ts = []
+    for k in range(reps):
+        t0 = time.perf_counter()
+        op(v)
+        ts.append(time.perf_counter() - t0)
+    us = sorted(ts)[len(ts) // 2] * 1e6
+    print("%-28s %8.1f us  %6.0f GB/s" % (name, us, bytes_moved / us / 1e3))
+c, r = cv(), rv()
+bench_ro("statistics (complex 16M)", c, lambda v: v.statistics(), B)
+bench_ro("statistics (real 16M)", r, lambda v: v.statistics(), B // 2)
+bench_ro("sum_sq (complex 16M)", c, lambda v: v.sum_sq(), B)
+bench_ro("dot_product (complex 16M)", c, lambda v: v.dot_product(other), 2 * B)
+bench_ro("statistics_split(4)", c, lambda v: v.statistics_split(4), B)
