@@ -30,6 +30,13 @@ class Complex64(C.Structure):
     _fields_ = [("re", C.c_double), ("im", C.c_double)]
 
 
+class PointerInteropResult(C.Structure):
+    _fields_ = [("result_code", C.c_int32), ("result", C.c_void_p)]
+
+
+AGG_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_void_p)
+
+
 def _stats_struct(name, scalar):
     """#[repr(C)] Statistics<T> (vector/src/vector_types/general/statistics.rs:11-31)."""
     return type(name, (C.Structure,), {"_fields_": [
@@ -197,6 +204,46 @@ for _s, _t, _R in (("32", _F, VectorInteropResult32), ("64", _D, VectorInteropRe
     _proto("complex_statistics_split" + _s, C.c_int32, _P, C.POINTER(_CST), _SZ)
     _proto("real_statistics_split_prec" + _s, C.c_int32, _P, C.POINTER(Statistics64), _SZ)
     _proto("complex_statistics_split_prec" + _s, C.c_int32, _P, C.POINTER(ComplexStatistics64), _SZ)
+    # per-element math family, differences / running sums, pairs, split / merge, callbacks
+    _VR = VectorInteropResult32 if _s == "32" else VectorInteropResult64
+    for _n in ("sqrt", "square", "ln", "exp", "sin", "cos", "tan", "asin", "acos", "atan", "sinh", "cosh", "tanh",
+               "asinh", "acosh", "atanh", "abs", "ln_approx", "exp_approx", "sin_approx", "cos_approx", "diff",
+               "diff_with_start", "cum_sum"):
+        _proto(_n + _s, _VR, _P)
+    for _n in ("powf", "root", "log", "expf", "wrap", "unwrap", "log_approx", "expf_approx", "powf_approx"):
+        _proto(_n + _s, _VR, _P, _t)
+    MAP_REAL_FN = C.CFUNCTYPE(_t, _t, _SZ)
+    # ctypes cannot build callbacks that RETURN structs: the complex-valued callbacks go through the library's
+    # bridges (pointer-style Python callback behind a C function with the facade's signature)
+    COMPLEX_PTR_FN = C.CFUNCTYPE(None, _P, _t, C.POINTER(_t))
+    MAP_COMPLEX_PTR_FN = C.CFUNCTYPE(None, _t, _t, _SZ, C.POINTER(_t))
+    ComplexBridge = type("ComplexBridge" + _s, (C.Structure,), {"_fields_": [("fn", COMPLEX_PTR_FN), ("ctx", _P)]})
+    MAP_COMPLEX_FN = _P
+    COMPLEX_FN = _P
+    _proto("bdsp_hip_set_map_complex_bridge" + _s, None, MAP_COMPLEX_PTR_FN)
+    AGG_MAP_REAL_FN = C.CFUNCTYPE(_P, _t, _SZ)
+    AGG_MAP_COMPLEX_FN = C.CFUNCTYPE(_P, _CX, _SZ)
+    AGG_FN = C.CFUNCTYPE(_P, _P, _P)
+    _REALFN = C.CFUNCTYPE(_t, _P, _t)
+    globals().update({"MAP_REAL_FN" + _s: MAP_REAL_FN, "MAP_COMPLEX_FN" + _s: MAP_COMPLEX_FN,
+                      "COMPLEX_PTR_FN" + _s: COMPLEX_PTR_FN, "MAP_COMPLEX_PTR_FN" + _s: MAP_COMPLEX_PTR_FN,
+                      "ComplexBridge" + _s: ComplexBridge, "AGG_MAP_REAL_FN" + _s: AGG_MAP_REAL_FN,
+                      "AGG_MAP_COMPLEX_FN" + _s: AGG_MAP_COMPLEX_FN})
+    _proto("map_inplace_real" + _s, _VR, _P, MAP_REAL_FN)
+    _proto("map_inplace_complex" + _s, _VR, _P, MAP_COMPLEX_FN)
+    _proto("map_aggregate_real" + _s, PointerInteropResult, _P, AGG_MAP_REAL_FN, AGG_FN)
+    _proto("map_aggregate_complex" + _s, PointerInteropResult, _P, AGG_MAP_COMPLEX_FN, AGG_FN)
+    _proto("get_real_imag" + _s, C.c_int32, _P, _P, _P)
+    _proto("get_mag_phase" + _s, C.c_int32, _P, _P, _P)
+    _proto("set_real_imag" + _s, _VR, _P, _P, _P)
+    _proto("set_mag_phase" + _s, _VR, _P, _P, _P)
+    _proto("split_into" + _s, C.c_int32, _P, C.POINTER(_P), _SZ)
+    _proto("merge" + _s, _VR, _P, C.POINTER(_P), _SZ)
+    _proto("convolve_complex" + _s, _VR, _P, COMPLEX_FN, _P, C.c_bool, _t, _SZ)
+    _proto("multiply_frequency_response_complex" + _s, _VR, _P, COMPLEX_FN, _P, C.c_bool, _t)
+    _proto("interpolatef_custom" + _s, _VR, _P, _REALFN, _P, C.c_bool, _t, _t, _SZ)
+    _proto("interpolate_custom" + _s, _VR, _P, _REALFN, _P, C.c_bool, _SZ, _t)
+    _proto("interpolatei_custom" + _s, _VR, _P, _REALFN, _P, C.c_bool, C.c_int32)
     # matrix / batch API
     _m = "bdsp_hip_mat_"
     _proto(_m + "new" + _s, _P, C.c_int32, C.c_int32, _SZ, _SZ, _t)

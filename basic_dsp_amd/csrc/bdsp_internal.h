@@ -129,14 +129,31 @@ template <typename T> int rg_decimate(const T* in, T* out, size_t out_points, si
 // interp.hip
 template <typename T>
 int interpolatef_dev(const T* in, T* out, size_t len, bool is_complex, int fid, T rolloff, T factor,
-                     T delay, size_t conv_len, T delta, hipStream_t s);
+                     T delay, size_t conv_len, T delta, hipStream_t s,
+                     T (*host_fn)(const void*, T) = nullptr, const void* host_fn_data = nullptr);
 template <typename T> size_t interpolatef_new_len(size_t len, T factor);
 template <typename T> int conv_function_taps(T* taps, size_t conv_len, int fid, T rolloff, T ratio, int stride, bool reversed, hipStream_t s);
-template <typename T> int conv_function_direct(const T* in, T* out, size_t points, bool is_complex, const T* taps, size_t conv_len, hipStream_t s);
+template <typename T> int conv_function_direct(const T* in, T* out, size_t points, bool is_complex, const T* taps, size_t conv_len, hipStream_t s,
+                                                   bool complex_taps = false);
 template <typename T> size_t interpolate_real_len(size_t len, T factor);
 template <typename T> int interpolate_real_dev(const T* in, T* out, size_t len, T factor, T delay, bool hermite, hipStream_t s);
 
 // reduce.hip: what one walk over a vector accumulates (sums in double; min / max with their keys and indices)
+// per-element math family ids (vecmath.hip); the oracle uses the same numbering
+enum MathFn {
+    MATH_SQRT = 0, MATH_SQUARE, MATH_POWF, MATH_LN, MATH_EXP, MATH_LOG, MATH_EXPF, MATH_SIN, MATH_COS, MATH_TAN,
+    MATH_ASIN, MATH_ACOS, MATH_ATAN, MATH_SINH, MATH_COSH, MATH_TANH, MATH_ASINH, MATH_ACOSH, MATH_ATANH, MATH_ABS,
+    MATH_WRAP, MATH_EXPF_APPROX, MATH_POWF_APPROX
+};
+template <typename T> int ew_math(T* x, size_t len, bool is_complex, int fn, T arg, hipStream_t s);
+template <typename T> int vm_diff(const T* in, T* out, size_t n_out, size_t step, bool with_start, hipStream_t s);
+template <typename T> size_t vm_cum_sum_scratch(size_t len, bool is_complex);
+template <typename T> int vm_cum_sum(T* x, size_t len, bool is_complex, void* scratch, hipStream_t s);
+template <typename T> int vm_unwrap(T* x, size_t len, T divisor, hipStream_t s);
+template <typename T> int vm_complex_split(const T* x, T* a, T* b, size_t points, int kind, hipStream_t s);
+template <typename T> int vm_complex_join(T* x, const T* a, const T* b, size_t points, int kind, hipStream_t s);
+template <typename T> int vm_split_merge(T* whole, T* const* parts_dev, size_t len, bool is_complex, size_t n, bool merge, hipStream_t s);
+
 struct StatPartial {
     double sr, si, qr, qi;       // sum, sum of squares (complex: z*z, not |z|^2 -- statistics.rs:344)
     double mn_key, mx_key;       // ordering keys: the value (real) or its norm (complex)

@@ -559,13 +559,14 @@ int op_convolve_signal(DevVec<T>* v, const DevVec<T>* h)
 }
 
 template <typename T>
-int op_interpolatef(DevVec<T>* v, int fid, T rolloff, T factor, T delay, size_t conv_len)
+int op_interpolatef(DevVec<T>* v, int fid, T rolloff, T factor, T delay, size_t conv_len,
+                    T (*host_fn)(const void*, T) = nullptr, const void* host_fn_data = nullptr)
 {
     size_t new_len = interpolatef_new_len<T>(v->valid_len, factor);
     BDSP_TRY(v->reserve(new_len > v->valid_len ? new_len : v->valid_len));
     if (v->valid_len == 0) return BDSP_OK;
     BDSP_TRY(interpolatef_dev<T>(v->data, v->buf, v->valid_len, v->complex_, fid, rolloff, factor, delay,
-                                 conv_len, v->delta, lib_stream()));
+                                 conv_len, v->delta, lib_stream(), host_fn, host_fn_data));
     v->trade();
     v->valid_len = new_len; // interpolation.rs:481; delta is left alone by interpolatef
     return BDSP_OK;
@@ -643,11 +644,59 @@ int op_window(DevVec<T>* v, int window, bool unapply)
 }
 
 
+// A host callback standing in for a built-in frequency response / impulse response (the *_custom and *_complex
+// facade variants, interop/src/lib.rs:245-377): sampled on the host into a table, applied on the device.
+template <typename T> struct CRet { T re, im; }; // #[repr(C)] Complex<T> returned by value
+template <typename T> struct Sampler {
+    T (*rfn)(const void*, T) = nullptr;
+    CRet<T> (*cfn)(const void*, T) = nullptr;
+    const void* data = nullptr;
+    bool symmetric = false;
+};
+
+template <typename T>
+int upload_table(WsBlock& tb, const std::vector<T>& h, hipStream_t s);
+
+// multiply_function_priv (time_freq/mod.rs:612-723) with a sampled function: element i is multiplied by
+// ratio * f(fft_swap_x(shifted, j, max) * ratio), j = -max + i (a symmetric function is only evaluated for j <= 0)
+template <typename T>
+int apply_sampled_response(T* x, size_t len, bool is_complex, const Sampler<T>& f, T ratio, bool shifted, hipStream_t s)
+{
+    const size_t points = is_complex ? len / 2 : len;
+    if (points == 0) return BDSP_OK;
+    const T maxv = (T)(points - points % 2) / (T)2;
+    auto axis = [&](size_t i) {
+        T j = -maxv + (T)i;
+        if (f.symmetric && j > (T)0) j = -j;
+        T xs;
+        if (!shifted) xs = j / maxv;                       // fft_swap_x, mod.rs:67-77
+        else if (j <= (T)0) xs = (T)1 + j / maxv;
+        else xs = -(maxv - j + (T)1) / maxv;
+        return xs * ratio;
+    };
+    WsBlock tb;
+    if (f.cfn) {
+        if (!is_complex) return BDSP_ERR_MUST_BE_COMPLEX;
+        std::vector<T> h(2 * points);
+        for (size_t i = 0; i < points; ++i) {
+            const CRet<T> v = f.cfn(f.data, axis(i));
+            h[2 * i] = ratio * v.re;
+            h[2 * i + 1] = ratio * v.im;
+        }
+        BDSP_TRY(upload_table<T>(tb, h, s));
+        return ew_binary<T>(x, tb.as<T>(), len, true, 2, s);
+    }
+    std::vector<T> h(points);
+    for (size_t i = 0; i < points; ++i) h[i] = ratio * f.rfn(f.data, axis(i));
+    BDSP_TRY(upload_table<T>(tb, h, s));
+    return ew_point_table<T>(x, len, is_complex, tb.as<T>(), false, s);
+}
+
 // ---- FFT-domain interpolation family, composed from the fused kernels -----------
 // interpolatei (interpolation.rs:484-532): zero_interleave -> plain_fft -> x frequency response on the
 // fft-shifted axis (scaled by the factor) -> plain_ifft -> scale(1/points) [-> real parts]
 template <typename T>
-int op_interpolatei(DevVec<T>* v, int fid, T rolloff, int factor)
+int op_interpolatei(DevVec<T>* v, int fid, T rolloff, int factor, const Sampler<T>* custom = nullptr)
 {
     if (factor <= 1) return BDSP_OK;
     hipStream_t s = lib_stream();
@@ -663,7 +712,8 @@ int op_interpolatei(DevVec<T>* v, int fid, T rolloff, int factor)
     bool in_b = false;
     BDSP_TRY(fft_two_buffers<T>(v->data, v->buf, np, 1, false, 0, (T)1, -1, (T)0, &in_b, s));
     if (in_b) v->trade();
-    BDSP_TRY(ew_freq_response<T>(v->data, 2 * np, true, fid, rolloff, (T)factor, true, s));
+    if (custom) BDSP_TRY(apply_sampled_response<T>(v->data, 2 * np, true, *custom, (T)factor, true, s));
+    else BDSP_TRY(ew_freq_response<T>(v->data, 2 * np, true, fid, rolloff, (T)factor, true, s));
     // plain_ifft then scale(1/points): the scale rides on the inverse transform's input
     BDSP_TRY(fft_two_buffers<T>(v->data, v->buf, np, 1, true, 0, (T)1 / (T)np, -1, (T)0, &in_b, s));
     if (in_b) v->trade();
@@ -679,7 +729,7 @@ int op_interpolatei(DevVec<T>* v, int fid, T rolloff, int factor)
 
 // interpolate / interpft (interpolation.rs:534-605).  fid < 0 = no frequency response.
 template <typename T>
-int op_interpolate(DevVec<T>* v, int fid, T rolloff, size_t dest_points, T delay)
+int op_interpolate(DevVec<T>* v, int fid, T rolloff, size_t dest_points, T delay, const Sampler<T>* custom = nullptr)
 {
     hipStream_t s = lib_stream();
     const bool was_complex = v->complex_;
@@ -700,7 +750,8 @@ int op_interpolate(DevVec<T>* v, int fid, T rolloff, size_t dest_points, T delay
     if (dest_points > points) {
         BDSP_TRY(rg_zero_pad<T>(v->data, v->buf, 2 * points, true, dest_points, 2, s));
         v->trade();
-        if (fid < 0) BDSP_TRY(ew_real_scale<T>(v->data, 2 * dest_points, factorf, s));
+        if (custom) BDSP_TRY(apply_sampled_response<T>(v->data, 2 * dest_points, true, *custom, factorf, true, s));
+        else if (fid < 0) BDSP_TRY(ew_real_scale<T>(v->data, 2 * dest_points, factorf, s));
         else BDSP_TRY(ew_freq_response<T>(v->data, 2 * dest_points, true, fid, rolloff, factorf, true, s));
     } else if (dest_points < points) {
         // interpolate_downsample (:362-376): keep the first pos and the last neg bins
@@ -805,7 +856,8 @@ int op_sifft(DevVec<T>* v, bool shift, int window)
 // vectors (:148-172) builds its tap vector with 1/ratio instead of ratio and fills every other tap of a
 // real vector only; the convolve_function_priv semantics are the documented ones and are used throughout.
 template <typename T>
-int op_convolve_function(DevVec<T>* v, int fid, T rolloff, T ratio, size_t conv_len, const T* host_taps)
+int op_convolve_function(DevVec<T>* v, int fid, T rolloff, T ratio, size_t conv_len, const T* host_taps,
+                         bool complex_taps = false)
 {
     if (v->freq) { v->poison(); return BDSP_OK; } // assert_time! (convolution.rs:95-102)
     const size_t points = v->points();
@@ -814,18 +866,22 @@ int op_convolve_function(DevVec<T>* v, int fid, T rolloff, T ratio, size_t conv_
     if (conv_len > points) conv_len = points; // mod.rs:197
     const size_t ntaps = 2 * conv_len + 1;
     const bool as_taps = ntaps <= points;
-    const int stride = (as_taps && v->complex_) ? 2 : 1;
+    const int stride = ((as_taps && v->complex_) || complex_taps) ? 2 : 1;
     WsBlock tb;
     BDSP_TRY(tb.alloc(sizeof(T) * ntaps * stride, s));
     if (host_taps) {
         std::vector<T> h(ntaps * stride, (T)0);
-        for (size_t k = 0; k < ntaps; ++k) h[(as_taps ? ntaps - 1 - k : k) * stride] = host_taps[k];
+        for (size_t k = 0; k < ntaps; ++k) {
+            const size_t at = (as_taps ? ntaps - 1 - k : k) * stride;
+            if (complex_taps) { h[at] = host_taps[2 * k]; h[at + 1] = host_taps[2 * k + 1]; }
+            else h[at] = host_taps[k];
+        }
         BDSP_HIP_TRY(hipMemcpyAsync(tb.p, h.data(), sizeof(T) * h.size(), hipMemcpyHostToDevice, s));
         BDSP_HIP_TRY(hipStreamSynchronize(s));
     } else {
         BDSP_TRY(conv_function_taps<T>(tb.as<T>(), conv_len, fid, rolloff, ratio, stride, as_taps, s));
     }
-    if (!as_taps) BDSP_TRY(conv_function_direct<T>(v->data, v->buf, points, v->complex_, tb.as<T>(), conv_len, s));
+    if (!as_taps) BDSP_TRY(conv_function_direct<T>(v->data, v->buf, points, v->complex_, tb.as<T>(), conv_len, s, complex_taps));
     else if (v->complex_) BDSP_TRY(conv_complex_dev<T>(v->data, v->buf, points, 1, tb.as<T>(), ntaps, s));
     else BDSP_TRY(conv_real_dev<T>(v->data, v->buf, points, tb.as<T>(), ntaps, s));
     v->trade();
@@ -1000,6 +1056,33 @@ int op_convolve_callback(DevVec<T>* v, T (*fun)(const void*, T), const void* dat
     return op_convolve_function<T>(v, 0, (T)0, ratio, conv_len, h.data());
 }
 
+// convolve_complex (convolution.rs:204-254): complex vector, complex impulse response callback
+template <typename T>
+int op_convolve_callback_complex(DevVec<T>* v, CRet<T> (*fun)(const void*, T), const void* data, T ratio, size_t conv_len)
+{
+    if (!v->complex_) { v->poison(); return BDSP_OK; } // assert_complex!
+    const size_t points = v->points();
+    if (conv_len > points) conv_len = points;
+    std::vector<T> h(2 * (2 * conv_len + 1));
+    T j = -(T)conv_len;
+    for (size_t k = 0; k < 2 * conv_len + 1; ++k) {
+        const CRet<T> w = fun(data, -j * ratio);
+        h[2 * k] = w.re; h[2 * k + 1] = w.im;
+        j = j + (T)1;
+    }
+    return op_convolve_function<T>(v, 0, (T)0, ratio, conv_len, h.data(), true);
+}
+
+// multiply_frequency_response_complex (convolution.rs:578-610): complex frequency-domain vector
+template <typename T>
+int op_custom_frequency_response_complex(DevVec<T>* v, CRet<T> (*fun)(const void*, T), const void* data, bool symmetric, T ratio)
+{
+    if (!v->complex_ || !v->freq) { v->poison(); return BDSP_OK; }
+    Sampler<T> sm;
+    sm.cfn = fun; sm.data = data; sm.symmetric = symmetric;
+    return apply_sampled_response<T>(v->data, v->valid_len, true, sm, ratio, false, lib_stream());
+}
+
 template <typename T>
 const T* vec_download(DevVec<T>* v)
 {
@@ -1011,6 +1094,162 @@ const T* vec_download(DevVec<T>* v)
     }
     if (hipStreamSynchronize(s) != hipSuccess) return nullptr;
     return v->mirror.data();
+}
+
+// ----------------------------------------------------------------------------------------------
+// Per-element math family, differences / running sums, phase wrapping, real<->complex pairs, split / merge
+// (vecmath.hip).  Number-space rules follow the reference: the RealOps family (abs, wrap, unwrap, *_approx)
+// poisons a complex vector (real_ops.rs:222-233), TrigOps / PowerOps accept both.
+// ----------------------------------------------------------------------------------------------
+template <typename T>
+int op_math(DevVec<T>* v, int fn, T arg, bool real_only)
+{
+    if (real_only && v->complex_) { v->poison(); return BDSP_OK; }
+    return ew_math<T>(v->data, v->valid_len, v->complex_, fn, arg, lib_stream());
+}
+
+// diff (diff_sum.rs:65-82) drops the first element; diff_with_start (:84-108) keeps it.  An empty vector stays
+// empty (the reference underflows valid_len there).
+template <typename T>
+int op_diff(DevVec<T>* v, bool with_start)
+{
+    const size_t step = v->complex_ ? 2 : 1;
+    if (v->valid_len < step) return BDSP_OK;
+    const size_t n_out = with_start ? v->valid_len : v->valid_len - step;
+    BDSP_TRY(vm_diff<T>(v->data, v->buf, n_out, step, with_start, lib_stream()));
+    v->trade();
+    v->valid_len = n_out;
+    return BDSP_OK;
+}
+
+template <typename T>
+int op_cum_sum(DevVec<T>* v)
+{
+    if (v->valid_len == 0) return BDSP_OK;
+    hipStream_t s = lib_stream();
+    WsBlock sc;
+    BDSP_TRY(sc.alloc(vm_cum_sum_scratch<T>(v->valid_len, v->complex_), s));
+    return vm_cum_sum<T>(v->data, v->valid_len, v->complex_, sc.p, s);
+}
+
+template <typename T>
+int op_unwrap(DevVec<T>* v, T divisor)
+{
+    if (v->complex_) { v->poison(); return BDSP_OK; }
+    return vm_unwrap<T>(v->data, v->valid_len, divisor, lib_stream());
+}
+
+// get_real_imag / get_mag_phase (complex_to_real.rs:674-712): both targets are resized to `points` reals; a real
+// source or a complex target empties both.  The source is consumed; the facade answers convert_void(Ok) = 9.
+template <typename T>
+int op_get_pair(DevVec<T>* v, DevVec<T>* a, DevVec<T>* b, int kind)
+{
+    int rc = BDSP_OK;
+    if (!v->complex_ || a->complex_ || b->complex_) {
+        a->valid_len = 0; b->valid_len = 0;
+    } else {
+        const size_t points = v->points();
+        rc = a->reserve(points ? points : 1);
+        if (rc == BDSP_OK) rc = b->reserve(points ? points : 1);
+        if (rc == BDSP_OK) rc = vm_complex_split<T>(v->data, a->data, b->data, points, kind, lib_stream());
+        if (rc == BDSP_OK) { a->valid_len = points; b->valid_len = points; }
+    }
+    delete v;
+    return rc == BDSP_OK ? 9 : rc;
+}
+
+// set_real_imag / set_mag_phase (complex_to_real.rs:726-770): code 7 unless both arguments have the same length
+template <typename T>
+int op_set_pair(DevVec<T>* v, const DevVec<T>* a, const DevVec<T>* b, int kind)
+{
+    if (a->valid_len != b->valid_len) return BDSP_ERR_ARG_LENGTH;
+    const size_t points = a->valid_len;
+    BDSP_TRY(v->reserve(2 * points ? 2 * points : 1));
+    BDSP_TRY(vm_complex_join<T>(v->data, a->data, b->data, points, kind, lib_stream()));
+    v->valid_len = 2 * points;
+    return BDSP_OK;
+}
+
+template <typename T>
+int upload_parts(WsBlock& tb, DevVec<T>* const* parts, size_t n, hipStream_t s)
+{
+    std::vector<T*> h(n);
+    for (size_t k = 0; k < n; ++k) h[k] = parts[k]->data;
+    BDSP_TRY(tb.alloc(sizeof(T*) * n, s));
+    BDSP_HIP_TRY(hipMemcpyAsync(tb.p, h.data(), sizeof(T*) * n, hipMemcpyHostToDevice, s));
+    BDSP_HIP_TRY(hipStreamSynchronize(s));
+    return BDSP_OK;
+}
+
+// split_into (data_reorganization.rs:484-512): every target is resized to len / n (13 for an odd length on a
+// complex target), element i goes to target i % n, position i / n.  convert_void: 9 on success.
+template <typename T>
+int op_split_into(const DevVec<T>* v, DevVec<T>* const* targets, size_t n)
+{
+    if (n == 0 || v->valid_len % n != 0) return BDSP_ERR_ARG_LENGTH;
+    const size_t tlen = v->valid_len / n;
+    for (size_t k = 0; k < n; ++k) {
+        if (targets[k]->complex_ && tlen % 2 != 0) return BDSP_ERR_EVEN_LENGTH;
+        BDSP_TRY(targets[k]->reserve(tlen ? tlen : 1));
+        targets[k]->valid_len = tlen;
+    }
+    if (tlen == 0) return 9;
+    if (v->complex_ && tlen % 2 != 0) return BDSP_ERR_ARG_LENGTH; // complex points do not divide evenly
+    hipStream_t s = lib_stream();
+    WsBlock tb;
+    BDSP_TRY(upload_parts<T>(tb, targets, n, s));
+    BDSP_TRY(vm_split_merge<T>(v->data, tb.as<T*>(), v->valid_len, v->complex_, n, false, s));
+    return 9;
+}
+
+// merge (data_reorganization.rs:522-555): the inverse; all sources must have the same length
+template <typename T>
+int op_merge(DevVec<T>* v, DevVec<T>* const* sources, size_t n)
+{
+    if (n == 0) return BDSP_ERR_ARG_LENGTH;
+    for (size_t k = 1; k < n; ++k)
+        if (sources[k]->valid_len != sources[0]->valid_len) return BDSP_ERR_ARG_LENGTH;
+    const size_t len = sources[0]->valid_len * n;
+    if (v->complex_ && len % 2 != 0) return BDSP_ERR_EVEN_LENGTH;
+    BDSP_TRY(v->reserve(len ? len : 1));
+    v->valid_len = len;
+    if (len == 0) return BDSP_OK;
+    if (v->complex_ && sources[0]->valid_len % 2 != 0) return BDSP_ERR_ARG_LENGTH;
+    hipStream_t s = lib_stream();
+    WsBlock tb;
+    BDSP_TRY(upload_parts<T>(tb, sources, n, s));
+    return vm_split_merge<T>(v->data, tb.as<T*>(), len, v->complex_, n, true, s);
+}
+
+// map_inplace / map_aggregate (mapping.rs:53-79, 92-140, 163-190, 203-250): the callback is host code, so the
+// vector makes one round trip -- download, one call per element in index order, upload.
+template <typename T, typename F>
+int op_map_inplace(DevVec<T>* v, bool want_complex, F&& per_element)
+{
+    if (v->complex_ != want_complex) { v->poison(); return BDSP_OK; }
+    if (v->valid_len == 0) return BDSP_OK;
+    hipStream_t s = lib_stream();
+    std::vector<T> h(v->valid_len);
+    BDSP_HIP_TRY(hipMemcpyAsync(h.data(), v->data, sizeof(T) * h.size(), hipMemcpyDeviceToHost, s));
+    BDSP_HIP_TRY(hipStreamSynchronize(s));
+    per_element(h);
+    BDSP_HIP_TRY(hipMemcpyAsync(v->data, h.data(), sizeof(T) * h.size(), hipMemcpyHostToDevice, s));
+    BDSP_HIP_TRY(hipStreamSynchronize(s));
+    return BDSP_OK;
+}
+
+template <typename T, typename F>
+int op_map_aggregate(const DevVec<T>* v, bool want_complex, const void** result, F&& fold)
+{
+    *result = nullptr;
+    if (v->complex_ != want_complex) return want_complex ? BDSP_ERR_MUST_BE_COMPLEX : BDSP_ERR_MUST_BE_REAL;
+    if (v->valid_len == 0) return BDSP_ERR_NOT_EMPTY;
+    hipStream_t s = lib_stream();
+    std::vector<T> h(v->valid_len);
+    BDSP_HIP_TRY(hipMemcpyAsync(h.data(), v->data, sizeof(T) * h.size(), hipMemcpyDeviceToHost, s));
+    BDSP_HIP_TRY(hipStreamSynchronize(s));
+    *result = fold(h);
+    return v->erroneous() ? BDSP_ERR_POISONED : BDSP_OK;
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -1576,6 +1815,225 @@ size_t bdsp_hip_overlap_discard_f64(double* x_time, size_t x_len, double* tmp, s
 BDSP_FACADE(32, float, VecBuf32, VectorInteropResult32)
 BDSP_FACADE(64, double, VecBuf64, VectorInteropResult64)
 #undef BDSP_FACADE
+
+// ---------------------------------------------------------------------------------------------- math family, pairs, split / merge, callbacks
+// (one block per precision, generated from the same template)
+VectorInteropResult32 sqrt32(VecBuf32* vector) { DevVec<float>* v = H<float>(vector); return finish<float>(v, op_math<float>(v, MATH_SQRT, (float)0, false)); }
+VectorInteropResult32 square32(VecBuf32* vector) { DevVec<float>* v = H<float>(vector); return finish<float>(v, op_math<float>(v, MATH_SQUARE, (float)0, false)); }
+VectorInteropResult32 ln32(VecBuf32* vector) { DevVec<float>* v = H<float>(vector); return finish<float>(v, op_math<float>(v, MATH_LN, (float)0, false)); }
+VectorInteropResult32 exp32(VecBuf32* vector) { DevVec<float>* v = H<float>(vector); return finish<float>(v, op_math<float>(v, MATH_EXP, (float)0, false)); }
+VectorInteropResult32 sin32(VecBuf32* vector) { DevVec<float>* v = H<float>(vector); return finish<float>(v, op_math<float>(v, MATH_SIN, (float)0, false)); }
+VectorInteropResult32 cos32(VecBuf32* vector) { DevVec<float>* v = H<float>(vector); return finish<float>(v, op_math<float>(v, MATH_COS, (float)0, false)); }
+VectorInteropResult32 tan32(VecBuf32* vector) { DevVec<float>* v = H<float>(vector); return finish<float>(v, op_math<float>(v, MATH_TAN, (float)0, false)); }
+VectorInteropResult32 asin32(VecBuf32* vector) { DevVec<float>* v = H<float>(vector); return finish<float>(v, op_math<float>(v, MATH_ASIN, (float)0, false)); }
+VectorInteropResult32 acos32(VecBuf32* vector) { DevVec<float>* v = H<float>(vector); return finish<float>(v, op_math<float>(v, MATH_ACOS, (float)0, false)); }
+VectorInteropResult32 atan32(VecBuf32* vector) { DevVec<float>* v = H<float>(vector); return finish<float>(v, op_math<float>(v, MATH_ATAN, (float)0, false)); }
+VectorInteropResult32 sinh32(VecBuf32* vector) { DevVec<float>* v = H<float>(vector); return finish<float>(v, op_math<float>(v, MATH_SINH, (float)0, false)); }
+VectorInteropResult32 cosh32(VecBuf32* vector) { DevVec<float>* v = H<float>(vector); return finish<float>(v, op_math<float>(v, MATH_COSH, (float)0, false)); }
+VectorInteropResult32 tanh32(VecBuf32* vector) { DevVec<float>* v = H<float>(vector); return finish<float>(v, op_math<float>(v, MATH_TANH, (float)0, false)); }
+VectorInteropResult32 asinh32(VecBuf32* vector) { DevVec<float>* v = H<float>(vector); return finish<float>(v, op_math<float>(v, MATH_ASINH, (float)0, false)); }
+VectorInteropResult32 acosh32(VecBuf32* vector) { DevVec<float>* v = H<float>(vector); return finish<float>(v, op_math<float>(v, MATH_ACOSH, (float)0, false)); }
+VectorInteropResult32 atanh32(VecBuf32* vector) { DevVec<float>* v = H<float>(vector); return finish<float>(v, op_math<float>(v, MATH_ATANH, (float)0, false)); }
+VectorInteropResult32 abs32(VecBuf32* vector) { DevVec<float>* v = H<float>(vector); return finish<float>(v, op_math<float>(v, MATH_ABS, (float)0, true)); }
+VectorInteropResult32 ln_approx32(VecBuf32* vector) { DevVec<float>* v = H<float>(vector); return finish<float>(v, op_math<float>(v, MATH_LN, (float)0, true)); }
+VectorInteropResult32 exp_approx32(VecBuf32* vector) { DevVec<float>* v = H<float>(vector); return finish<float>(v, op_math<float>(v, MATH_EXP, (float)0, true)); }
+VectorInteropResult32 sin_approx32(VecBuf32* vector) { DevVec<float>* v = H<float>(vector); return finish<float>(v, op_math<float>(v, MATH_SIN, (float)0, true)); }
+VectorInteropResult32 cos_approx32(VecBuf32* vector) { DevVec<float>* v = H<float>(vector); return finish<float>(v, op_math<float>(v, MATH_COS, (float)0, true)); }
+VectorInteropResult32 bdsp_powf32(VecBuf32* vector, float value) { DevVec<float>* v = H<float>(vector); return finish<float>(v, op_math<float>(v, MATH_POWF, value, false)); }
+VectorInteropResult32 log32(VecBuf32* vector, float value) { DevVec<float>* v = H<float>(vector); return finish<float>(v, op_math<float>(v, MATH_LOG, value, false)); }
+VectorInteropResult32 bdsp_expf32(VecBuf32* vector, float value) { DevVec<float>* v = H<float>(vector); return finish<float>(v, op_math<float>(v, MATH_EXPF, value, false)); }
+VectorInteropResult32 wrap32(VecBuf32* vector, float value) { DevVec<float>* v = H<float>(vector); return finish<float>(v, op_math<float>(v, MATH_WRAP, value, true)); }
+VectorInteropResult32 log_approx32(VecBuf32* vector, float value) { DevVec<float>* v = H<float>(vector); return finish<float>(v, op_math<float>(v, MATH_LOG, value, true)); }
+VectorInteropResult32 expf_approx32(VecBuf32* vector, float value) { DevVec<float>* v = H<float>(vector); return finish<float>(v, op_math<float>(v, MATH_EXPF_APPROX, value, true)); }
+VectorInteropResult32 powf_approx32(VecBuf32* vector, float value) { DevVec<float>* v = H<float>(vector); return finish<float>(v, op_math<float>(v, MATH_POWF_APPROX, value, true)); }
+VectorInteropResult32 root32(VecBuf32* vector, float value) { DevVec<float>* v = H<float>(vector); return finish<float>(v, op_math<float>(v, MATH_POWF, (float)1 / value, false)); } // powf(1/degree), trigonometry_and_powers.rs:384-386
+VectorInteropResult32 diff32(VecBuf32* vector) { DevVec<float>* v = H<float>(vector); return finish<float>(v, op_diff<float>(v, false)); }
+VectorInteropResult32 diff_with_start32(VecBuf32* vector) { DevVec<float>* v = H<float>(vector); return finish<float>(v, op_diff<float>(v, true)); }
+VectorInteropResult32 cum_sum32(VecBuf32* vector) { DevVec<float>* v = H<float>(vector); return finish<float>(v, op_cum_sum<float>(v)); }
+VectorInteropResult32 unwrap32(VecBuf32* vector, float value) { DevVec<float>* v = H<float>(vector); return finish<float>(v, op_unwrap<float>(v, value)); }
+VectorInteropResult32 map_inplace_real32(VecBuf32* vector, float (*map)(float, size_t))
+{
+    DevVec<float>* v = H<float>(vector);
+    return finish<float>(v, op_map_inplace<float>(v, false, [&](std::vector<float>& h) { for (size_t i = 0; i < h.size(); ++i) h[i] = map(h[i], i); }));
+}
+VectorInteropResult32 map_inplace_complex32(VecBuf32* vector, bdsp_complex32 (*map)(bdsp_complex32, size_t))
+{
+    DevVec<float>* v = H<float>(vector);
+    return finish<float>(v, op_map_inplace<float>(v, true, [&](std::vector<float>& h) {
+        for (size_t i = 0; i + 1 < h.size(); i += 2) { const bdsp_complex32 r = map(bdsp_complex32{h[i], h[i + 1]}, i / 2); h[i] = r.re; h[i + 1] = r.im; }
+    }));
+}
+PointerInteropResult map_aggregate_real32(const VecBuf32* vector, const void* (*map)(float, size_t), const void* (*aggregate)(const void*, const void*))
+{
+    PointerInteropResult r;
+    r.result_code = op_map_aggregate<float>(H<float>(vector), false, &r.result, [&](const std::vector<float>& h) {
+        const void* acc = map(h[0], 0);
+        for (size_t i = 1; i < h.size(); ++i) acc = aggregate(acc, map(h[i], i));
+        return acc;
+    });
+    return r;
+}
+PointerInteropResult map_aggregate_complex32(const VecBuf32* vector, const void* (*map)(bdsp_complex32, size_t), const void* (*aggregate)(const void*, const void*))
+{
+    PointerInteropResult r;
+    r.result_code = op_map_aggregate<float>(H<float>(vector), true, &r.result, [&](const std::vector<float>& h) {
+        const void* acc = map(bdsp_complex32{h[0], h[1]}, 0);
+        for (size_t i = 2; i + 1 < h.size(); i += 2) acc = aggregate(acc, map(bdsp_complex32{h[i], h[i + 1]}, i / 2));
+        return acc;
+    });
+    return r;
+}
+int32_t get_real_imag32(VecBuf32* vector, VecBuf32* real, VecBuf32* imag) { return op_get_pair<float>(H<float>(vector), H<float>(real), H<float>(imag), 0); }
+int32_t get_mag_phase32(VecBuf32* vector, VecBuf32* mag, VecBuf32* phase) { return op_get_pair<float>(H<float>(vector), H<float>(mag), H<float>(phase), 1); }
+VectorInteropResult32 set_real_imag32(VecBuf32* vector, const VecBuf32* real, const VecBuf32* imag) { DevVec<float>* v = H<float>(vector); return finish<float>(v, op_set_pair<float>(v, H<float>(real), H<float>(imag), 0)); }
+VectorInteropResult32 set_mag_phase32(VecBuf32* vector, const VecBuf32* mag, const VecBuf32* phase) { DevVec<float>* v = H<float>(vector); return finish<float>(v, op_set_pair<float>(v, H<float>(mag), H<float>(phase), 1)); }
+int32_t split_into32(const VecBuf32* vector, VecBuf32** targets, size_t len)
+{ return op_split_into<float>(H<float>(vector), reinterpret_cast<DevVec<float>* const*>(targets), len); }
+VectorInteropResult32 merge32(VecBuf32* vector, VecBuf32* const* sources, size_t len)
+{ DevVec<float>* v = H<float>(vector); return finish<float>(v, op_merge<float>(v, reinterpret_cast<DevVec<float>* const*>(sources), len)); }
+VectorInteropResult32 convolve_complex32(VecBuf32* vector, bdsp_complex32 (*impulse_response)(const void*, float), const void* impulse_response_data, bool, float ratio, size_t len)
+{
+    DevVec<float>* v = H<float>(vector);
+    return finish<float>(v, op_convolve_callback_complex<float>(v, reinterpret_cast<CRet<float> (*)(const void*, float)>(impulse_response), impulse_response_data, ratio, len));
+}
+VectorInteropResult32 multiply_frequency_response_complex32(VecBuf32* vector, bdsp_complex32 (*frequency_response)(const void*, float), const void* frequency_response_data, bool is_symmetric, float ratio)
+{
+    DevVec<float>* v = H<float>(vector);
+    return finish<float>(v, op_custom_frequency_response_complex<float>(v, reinterpret_cast<CRet<float> (*)(const void*, float)>(frequency_response), frequency_response_data, is_symmetric, ratio));
+}
+VectorInteropResult32 interpolatef_custom32(VecBuf32* vector, float (*impulse_response)(const void*, float), const void* impulse_response_data, bool, float interpolation_factor, float delay, size_t len)
+{ DevVec<float>* v = H<float>(vector); return finish<float>(v, op_interpolatef<float>(v, 0, (float)0, interpolation_factor, delay, len, impulse_response, impulse_response_data)); }
+VectorInteropResult32 interpolate_custom32(VecBuf32* vector, float (*frequency_response)(const void*, float), const void* frequency_response_data, bool is_symmetric, size_t dest_points, float delay)
+{
+    DevVec<float>* v = H<float>(vector);
+    Sampler<float> sm; sm.rfn = frequency_response; sm.data = frequency_response_data; sm.symmetric = is_symmetric;
+    return finish<float>(v, op_interpolate<float>(v, 0, (float)0, dest_points, delay, &sm));
+}
+VectorInteropResult32 interpolatei_custom32(VecBuf32* vector, float (*frequency_response)(const void*, float), const void* frequency_response_data, bool is_symmetric, int32_t interpolation_factor)
+{
+    DevVec<float>* v = H<float>(vector);
+    Sampler<float> sm; sm.rfn = frequency_response; sm.data = frequency_response_data; sm.symmetric = is_symmetric;
+    return finish<float>(v, op_interpolatei<float>(v, 0, (float)0, interpolation_factor, &sm));
+}
+
+VectorInteropResult64 sqrt64(VecBuf64* vector) { DevVec<double>* v = H<double>(vector); return finish<double>(v, op_math<double>(v, MATH_SQRT, (double)0, false)); }
+VectorInteropResult64 square64(VecBuf64* vector) { DevVec<double>* v = H<double>(vector); return finish<double>(v, op_math<double>(v, MATH_SQUARE, (double)0, false)); }
+VectorInteropResult64 ln64(VecBuf64* vector) { DevVec<double>* v = H<double>(vector); return finish<double>(v, op_math<double>(v, MATH_LN, (double)0, false)); }
+VectorInteropResult64 exp64(VecBuf64* vector) { DevVec<double>* v = H<double>(vector); return finish<double>(v, op_math<double>(v, MATH_EXP, (double)0, false)); }
+VectorInteropResult64 sin64(VecBuf64* vector) { DevVec<double>* v = H<double>(vector); return finish<double>(v, op_math<double>(v, MATH_SIN, (double)0, false)); }
+VectorInteropResult64 cos64(VecBuf64* vector) { DevVec<double>* v = H<double>(vector); return finish<double>(v, op_math<double>(v, MATH_COS, (double)0, false)); }
+VectorInteropResult64 tan64(VecBuf64* vector) { DevVec<double>* v = H<double>(vector); return finish<double>(v, op_math<double>(v, MATH_TAN, (double)0, false)); }
+VectorInteropResult64 asin64(VecBuf64* vector) { DevVec<double>* v = H<double>(vector); return finish<double>(v, op_math<double>(v, MATH_ASIN, (double)0, false)); }
+VectorInteropResult64 acos64(VecBuf64* vector) { DevVec<double>* v = H<double>(vector); return finish<double>(v, op_math<double>(v, MATH_ACOS, (double)0, false)); }
+VectorInteropResult64 atan64(VecBuf64* vector) { DevVec<double>* v = H<double>(vector); return finish<double>(v, op_math<double>(v, MATH_ATAN, (double)0, false)); }
+VectorInteropResult64 sinh64(VecBuf64* vector) { DevVec<double>* v = H<double>(vector); return finish<double>(v, op_math<double>(v, MATH_SINH, (double)0, false)); }
+VectorInteropResult64 cosh64(VecBuf64* vector) { DevVec<double>* v = H<double>(vector); return finish<double>(v, op_math<double>(v, MATH_COSH, (double)0, false)); }
+VectorInteropResult64 tanh64(VecBuf64* vector) { DevVec<double>* v = H<double>(vector); return finish<double>(v, op_math<double>(v, MATH_TANH, (double)0, false)); }
+VectorInteropResult64 asinh64(VecBuf64* vector) { DevVec<double>* v = H<double>(vector); return finish<double>(v, op_math<double>(v, MATH_ASINH, (double)0, false)); }
+VectorInteropResult64 acosh64(VecBuf64* vector) { DevVec<double>* v = H<double>(vector); return finish<double>(v, op_math<double>(v, MATH_ACOSH, (double)0, false)); }
+VectorInteropResult64 atanh64(VecBuf64* vector) { DevVec<double>* v = H<double>(vector); return finish<double>(v, op_math<double>(v, MATH_ATANH, (double)0, false)); }
+VectorInteropResult64 abs64(VecBuf64* vector) { DevVec<double>* v = H<double>(vector); return finish<double>(v, op_math<double>(v, MATH_ABS, (double)0, true)); }
+VectorInteropResult64 ln_approx64(VecBuf64* vector) { DevVec<double>* v = H<double>(vector); return finish<double>(v, op_math<double>(v, MATH_LN, (double)0, true)); }
+VectorInteropResult64 exp_approx64(VecBuf64* vector) { DevVec<double>* v = H<double>(vector); return finish<double>(v, op_math<double>(v, MATH_EXP, (double)0, true)); }
+VectorInteropResult64 sin_approx64(VecBuf64* vector) { DevVec<double>* v = H<double>(vector); return finish<double>(v, op_math<double>(v, MATH_SIN, (double)0, true)); }
+VectorInteropResult64 cos_approx64(VecBuf64* vector) { DevVec<double>* v = H<double>(vector); return finish<double>(v, op_math<double>(v, MATH_COS, (double)0, true)); }
+VectorInteropResult64 bdsp_powf64(VecBuf64* vector, double value) { DevVec<double>* v = H<double>(vector); return finish<double>(v, op_math<double>(v, MATH_POWF, value, false)); }
+VectorInteropResult64 log64(VecBuf64* vector, double value) { DevVec<double>* v = H<double>(vector); return finish<double>(v, op_math<double>(v, MATH_LOG, value, false)); }
+VectorInteropResult64 bdsp_expf64(VecBuf64* vector, double value) { DevVec<double>* v = H<double>(vector); return finish<double>(v, op_math<double>(v, MATH_EXPF, value, false)); }
+VectorInteropResult64 wrap64(VecBuf64* vector, double value) { DevVec<double>* v = H<double>(vector); return finish<double>(v, op_math<double>(v, MATH_WRAP, value, true)); }
+VectorInteropResult64 log_approx64(VecBuf64* vector, double value) { DevVec<double>* v = H<double>(vector); return finish<double>(v, op_math<double>(v, MATH_LOG, value, true)); }
+VectorInteropResult64 expf_approx64(VecBuf64* vector, double value) { DevVec<double>* v = H<double>(vector); return finish<double>(v, op_math<double>(v, MATH_EXPF_APPROX, value, true)); }
+VectorInteropResult64 powf_approx64(VecBuf64* vector, double value) { DevVec<double>* v = H<double>(vector); return finish<double>(v, op_math<double>(v, MATH_POWF_APPROX, value, true)); }
+VectorInteropResult64 root64(VecBuf64* vector, double value) { DevVec<double>* v = H<double>(vector); return finish<double>(v, op_math<double>(v, MATH_POWF, (double)1 / value, false)); } // powf(1/degree), trigonometry_and_powers.rs:384-386
+VectorInteropResult64 diff64(VecBuf64* vector) { DevVec<double>* v = H<double>(vector); return finish<double>(v, op_diff<double>(v, false)); }
+VectorInteropResult64 diff_with_start64(VecBuf64* vector) { DevVec<double>* v = H<double>(vector); return finish<double>(v, op_diff<double>(v, true)); }
+VectorInteropResult64 cum_sum64(VecBuf64* vector) { DevVec<double>* v = H<double>(vector); return finish<double>(v, op_cum_sum<double>(v)); }
+VectorInteropResult64 unwrap64(VecBuf64* vector, double value) { DevVec<double>* v = H<double>(vector); return finish<double>(v, op_unwrap<double>(v, value)); }
+VectorInteropResult64 map_inplace_real64(VecBuf64* vector, double (*map)(double, size_t))
+{
+    DevVec<double>* v = H<double>(vector);
+    return finish<double>(v, op_map_inplace<double>(v, false, [&](std::vector<double>& h) { for (size_t i = 0; i < h.size(); ++i) h[i] = map(h[i], i); }));
+}
+VectorInteropResult64 map_inplace_complex64(VecBuf64* vector, bdsp_complex64 (*map)(bdsp_complex64, size_t))
+{
+    DevVec<double>* v = H<double>(vector);
+    return finish<double>(v, op_map_inplace<double>(v, true, [&](std::vector<double>& h) {
+        for (size_t i = 0; i + 1 < h.size(); i += 2) { const bdsp_complex64 r = map(bdsp_complex64{h[i], h[i + 1]}, i / 2); h[i] = r.re; h[i + 1] = r.im; }
+    }));
+}
+PointerInteropResult map_aggregate_real64(const VecBuf64* vector, const void* (*map)(double, size_t), const void* (*aggregate)(const void*, const void*))
+{
+    PointerInteropResult r;
+    r.result_code = op_map_aggregate<double>(H<double>(vector), false, &r.result, [&](const std::vector<double>& h) {
+        const void* acc = map(h[0], 0);
+        for (size_t i = 1; i < h.size(); ++i) acc = aggregate(acc, map(h[i], i));
+        return acc;
+    });
+    return r;
+}
+PointerInteropResult map_aggregate_complex64(const VecBuf64* vector, const void* (*map)(bdsp_complex64, size_t), const void* (*aggregate)(const void*, const void*))
+{
+    PointerInteropResult r;
+    r.result_code = op_map_aggregate<double>(H<double>(vector), true, &r.result, [&](const std::vector<double>& h) {
+        const void* acc = map(bdsp_complex64{h[0], h[1]}, 0);
+        for (size_t i = 2; i + 1 < h.size(); i += 2) acc = aggregate(acc, map(bdsp_complex64{h[i], h[i + 1]}, i / 2));
+        return acc;
+    });
+    return r;
+}
+int32_t get_real_imag64(VecBuf64* vector, VecBuf64* real, VecBuf64* imag) { return op_get_pair<double>(H<double>(vector), H<double>(real), H<double>(imag), 0); }
+int32_t get_mag_phase64(VecBuf64* vector, VecBuf64* mag, VecBuf64* phase) { return op_get_pair<double>(H<double>(vector), H<double>(mag), H<double>(phase), 1); }
+VectorInteropResult64 set_real_imag64(VecBuf64* vector, const VecBuf64* real, const VecBuf64* imag) { DevVec<double>* v = H<double>(vector); return finish<double>(v, op_set_pair<double>(v, H<double>(real), H<double>(imag), 0)); }
+VectorInteropResult64 set_mag_phase64(VecBuf64* vector, const VecBuf64* mag, const VecBuf64* phase) { DevVec<double>* v = H<double>(vector); return finish<double>(v, op_set_pair<double>(v, H<double>(mag), H<double>(phase), 1)); }
+int32_t split_into64(const VecBuf64* vector, VecBuf64** targets, size_t len)
+{ return op_split_into<double>(H<double>(vector), reinterpret_cast<DevVec<double>* const*>(targets), len); }
+VectorInteropResult64 merge64(VecBuf64* vector, VecBuf64* const* sources, size_t len)
+{ DevVec<double>* v = H<double>(vector); return finish<double>(v, op_merge<double>(v, reinterpret_cast<DevVec<double>* const*>(sources), len)); }
+VectorInteropResult64 convolve_complex64(VecBuf64* vector, bdsp_complex64 (*impulse_response)(const void*, double), const void* impulse_response_data, bool, double ratio, size_t len)
+{
+    DevVec<double>* v = H<double>(vector);
+    return finish<double>(v, op_convolve_callback_complex<double>(v, reinterpret_cast<CRet<double> (*)(const void*, double)>(impulse_response), impulse_response_data, ratio, len));
+}
+VectorInteropResult64 multiply_frequency_response_complex64(VecBuf64* vector, bdsp_complex64 (*frequency_response)(const void*, double), const void* frequency_response_data, bool is_symmetric, double ratio)
+{
+    DevVec<double>* v = H<double>(vector);
+    return finish<double>(v, op_custom_frequency_response_complex<double>(v, reinterpret_cast<CRet<double> (*)(const void*, double)>(frequency_response), frequency_response_data, is_symmetric, ratio));
+}
+VectorInteropResult64 interpolatef_custom64(VecBuf64* vector, double (*impulse_response)(const void*, double), const void* impulse_response_data, bool, double interpolation_factor, double delay, size_t len)
+{ DevVec<double>* v = H<double>(vector); return finish<double>(v, op_interpolatef<double>(v, 0, (double)0, interpolation_factor, delay, len, impulse_response, impulse_response_data)); }
+VectorInteropResult64 interpolate_custom64(VecBuf64* vector, double (*frequency_response)(const void*, double), const void* frequency_response_data, bool is_symmetric, size_t dest_points, double delay)
+{
+    DevVec<double>* v = H<double>(vector);
+    Sampler<double> sm; sm.rfn = frequency_response; sm.data = frequency_response_data; sm.symmetric = is_symmetric;
+    return finish<double>(v, op_interpolate<double>(v, 0, (double)0, dest_points, delay, &sm));
+}
+VectorInteropResult64 interpolatei_custom64(VecBuf64* vector, double (*frequency_response)(const void*, double), const void* frequency_response_data, bool is_symmetric, int32_t interpolation_factor)
+{
+    DevVec<double>* v = H<double>(vector);
+    Sampler<double> sm; sm.rfn = frequency_response; sm.data = frequency_response_data; sm.symmetric = is_symmetric;
+    return finish<double>(v, op_interpolatei<double>(v, 0, (double)0, interpolation_factor, &sm));
+}
+
+// ---------------------------------------------------------------------------------------------- callback bridges
+#define BDSP_BRIDGE(SFX, T)                                                                                  \
+    bdsp_complex##SFX bdsp_hip_complex_fn_bridge##SFX(const void* bridge, T x)                               \
+    {                                                                                                        \
+        const bdsp_complex_bridge##SFX* b = static_cast<const bdsp_complex_bridge##SFX*>(bridge);            \
+        T out[2] = {0, 0};                                                                                   \
+        b->fn(b->ctx, x, out);                                                                               \
+        return bdsp_complex##SFX{out[0], out[1]};                                                            \
+    }                                                                                                        \
+    static thread_local void (*g_map_bridge##SFX)(T, T, size_t, T*) = nullptr;                               \
+    void bdsp_hip_set_map_complex_bridge##SFX(void (*fn)(T, T, size_t, T*)) { g_map_bridge##SFX = fn; }      \
+    bdsp_complex##SFX bdsp_hip_map_complex_bridge##SFX(bdsp_complex##SFX value, size_t index)                \
+    {                                                                                                        \
+        T out[2] = {value.re, value.im};                                                                     \
+        if (g_map_bridge##SFX) g_map_bridge##SFX(value.re, value.im, index, out);                            \
+        return bdsp_complex##SFX{out[0], out[1]};                                                            \
+    }
+BDSP_BRIDGE(32, float)
+BDSP_BRIDGE(64, double)
+#undef BDSP_BRIDGE
 
 // ---------------------------------------------------------------------------------------------- statistics
 #define BDSP_STATS(SFX, T, VB)                                                                              \

@@ -5,72 +5,9 @@
 // complex/complex_ops.rs:81-116 bit for bit wherever the math library is not involved.
 #include "bdsp_internal.h"
 #include "dsp_funcs.h"
+#include "ew_map.h"
 
 namespace bdsp {
-
-template <typename T> struct Vec16;
-template <> struct Vec16<float> { using type = float4; static constexpr int N = 4; };
-template <> struct Vec16<double> { using type = double2; static constexpr int N = 2; };
-
-static inline unsigned ew_grid(size_t work_items)
-{
-    size_t blocks = (work_items + 255) / 256;
-    size_t cap = (size_t)num_cus() * 8;
-    if (blocks > cap) blocks = cap;
-    if (blocks == 0) blocks = 1;
-    return (unsigned)blocks;
-}
-
-// Generic in-place map over `len` scalars in 16-byte packets.  OP::apply(e, i0, p) sees V
-// consecutive scalars starting at scalar index i0 (i0 is a multiple of V, so complex pairs never
-// straddle packets); the unaligned head/tail of odd-sized buffers goes through OP::apply1/2.
-template <typename T, typename OP>
-__global__ __launch_bounds__(256) void k_map_inplace(T* __restrict__ x, size_t len, typename OP::Params p)
-{
-    using V = typename Vec16<T>::type;
-    constexpr int VN = Vec16<T>::N;
-    const size_t nvec = len / VN;
-    V* xv = reinterpret_cast<V*>(x);
-    // Each workgroup streams contiguous 16 KiB chunks (4 packets of 16 bytes in flight per lane).
-    // (One packet per iteration measured 62 % of the HBM peak on 256 MiB; four packets a grid
-    // stride apart measured WORSE, 42 % -- the 8 MiB spacing thrashes DRAM pages; contiguous chunks
-    // keep the row buffers hot.)
-    const size_t nchunks = nvec / 1024;
-    for (size_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
-        const size_t i = c * 1024 + threadIdx.x;
-        V p0 = xv[i], p1 = xv[i + 256], p2 = xv[i + 512], p3 = xv[i + 768];
-        OP::apply(reinterpret_cast<T*>(&p0), VN, i * VN, p);
-        OP::apply(reinterpret_cast<T*>(&p1), VN, (i + 256) * VN, p);
-        OP::apply(reinterpret_cast<T*>(&p2), VN, (i + 512) * VN, p);
-        OP::apply(reinterpret_cast<T*>(&p3), VN, (i + 768) * VN, p);
-        xv[i] = p0; xv[i + 256] = p1; xv[i + 512] = p2; xv[i + 768] = p3;
-    }
-    for (size_t i = nchunks * 1024 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec;
-         i += (size_t)gridDim.x * blockDim.x) {
-        V pk = xv[i];
-        T* e = reinterpret_cast<T*>(&pk);
-        OP::apply(e, VN, i * VN, p);
-        xv[i] = pk;
-    }
-    // tail (fewer than VN scalars; always an even count for complex data)
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        size_t done = nvec * VN;
-        if (done < len) OP::apply(x + done, (int)(len - done), done, p);
-    }
-}
-
-template <typename T, typename OP>
-static int launch_map(T* x, size_t len, typename OP::Params p, hipStream_t s)
-{
-    if (len == 0) return BDSP_OK;
-    if (reinterpret_cast<uintptr_t>(x) % 16 != 0) {
-        set_last_error("elementwise: buffer must be 16-byte aligned");
-        return BDSP_ERR_UNSUPPORTED;
-    }
-    hipLaunchKernelGGL((k_map_inplace<T, OP>), dim3(ew_grid(len / Vec16<T>::N + 1)), dim3(256), 0, s, x, len, p);
-    BDSP_LAUNCH_CHECK();
-    return BDSP_OK;
-}
 
 // ---- ops -------------------------------------------------------------------------------------
 template <typename T> struct OpRealScale {

@@ -14,6 +14,7 @@
 // All tap arguments are accumulated in T by repeated +1 exactly as the reference does.
 #include "bdsp_internal.h"
 #include "dsp_funcs.h"
+#include <vector>
 
 namespace bdsp {
 
@@ -253,9 +254,39 @@ __global__ __launch_bounds__(256) void k_interp_scalar(const T* __restrict__ x, 
     }
 }
 
+// scalar path with host-sampled weights (interpolatef_custom): w[i*ntaps + k] is the callback's value for tap k
+// of output i, sampled on the host with the same accumulated arguments as k_interp_scalar
+template <typename T, bool CPLX>
+__global__ __launch_bounds__(256) void k_interp_scalar_tab(const T* __restrict__ x, T* __restrict__ y,
+                                                            const T* __restrict__ w, long long points,
+                                                            long long new_points, int conv_len, T factor)
+{
+    const int ntaps = 2 * conv_len + 1;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < new_points;
+         i += (long long)gridDim.x * blockDim.x) {
+        T center = (T)i / factor;
+        T rounded = dev_floor<T>(center);
+        long long pos = ((long long)rounded - conv_len - 1) % points;
+        if (pos < 0) pos += points;
+        const T* wi = w + i * ntaps;
+        T sr = 0, si = 0;
+        for (int k = 0; k < ntaps; ++k) {
+            pos = pos + 1 < points ? pos + 1 : 0;
+            if (CPLX) {
+                T re = x[2 * pos], im = x[2 * pos + 1];
+                sr = sr + (re * wi[k] - im * (T)0);
+                si = si + (re * (T)0 + im * wi[k]);
+            } else sr = sr + x[pos] * wi[k];
+        }
+        if (CPLX) { y[2 * i] = sr; y[2 * i + 1] = si; }
+        else y[i] = sr;
+    }
+}
+
 template <typename T>
 int interpolatef_dev(const T* in, T* out, size_t len, bool is_complex, int fid, T rolloff, T factor,
-                     T delay, size_t conv_len, T delta, hipStream_t s)
+                     T delay, size_t conv_len, T delta, hipStream_t s, T (*host_fn)(const void*, T),
+                     const void* host_fn_data)
 {
     const size_t elem = is_complex ? 2 : 1;
     const size_t points = len / elem;
@@ -277,9 +308,20 @@ int interpolatef_dev(const T* in, T* out, size_t len, bool is_complex, int fid, 
         int ntaps = 2 * (int)conv_len + 1;
         WsBlock tb;
         BDSP_TRY(tb.alloc(sizeof(T) * (size_t)ntaps * f, s));
-        hipLaunchKernelGGL((k_interp_taps<T>), dim3((f * ntaps + 63) / 64), dim3(64), 0, s, tb.as<T>(), fid,
-                           rolloff, (int)conv_len, f, delay);
-        BDSP_LAUNCH_CHECK();
+        if (host_fn) { // the callback variant: the same table, sampled on the host
+            std::vector<T> ht((size_t)ntaps * f);
+            for (int sft = 0; sft < f; ++sft) {
+                const T offset = (T)sft / (T)f;
+                T j = -((T)conv_len - (T)1) + delay;
+                for (int m = 0; m < ntaps; ++m) { ht[(size_t)sft * ntaps + m] = host_fn(host_fn_data, j - offset); j = j + (T)1; }
+            }
+            BDSP_HIP_TRY(hipMemcpyAsync(tb.p, ht.data(), sizeof(T) * ht.size(), hipMemcpyHostToDevice, s));
+            BDSP_HIP_TRY(hipStreamSynchronize(s));
+        } else {
+            hipLaunchKernelGGL((k_interp_taps<T>), dim3((f * ntaps + 63) / 64), dim3(64), 0, s, tb.as<T>(), fid,
+                               rolloff, (int)conv_len, f, delay);
+            BDSP_LAUNCH_CHECK();
+        }
         size_t lds = sizeof(T) * (size_t)ntaps * f;
         if (lds > 60 * 1024) { set_last_error("interpolatef: tap table exceeds LDS"); return BDSP_ERR_UNSUPPORTED; }
         // edges (and everything, for factors without a blocked instantiation) by the generic kernel;
@@ -322,6 +364,28 @@ int interpolatef_dev(const T* in, T* out, size_t len, bool is_complex, int fid, 
 #undef BDSP_INNER2
 #undef BDSP_INNER
         }
+    } else if (host_fn) {
+        const size_t ntaps = 2 * conv_len + 1;
+        std::vector<T> hw(new_points * ntaps);
+        for (size_t i = 0; i < new_points; ++i) {
+            const T center = (T)i / factor;
+            const T rounded = sizeof(T) == 4 ? (T)floorf((float)center) : (T)floor((double)center);
+            T j = -(T)conv_len - (center - rounded) + delay;
+            for (size_t k = 0; k < ntaps; ++k) { hw[i * ntaps + k] = host_fn(host_fn_data, j); j = j + (T)1; }
+        }
+        WsBlock wb;
+        BDSP_TRY(wb.alloc(sizeof(T) * hw.size(), s));
+        BDSP_HIP_TRY(hipMemcpyAsync(wb.p, hw.data(), sizeof(T) * hw.size(), hipMemcpyHostToDevice, s));
+        BDSP_HIP_TRY(hipStreamSynchronize(s));
+        if (is_complex)
+            hipLaunchKernelGGL((k_interp_scalar_tab<T, true>), dim3((unsigned)blocks), dim3(256), 0, s, in, out, wb.as<T>(),
+                               (long long)points, (long long)new_points, (int)conv_len, factor);
+        else
+            hipLaunchKernelGGL((k_interp_scalar_tab<T, false>), dim3((unsigned)blocks), dim3(256), 0, s, in, out, wb.as<T>(),
+                               (long long)points, (long long)new_points, (int)conv_len, factor);
+        BDSP_LAUNCH_CHECK();
+        BDSP_HIP_TRY(hipStreamSynchronize(s)); // the weight table is released on return
+        return BDSP_OK;
     } else {
         if (is_complex)
             hipLaunchKernelGGL((k_interp_scalar<T, true>), dim3((unsigned)blocks), dim3(256), 0, s, in, out,
@@ -354,7 +418,7 @@ __global__ void k_conv_fn_taps(T* __restrict__ taps, long long L, int fid, T rol
     if (stride == 2) taps[at * 2 + 1] = (T)0;
 }
 
-template <typename T, bool CPLX>
+template <typename T, bool CPLX, bool CW = false>
 __global__ void __launch_bounds__(256)
 k_conv_function(const T* __restrict__ in, T* __restrict__ out, const T* __restrict__ taps, long long points, long long L)
 {
@@ -363,8 +427,12 @@ k_conv_function(const T* __restrict__ in, T* __restrict__ out, const T* __restri
         if (p < 0) p += points;
         T sre = 0, sim = 0;
         for (long long k = 0; k <= 2 * L; ++k) {
-            T w = taps[k];
-            if (CPLX) {
+            T w = CW ? taps[2 * k] : taps[k];
+            if (CW) { // complex weights (convolve_complex): Complex * Complex, then the sum
+                const T wi = taps[2 * k + 1], xr = in[2 * p], xi = in[2 * p + 1];
+                sre = sre + (xr * w - xi * wi);
+                sim = sim + (xr * wi + xi * w);
+            } else if (CPLX) {
                 sre = sre + in[2 * p] * w;
                 sim = sim + in[2 * p + 1] * w;
             } else {
@@ -388,12 +456,16 @@ int conv_function_taps(T* taps, size_t conv_len, int fid, T rolloff, T ratio, in
 }
 
 template <typename T>
-int conv_function_direct(const T* in, T* out, size_t points, bool is_complex, const T* taps, size_t conv_len, hipStream_t s)
+int conv_function_direct(const T* in, T* out, size_t points, bool is_complex, const T* taps, size_t conv_len, hipStream_t s,
+                         bool complex_taps)
 {
     if (points == 0) return BDSP_OK;
     size_t blocks = (points + 255) / 256, cap = (size_t)num_cus() * 16;
     if (blocks > cap) blocks = cap;
-    if (is_complex)
+    if (complex_taps)
+        hipLaunchKernelGGL((k_conv_function<T, true, true>), dim3((unsigned)blocks), dim3(256), 0, s, in, out, taps,
+                           (long long)points, (long long)conv_len);
+    else if (is_complex)
         hipLaunchKernelGGL((k_conv_function<T, true>), dim3((unsigned)blocks), dim3(256), 0, s, in, out, taps,
                            (long long)points, (long long)conv_len);
     else
@@ -498,14 +570,14 @@ int interpolate_real_dev(const T* in, T* out, size_t len, T factor, T delay, boo
 
 #define BDSP_INST(T)                                                                                          \
     template int conv_function_taps<T>(T*, size_t, int, T, T, int, bool, hipStream_t);                        \
-    template int conv_function_direct<T>(const T*, T*, size_t, bool, const T*, size_t, hipStream_t);          \
+    template int conv_function_direct<T>(const T*, T*, size_t, bool, const T*, size_t, hipStream_t, bool);          \
     template size_t interpolate_real_len<T>(size_t, T);                                                       \
     template int interpolate_real_dev<T>(const T*, T*, size_t, T, T, bool, hipStream_t);
 BDSP_INST(float)
 BDSP_INST(double)
 #undef BDSP_INST
 
-template int interpolatef_dev<float>(const float*, float*, size_t, bool, int, float, float, float, size_t, float, hipStream_t);
-template int interpolatef_dev<double>(const double*, double*, size_t, bool, int, double, double, double, size_t, double, hipStream_t);
+template int interpolatef_dev<float>(const float*, float*, size_t, bool, int, float, float, float, size_t, float, hipStream_t, float (*)(const void*, float), const void*);
+template int interpolatef_dev<double>(const double*, double*, size_t, bool, int, double, double, double, size_t, double, hipStream_t, double (*)(const void*, double), const void*);
 
 } // namespace bdsp

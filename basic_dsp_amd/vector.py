@@ -269,6 +269,119 @@ class DspVec:
     def windowed_sifft(self, window):
         return self._call("windowed_sifft", int(window))
 
+    # ------------------------------------------------------------------ per-element math family & co.
+    def _math0(name):  # noqa: N805 -- method factory
+        def method(self):
+            return self._call(name)
+        method.__name__ = name
+        method.__doc__ = "TrigOps / PowerOps / RealOps `%s` in place (trigonometry_and_powers.rs, real_ops.rs)" % name
+        return method
+
+    def _math1(name):  # noqa: N805
+        def method(self, value):
+            return self._call(name, value)
+        method.__name__ = name
+        return method
+
+    for _n in ("sqrt", "square", "ln", "exp", "sin", "cos", "tan", "asin", "acos", "atan", "sinh", "cosh", "tanh",
+               "asinh", "acosh", "atanh", "abs", "ln_approx", "exp_approx", "sin_approx", "cos_approx", "diff",
+               "diff_with_start", "cum_sum"):
+        locals()[_n] = _math0(_n)
+    for _n in ("powf", "root", "log", "expf", "wrap", "unwrap", "log_approx", "expf_approx", "powf_approx"):
+        locals()[_n] = _math1(_n)
+    del _n, _math0, _math1
+
+    def map_inplace(self, f):
+        """f(value, index) -> value, called on the host for every element (mapping.rs:53-79, 163-190)"""
+        if self.is_complex():
+            def cb(re, im, i, out):
+                r = complex(f(complex(re, im), i))
+                out[0], out[1] = r.real, r.imag
+            keep = getattr(_lib, "MAP_COMPLEX_PTR_FN" + self._sfx)(cb)
+            self._fn("bdsp_hip_set_map_complex_bridge")(keep)
+            import ctypes as C
+            bridge = C.cast(self._fn("bdsp_hip_map_complex_bridge"), C.c_void_p)
+            return self._call("map_inplace_complex", bridge)
+        return self._call("map_inplace_real", getattr(_lib, "MAP_REAL_FN" + self._sfx)(lambda x, i: f(x, i)))
+
+    def map_aggregate(self, map_fn, aggregate):
+        """Folds map_fn(value, index) over the vector with aggregate(a, b); the C ABI carries the intermediate
+        values as opaque pointers, here as keys into a table of Python objects.  Returns (code, result)."""
+        table = [None]
+
+        def put(obj):
+            table.append(obj)
+            return len(table) - 1
+        agg = _lib.AGG_FN(lambda a, b: put(aggregate(table[a], table[b])))
+        if self.is_complex():
+            m = getattr(_lib, "AGG_MAP_COMPLEX_FN" + self._sfx)(lambda z, i: put(map_fn(complex(z.re, z.im), i)))
+            r = self._fn("map_aggregate_complex")(self._h, m, agg)
+        else:
+            m = getattr(_lib, "AGG_MAP_REAL_FN" + self._sfx)(lambda x, i: put(map_fn(x, i)))
+            r = self._fn("map_aggregate_real")(self._h, m, agg)
+        _lib.check(r.result_code, "map_aggregate")
+        return r.result_code, (table[r.result] if r.result_code == 0 and r.result else None)
+
+    def _get_pair(self, name, a, b):
+        src = self.clone()
+        code = self._fn(name)(src._h, a._h, b._h)
+        src._h = None  # consumed by the call
+        return _lib.check(code, name + self._sfx)
+
+    def get_real_imag(self, real, imag):
+        return self._get_pair("get_real_imag", real, imag)
+
+    def get_mag_phase(self, mag, phase):
+        return self._get_pair("get_mag_phase", mag, phase)
+
+    def set_real_imag(self, real, imag):
+        return self._call("set_real_imag", real._h, imag._h)
+
+    def set_mag_phase(self, mag, phase):
+        return self._call("set_mag_phase", mag._h, phase._h)
+
+    def split_into(self, targets):
+        import ctypes as C
+        arr = (C.c_void_p * len(targets))(*[t._h for t in targets])
+        return _lib.check(self._fn("split_into")(self._h, arr, len(targets)), "split_into")
+
+    def merge(self, sources):
+        import ctypes as C
+        arr = (C.c_void_p * len(sources))(*[t._h for t in sources])
+        return self._call("merge", arr, len(sources))
+
+    def _complex_fn(self, f):
+        """(callback, data) for a complex-valued facade callback: the library's bridge + a pointer-style closure"""
+        import ctypes as C
+
+        def cb(_ctx, x, out):
+            r = complex(f(x))
+            out[0], out[1] = r.real, r.imag
+        bridge = getattr(_lib, "ComplexBridge" + self._sfx)(getattr(_lib, "COMPLEX_PTR_FN" + self._sfx)(cb), None)
+        return C.cast(self._fn("bdsp_hip_complex_fn_bridge"), C.c_void_p), bridge
+
+    def convolve_complex(self, function, ratio, conv_len):
+        import ctypes as C
+        fn, bridge = self._complex_fn(function)
+        return self._call("convolve_complex", fn, C.addressof(bridge), True, ratio, int(conv_len))
+
+    def multiply_frequency_response_complex(self, function, ratio, is_symmetric=False):
+        import ctypes as C
+        fn, bridge = self._complex_fn(function)
+        return self._call("multiply_frequency_response_complex", fn, C.addressof(bridge), bool(is_symmetric), ratio)
+
+    def interpolatef_custom(self, function, interpolation_factor, delay, conv_len):
+        cb = self._real_fn(lambda _data, x: function(x))
+        return self._call("interpolatef_custom", cb, None, True, interpolation_factor, delay, int(conv_len))
+
+    def interpolate_custom(self, function, dest_points, delay=0.0, is_symmetric=True):
+        cb = self._real_fn(lambda _data, x: function(x))
+        return self._call("interpolate_custom", cb, None, bool(is_symmetric), int(dest_points), delay)
+
+    def interpolatei_custom(self, function, interpolation_factor, is_symmetric=True):
+        cb = self._real_fn(lambda _data, x: function(x))
+        return self._call("interpolatei_custom", cb, None, bool(is_symmetric), int(interpolation_factor))
+
     # ------------------------------------------------------------------ statistics, sums, dot products
     @staticmethod
     def _stats_dict(st, cplx):

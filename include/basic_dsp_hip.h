@@ -456,6 +456,161 @@ int32_t complex_statistics_split64(const VecBuf64 *vector, ComplexStatistics64 *
 int32_t real_statistics_split_prec64(const VecBuf64 *vector, Statistics64 *data, size_t len);          /* facade32.rs:889-907 */
 int32_t complex_statistics_split_prec64(const VecBuf64 *vector, ComplexStatistics64 *data, size_t len);/* facade32.rs:910-931 */
 
+/* ----------------------------------------------------------------------------------------
+ * Per-element math family, differences / running sums, phase wrapping, real<->complex pairs, split / merge,
+ * host callbacks (trigonometry_and_powers.rs, real_ops.rs, diff_sum.rs, complex_to_real.rs:674-770,
+ * data_reorganization.rs:484-555, mapping.rs).  TrigOps / PowerOps work on real and complex vectors (complex
+ * functions as in num-complex 0.4); abs / wrap / unwrap / the *_approx family poison a complex vector.  The
+ * "approximated" functions are the standard ones, as in the reference's build without explicit SIMD
+ * (simd_extensions/approx_fallback.rs).  cum_sum carries the running sum in double.
+ * glibc's <math.h> declares powf32 / expf32 / powf64 / expf64 itself (the _Float32 / _Float64 functions of
+ * ISO/IEC TS 18661-3) and the reference's facade uses the very same names for different functions: the C
+ * declarations below carry a bdsp_ prefix and bind to the facade's symbol name, so the library still exports
+ * `powf32` etc. for ctypes / Rust callers and this header can be included next to <math.h>.
+ * -------------------------------------------------------------------------------------- */
+#define BDSP_FACADE_SYMBOL(name) __asm__(#name)
+VectorInteropResult32 diff32(VecBuf32 *vector);                        /* facade32.rs:348-350 */
+VectorInteropResult32 diff_with_start32(VecBuf32 *vector);             /* facade32.rs:353-355 */
+VectorInteropResult32 cum_sum32(VecBuf32 *vector);                     /* facade32.rs:358-360 */
+VectorInteropResult32 abs32(VecBuf32 *vector);                         /* facade32.rs:373-375 */
+VectorInteropResult32 sqrt32(VecBuf32 *vector);                        /* facade32.rs:378-380 */
+VectorInteropResult32 square32(VecBuf32 *vector);                      /* facade32.rs:383-385 */
+VectorInteropResult32 root32(VecBuf32 *vector, float value);           /* facade32.rs:388-390 */
+VectorInteropResult32 bdsp_powf32(VecBuf32 *vector, float value) BDSP_FACADE_SYMBOL(powf32);           /* facade32.rs:393-395 */
+VectorInteropResult32 ln32(VecBuf32 *vector);                          /* facade32.rs:398-400 */
+VectorInteropResult32 exp32(VecBuf32 *vector);                         /* facade32.rs:403-405 */
+VectorInteropResult32 log32(VecBuf32 *vector, float value);            /* facade32.rs:408-410 */
+VectorInteropResult32 bdsp_expf32(VecBuf32 *vector, float value) BDSP_FACADE_SYMBOL(expf32);           /* facade32.rs:413-415 */
+VectorInteropResult32 sin32(VecBuf32 *vector);                         /* facade32.rs:423-425 */
+VectorInteropResult32 cos32(VecBuf32 *vector);                         /* facade32.rs:428-430 */
+VectorInteropResult32 tan32(VecBuf32 *vector);
+VectorInteropResult32 asin32(VecBuf32 *vector);
+VectorInteropResult32 acos32(VecBuf32 *vector);
+VectorInteropResult32 atan32(VecBuf32 *vector);
+VectorInteropResult32 sinh32(VecBuf32 *vector);
+VectorInteropResult32 cosh32(VecBuf32 *vector);
+VectorInteropResult32 tanh32(VecBuf32 *vector);
+VectorInteropResult32 asinh32(VecBuf32 *vector);
+VectorInteropResult32 acosh32(VecBuf32 *vector);
+VectorInteropResult32 atanh32(VecBuf32 *vector);                       /* facade32.rs:433-479 */
+VectorInteropResult32 ln_approx32(VecBuf32 *vector);                   /* facade32.rs:482-484 */
+VectorInteropResult32 exp_approx32(VecBuf32 *vector);
+VectorInteropResult32 sin_approx32(VecBuf32 *vector);
+VectorInteropResult32 cos_approx32(VecBuf32 *vector);
+VectorInteropResult32 log_approx32(VecBuf32 *vector, float value);
+VectorInteropResult32 expf_approx32(VecBuf32 *vector, float value);
+VectorInteropResult32 powf_approx32(VecBuf32 *vector, float value);    /* facade32.rs:487-514 */
+VectorInteropResult32 wrap32(VecBuf32 *vector, float value);           /* facade32.rs:517-519 */
+VectorInteropResult32 unwrap32(VecBuf32 *vector, float value);         /* facade32.rs:522-524; sequential recurrence */
+/* callbacks are host code: the vector makes one host round trip, one call per element in index order */
+VectorInteropResult32 map_inplace_real32(VecBuf32 *vector, float (*map)(float, size_t));                  /* facade32.rs:594-600 */
+VectorInteropResult32 map_inplace_complex32(VecBuf32 *vector, bdsp_complex32 (*map)(bdsp_complex32, size_t)); /* facade32.rs:603-609 */
+typedef struct { int32_t result_code; const void *result; } PointerInteropResult;  /* ScalarInteropResult<*const c_void> */
+PointerInteropResult map_aggregate_real32(const VecBuf32 *vector, const void *(*map)(float, size_t),
+                                          const void *(*aggregate)(const void *, const void *));       /* facade32.rs:614-629 */
+PointerInteropResult map_aggregate_complex32(const VecBuf32 *vector, const void *(*map)(bdsp_complex32, size_t),
+                                             const void *(*aggregate)(const void *, const void *));    /* facade32.rs:634-649 */
+/* the source handle is CONSUMED, the answer is convert_void(Ok) = 9 (interop/src/lib.rs:100-105) */
+int32_t get_real_imag32(VecBuf32 *vector, VecBuf32 *real, VecBuf32 *imag);                              /* facade32.rs:768-774 */
+int32_t get_mag_phase32(VecBuf32 *vector, VecBuf32 *mag, VecBuf32 *phase);                              /* facade32.rs:777-783 */
+VectorInteropResult32 set_real_imag32(VecBuf32 *vector, const VecBuf32 *real, const VecBuf32 *imag);    /* facade32.rs:786-792 */
+VectorInteropResult32 set_mag_phase32(VecBuf32 *vector, const VecBuf32 *mag, const VecBuf32 *phase);    /* facade32.rs:795-801 */
+int32_t split_into32(const VecBuf32 *vector, VecBuf32 **targets, size_t len);                           /* facade32.rs:804-811; 9 = ok */
+VectorInteropResult32 merge32(VecBuf32 *vector, VecBuf32 *const *sources, size_t len);                  /* facade32.rs:814-824 */
+typedef bdsp_complex32 (*bdsp_complex_fn32)(const void *function_data, float x);                        /* lib.rs:279-284 */
+VectorInteropResult32 convolve_complex32(VecBuf32 *vector, bdsp_complex_fn32 impulse_response,
+                                         const void *impulse_response_data, bool is_symmetric, float ratio,
+                                         size_t len);                                                   /* facade32.rs:1206-1222 */
+VectorInteropResult32 multiply_frequency_response_complex32(VecBuf32 *vector, bdsp_complex_fn32 frequency_response,
+                                         const void *frequency_response_data, bool is_symmetric,
+                                         float ratio);                                                  /* facade32.rs:1269-1284 */
+VectorInteropResult32 interpolatef_custom32(VecBuf32 *vector, bdsp_real_fn32 impulse_response,
+                                            const void *impulse_response_data, bool is_symmetric,
+                                            float interpolation_factor, float delay, size_t len);       /* facade32.rs:1308-1326 */
+VectorInteropResult32 interpolate_custom32(VecBuf32 *vector, bdsp_real_fn32 frequency_response,
+                                           const void *frequency_response_data, bool is_symmetric,
+                                           size_t dest_points, float delay);                            /* facade32.rs:1353-1369 */
+VectorInteropResult32 interpolatei_custom32(VecBuf32 *vector, bdsp_real_fn32 frequency_response,
+                                            const void *frequency_response_data, bool is_symmetric,
+                                            int32_t interpolation_factor);                              /* facade32.rs:1402-1417 */
+
+VectorInteropResult64 diff64(VecBuf64 *vector);                        /* facade32.rs:348-350 */
+VectorInteropResult64 diff_with_start64(VecBuf64 *vector);             /* facade32.rs:353-355 */
+VectorInteropResult64 cum_sum64(VecBuf64 *vector);                     /* facade32.rs:358-360 */
+VectorInteropResult64 abs64(VecBuf64 *vector);                         /* facade32.rs:373-375 */
+VectorInteropResult64 sqrt64(VecBuf64 *vector);                        /* facade32.rs:378-380 */
+VectorInteropResult64 square64(VecBuf64 *vector);                      /* facade32.rs:383-385 */
+VectorInteropResult64 root64(VecBuf64 *vector, double value);           /* facade32.rs:388-390 */
+VectorInteropResult64 bdsp_powf64(VecBuf64 *vector, double value) BDSP_FACADE_SYMBOL(powf64);           /* facade32.rs:393-395 */
+VectorInteropResult64 ln64(VecBuf64 *vector);                          /* facade32.rs:398-400 */
+VectorInteropResult64 exp64(VecBuf64 *vector);                         /* facade32.rs:403-405 */
+VectorInteropResult64 log64(VecBuf64 *vector, double value);            /* facade32.rs:408-410 */
+VectorInteropResult64 bdsp_expf64(VecBuf64 *vector, double value) BDSP_FACADE_SYMBOL(expf64);           /* facade32.rs:413-415 */
+VectorInteropResult64 sin64(VecBuf64 *vector);                         /* facade32.rs:423-425 */
+VectorInteropResult64 cos64(VecBuf64 *vector);                         /* facade32.rs:428-430 */
+VectorInteropResult64 tan64(VecBuf64 *vector);
+VectorInteropResult64 asin64(VecBuf64 *vector);
+VectorInteropResult64 acos64(VecBuf64 *vector);
+VectorInteropResult64 atan64(VecBuf64 *vector);
+VectorInteropResult64 sinh64(VecBuf64 *vector);
+VectorInteropResult64 cosh64(VecBuf64 *vector);
+VectorInteropResult64 tanh64(VecBuf64 *vector);
+VectorInteropResult64 asinh64(VecBuf64 *vector);
+VectorInteropResult64 acosh64(VecBuf64 *vector);
+VectorInteropResult64 atanh64(VecBuf64 *vector);                       /* facade32.rs:433-479 */
+VectorInteropResult64 ln_approx64(VecBuf64 *vector);                   /* facade32.rs:482-484 */
+VectorInteropResult64 exp_approx64(VecBuf64 *vector);
+VectorInteropResult64 sin_approx64(VecBuf64 *vector);
+VectorInteropResult64 cos_approx64(VecBuf64 *vector);
+VectorInteropResult64 log_approx64(VecBuf64 *vector, double value);
+VectorInteropResult64 expf_approx64(VecBuf64 *vector, double value);
+VectorInteropResult64 powf_approx64(VecBuf64 *vector, double value);    /* facade32.rs:487-514 */
+VectorInteropResult64 wrap64(VecBuf64 *vector, double value);           /* facade32.rs:517-519 */
+VectorInteropResult64 unwrap64(VecBuf64 *vector, double value);         /* facade32.rs:522-524; sequential recurrence */
+/* callbacks are host code: the vector makes one host round trip, one call per element in index order */
+VectorInteropResult64 map_inplace_real64(VecBuf64 *vector, double (*map)(double, size_t));                  /* facade32.rs:594-600 */
+VectorInteropResult64 map_inplace_complex64(VecBuf64 *vector, bdsp_complex64 (*map)(bdsp_complex64, size_t)); /* facade32.rs:603-609 */
+PointerInteropResult map_aggregate_real64(const VecBuf64 *vector, const void *(*map)(double, size_t),
+                                          const void *(*aggregate)(const void *, const void *));       /* facade32.rs:614-629 */
+PointerInteropResult map_aggregate_complex64(const VecBuf64 *vector, const void *(*map)(bdsp_complex64, size_t),
+                                             const void *(*aggregate)(const void *, const void *));    /* facade32.rs:634-649 */
+/* the source handle is CONSUMED, the answer is convert_void(Ok) = 9 (interop/src/lib.rs:100-105) */
+int32_t get_real_imag64(VecBuf64 *vector, VecBuf64 *real, VecBuf64 *imag);                              /* facade32.rs:768-774 */
+int32_t get_mag_phase64(VecBuf64 *vector, VecBuf64 *mag, VecBuf64 *phase);                              /* facade32.rs:777-783 */
+VectorInteropResult64 set_real_imag64(VecBuf64 *vector, const VecBuf64 *real, const VecBuf64 *imag);    /* facade32.rs:786-792 */
+VectorInteropResult64 set_mag_phase64(VecBuf64 *vector, const VecBuf64 *mag, const VecBuf64 *phase);    /* facade32.rs:795-801 */
+int32_t split_into64(const VecBuf64 *vector, VecBuf64 **targets, size_t len);                           /* facade32.rs:804-811; 9 = ok */
+VectorInteropResult64 merge64(VecBuf64 *vector, VecBuf64 *const *sources, size_t len);                  /* facade32.rs:814-824 */
+typedef bdsp_complex64 (*bdsp_complex_fn64)(const void *function_data, double x);                        /* lib.rs:279-284 */
+VectorInteropResult64 convolve_complex64(VecBuf64 *vector, bdsp_complex_fn64 impulse_response,
+                                         const void *impulse_response_data, bool is_symmetric, double ratio,
+                                         size_t len);                                                   /* facade32.rs:1206-1222 */
+VectorInteropResult64 multiply_frequency_response_complex64(VecBuf64 *vector, bdsp_complex_fn64 frequency_response,
+                                         const void *frequency_response_data, bool is_symmetric,
+                                         double ratio);                                                  /* facade32.rs:1269-1284 */
+VectorInteropResult64 interpolatef_custom64(VecBuf64 *vector, bdsp_real_fn64 impulse_response,
+                                            const void *impulse_response_data, bool is_symmetric,
+                                            double interpolation_factor, double delay, size_t len);       /* facade32.rs:1308-1326 */
+VectorInteropResult64 interpolate_custom64(VecBuf64 *vector, bdsp_real_fn64 frequency_response,
+                                           const void *frequency_response_data, bool is_symmetric,
+                                           size_t dest_points, double delay);                            /* facade32.rs:1353-1369 */
+VectorInteropResult64 interpolatei_custom64(VecBuf64 *vector, bdsp_real_fn64 frequency_response,
+                                            const void *frequency_response_data, bool is_symmetric,
+                                            int32_t interpolation_factor);                              /* facade32.rs:1402-1417 */
+
+/* Bridges for foreign-function layers that cannot describe callbacks RETURNING structs (Python ctypes): these
+ * functions have the facade's callback signatures and forward to a pointer-style callback.  Pass
+ * bdsp_hip_complex_fn_bridge32 as the `bdsp_complex_fn32` and a bdsp_complex_bridge32 as its function_data; for
+ * map_inplace_complex32 (no data argument) register the target for the calling thread first. */
+typedef struct { void (*fn)(void *ctx, float x, float *re_im_out); void *ctx; } bdsp_complex_bridge32;
+typedef struct { void (*fn)(void *ctx, double x, double *re_im_out); void *ctx; } bdsp_complex_bridge64;
+bdsp_complex32 bdsp_hip_complex_fn_bridge32(const void *bridge, float x);
+bdsp_complex64 bdsp_hip_complex_fn_bridge64(const void *bridge, double x);
+void bdsp_hip_set_map_complex_bridge32(void (*fn)(float re, float im, size_t index, float *re_im_out));
+void bdsp_hip_set_map_complex_bridge64(void (*fn)(double re, double im, size_t index, double *re_im_out));
+bdsp_complex32 bdsp_hip_map_complex_bridge32(bdsp_complex32 value, size_t index);
+bdsp_complex64 bdsp_hip_map_complex_bridge64(bdsp_complex64 value, size_t index);
+
 /* ========================================================================================
  * B2m -- matrix / batch API: `rows` equally long vectors in one allocation, every operation a
  *        batched launch.  The reference's matrix crate has no C facade; these entry points mirror

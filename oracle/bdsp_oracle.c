@@ -32,7 +32,10 @@
 #define R_FLOOR floorf
 #define R_ROUND roundf
 #define R_FABS fabsf
+#define MF(name) name##f
 #include "bdsp_oracle_impl.h"
+#include "bdsp_oracle_math_impl.h"
+#undef MF
 #undef REAL
 #undef SFX
 #undef R_SIN
@@ -55,7 +58,9 @@
 #define R_FLOOR floor
 #define R_ROUND round
 #define R_FABS fabs
+#define MF(name) name
 #include "bdsp_oracle_impl.h"
+#include "bdsp_oracle_math_impl.h"
 
 /* Synthetic input generator shared by tests and bench:
  * counter-based splitmix64(seed + index) -> uniform [lo, hi). */

@@ -347,3 +347,75 @@ def dot(x, y, is_complex):
     fn.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]; fn.restype = None
     fn(_p(x), _p(y), min(x.size, y.size), int(is_complex), _p(out))
     return complex(out[0], out[1]) if is_complex else out[0]
+
+
+# ---- per-element math family, differences / running sums, phase wrapping, split / merge ----------------------
+MATH_IDS = {name: i for i, name in enumerate(
+    ["sqrt", "square", "powf", "ln", "exp", "log", "expf", "sin", "cos", "tan", "asin", "acos", "atan", "sinh",
+     "cosh", "tanh", "asinh", "acosh", "atanh", "abs", "wrap", "expf_approx", "powf_approx"])}
+
+
+def _scalar(dtype):
+    return C.c_float if np.dtype(dtype) == np.float32 else C.c_double
+
+
+def math(x, is_complex, name, arg=0.0):
+    out = np.array(x, copy=True); fn = _fn("orc_math", out.dtype)
+    fn.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, _scalar(out.dtype)]; fn.restype = None
+    fn(_p(out), out.size, int(is_complex), MATH_IDS[name], arg)
+    return out
+
+
+def diff(x, is_complex, with_start=False):
+    out = np.array(x, copy=True)
+    if with_start:
+        fn = _fn("orc_diff_with_start", out.dtype); fn.argtypes = [C.c_void_p, C.c_size_t, C.c_int]; fn.restype = None
+        fn(_p(out), out.size, int(is_complex))
+        return out
+    fn = _fn("orc_diff", out.dtype); fn.argtypes = [C.c_void_p, C.c_size_t, C.c_int]; fn.restype = C.c_size_t
+    return out[: fn(_p(out), out.size, int(is_complex))]
+
+
+def cum_sum(x, is_complex):
+    out = np.array(x, copy=True); fn = _fn("orc_cum_sum", out.dtype)
+    fn.argtypes = [C.c_void_p, C.c_size_t, C.c_int]; fn.restype = None
+    fn(_p(out), out.size, int(is_complex))
+    return out
+
+
+def unwrap(x, divisor):
+    out = np.array(x, copy=True); fn = _fn("orc_unwrap", out.dtype)
+    fn.argtypes = [C.c_void_p, C.c_size_t, _scalar(out.dtype)]; fn.restype = None
+    fn(_p(out), out.size, divisor)
+    return out
+
+
+def get_mag_phase(x):
+    x = np.ascontiguousarray(x); mag = np.zeros(x.size // 2, x.dtype); ph = np.zeros(x.size // 2, x.dtype)
+    fn = _fn("orc_get_mag_phase", x.dtype); fn.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+    fn.restype = None
+    fn(_p(x), x.size, _p(mag), _p(ph))
+    return mag, ph
+
+
+def set_mag_phase(mag, phase):
+    mag = np.ascontiguousarray(mag); phase = np.ascontiguousarray(phase, dtype=mag.dtype)
+    out = np.zeros(2 * mag.size, mag.dtype); fn = _fn("orc_set_mag_phase", mag.dtype)
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]; fn.restype = None
+    fn(_p(mag), _p(phase), mag.size, _p(out))
+    return out
+
+
+def split_into(x, is_complex, n):
+    x = np.ascontiguousarray(x); out = np.zeros(x.size, x.dtype); fn = _fn("orc_split_into", x.dtype)
+    fn.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_size_t, C.c_void_p]; fn.restype = C.c_int
+    code = fn(_p(x), x.size, int(is_complex), n, _p(out))
+    return code, ([out[k * (x.size // n):(k + 1) * (x.size // n)] for k in range(n)] if code == 0 else [])
+
+
+def merge(sources, is_complex):
+    src = np.ascontiguousarray(np.concatenate(sources)); out = np.zeros(src.size, src.dtype)
+    fn = _fn("orc_merge", src.dtype); fn.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_size_t, C.c_void_p]
+    fn.restype = None
+    fn(_p(src), sources[0].size, int(is_complex), len(sources), _p(out))
+    return out

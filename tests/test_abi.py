@@ -15,8 +15,10 @@ def declared_functions():
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     text = re.sub(r"^\s*#.*$", "", text, flags=re.M)  # preprocessor lines (#define X (-1) ...)
     text = re.sub(r"typedef[^;{]*\(\s*\*[^;]*;", "", text)  # function-pointer typedefs are not exports
+    # declarations bound to another symbol name (powf32 & co. clash with <math.h>): the label is what is exported
+    text = re.sub(r"\b[A-Za-z_][A-Za-z0-9_]*(\s*\([^;{}()]*\))\s*BDSP_FACADE_SYMBOL\((\w+)\)\s*;", r"\2\1;", text)
     names = re.findall(r"\b([A-Za-z_][A-Za-z0-9_]*)\s*\([^;{}]*\)\s*;", text)
-    return sorted(set(n for n in names if n not in ("defined",)))
+    return sorted(set(n for n in names if n not in ("defined", "void")))  # "void (*fn)(...)" members
 
 
 def test_header_declares_the_expected_surface():

@@ -1018,3 +1018,220 @@ def test_statistics_sums_dot_products(dtype):
     assert (t["max_index"], t["min_index"]) == (1, 3)
     e0 = DspVec(dtype=dtype, length=0).statistics()
     assert e0["count"] == 0 and np.isnan(e0["average"]) and e0["min"] == np.inf and e0["max"] == -np.inf
+
+
+# ---- the facade's remaining families: per-element math, differences / running sums, pairs, split / merge, callbacks
+_MATH_DOMAINS = {  # real input ranges that keep the function real-valued
+    "sqrt": (0.0, 50.0), "square": (-10, 10), "ln": (1e-3, 50.0), "exp": (-10, 10), "sin": (-10, 10), "cos": (-10, 10),
+    "tan": (-1.4, 1.4), "asin": (-0.99, 0.99), "acos": (-0.99, 0.99), "atan": (-10, 10), "sinh": (-8, 8),
+    "cosh": (-8, 8), "tanh": (-8, 8), "asinh": (-10, 10), "acosh": (1.01, 50.0), "atanh": (-0.99, 0.99),
+    "abs": (-10, 10), "ln_approx": (1e-3, 50.0), "exp_approx": (-10, 10), "sin_approx": (-10, 10),
+    "cos_approx": (-10, 10)}
+_MATH_ARGS = {"powf": ((0.1, 10.0), 2.5), "root": ((0.1, 10.0), 3.0), "log": ((1e-3, 50.0), 10.0),
+              "expf": ((-3, 3), 10.0), "wrap": ((-20, 20), 4.0), "log_approx": ((1e-3, 50.0), 10.0),
+              "expf_approx": ((-3, 3), 10.0), "powf_approx": ((0.1, 10.0), 2.5)}
+
+
+def _oracle_math(x, cplx, name, arg):
+    key = {"ln_approx": "ln", "exp_approx": "exp", "sin_approx": "sin", "cos_approx": "cos", "log_approx": "log"}.get(name, name)
+    if name == "root":
+        key, arg = "powf", 1.0 / arg
+    return orc.math(x.astype(np.float64), cplx, key, arg)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_math_family(dtype):
+    # doc-test KATs (trigonometry_and_powers.rs:14-189)
+    v = DspVec(np.array([1, 4, 9, 16, 25], dtype))
+    assert v.sqrt() == 0 and list(v.data()) == [1, 2, 3, 4, 5]
+    v = DspVec(np.array([1, 2, 3], dtype))
+    assert v.expf(10.0) == 0
+    np.testing.assert_allclose(v.data(), [10, 100, 1000], rtol=1e-6)
+    v = DspVec(np.array([1, 8, 27], dtype))
+    assert v.root(3.0) == 0
+    np.testing.assert_allclose(v.data(), [1, 2, 3], rtol=1e-6)
+    tol = 3e-6 if dtype == np.float32 else 1e-13
+    n = 100_003
+    for name, (lo, hi) in _MATH_DOMAINS.items():
+        x = orc.fill_uniform(n, 31, lo, hi, dtype)
+        v = DspVec(x)
+        assert getattr(v, name)() == 0, name
+        ref = _oracle_math(x, False, name, 0.0)
+        assert np.max(np.abs(v.data() - ref) / (np.abs(ref) + 1.0)) < tol, name
+    for name, ((lo, hi), arg) in _MATH_ARGS.items():
+        x = orc.fill_uniform(n, 32, lo, hi, dtype)
+        v = DspVec(x)
+        assert getattr(v, name)(arg) == 0, name
+        ref = _oracle_math(x, False, name, arg)
+        assert np.max(np.abs(v.data() - ref) / (np.abs(ref) + 1.0)) < tol * 4, name
+    # complex vectors: TrigOps / PowerOps follow num-complex's formulas, the RealOps family poisons
+    ctol = 2e-5 if dtype == np.float32 else 1e-12
+    x = orc.fill_uniform(2 * n, 33, -3, 3, dtype)
+    for name in ("sqrt", "square", "ln", "exp", "sin", "cos", "tan", "asin", "acos", "atan", "sinh", "cosh", "tanh",
+                 "asinh", "acosh", "atanh"):
+        v = DspVec(x, is_complex=True)
+        assert getattr(v, name)() == 0, name
+        ref = _oracle_math(x, True, name, 0.0)
+        assert rel_l2(v.data(), ref) < ctol, name
+    for name, arg in (("powf", 2.5), ("root", 3.0), ("log", 10.0), ("expf", 7.0)):
+        v = DspVec(x, is_complex=True)
+        assert getattr(v, name)(arg) == 0, name
+        assert rel_l2(v.data(), _oracle_math(x, True, name, arg)) < ctol, name
+    for name in ("abs", "ln_approx", "sin_approx"):
+        v = DspVec(x, is_complex=True)
+        assert getattr(v, name)() == -1 and len(v) == 0, name
+    for name in ("wrap", "unwrap", "powf_approx"):
+        v = DspVec(x, is_complex=True)
+        assert getattr(v, name)(2.0) == -1, name
+    # special values of the complex square root (sign of zero) and powf(0)
+    z = DspVec(np.array([-4, 0, -4, -0.0, 0, 2, 0, -2, 9, 0], dtype), is_complex=True)
+    assert z.sqrt() == 0
+    np.testing.assert_allclose(z.data(), [0, 2, 0, -2, 1, 1, 1, -1, 3, 0], atol=1e-6)
+    z = DspVec(np.array([3, 4, -1, 2], dtype), is_complex=True)
+    assert z.powf(0.0) == 0 and list(z.data()) == [1, 0, 1, 0]
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_diff_cum_sum_wrap_unwrap(dtype):
+    # KATs diff_sum.rs:18-53, real_ops.rs:49-65
+    v = DspVec(np.array([2, 3, 2, 6], dtype))
+    assert v.diff() == 0 and list(v.data()) == [1, -1, 4]
+    v = DspVec(np.array([2, 2, 3, 3, 5, 5], dtype), is_complex=True)
+    assert v.diff_with_start() == 0 and list(v.data()) == [2, 2, 1, 1, 2, 2]
+    v = DspVec(np.array([2, 1, -1, 4], dtype))
+    assert v.cum_sum() == 0 and list(v.data()) == [2, 3, 2, 6]
+    v = DspVec(np.arange(1, 9, dtype=dtype))
+    assert v.wrap(4.0) == 0 and list(v.data()) == [1, 2, 3, 0, 1, 2, 3, 0]
+    assert v.unwrap(4.0) == 0 and list(v.data()) == [1, 2, 3, 4, 5, 6, 7, 8]
+    for cplx, n in ((False, 1), (False, 4097), (False, 300_001), (True, 1), (True, 5000), (True, 262_147)):
+        e = 2 if cplx else 1
+        x = orc.fill_uniform(n * e, 40 + n, -10, 10, dtype)
+        for with_start in (False, True):
+            v = DspVec(x, is_complex=cplx)
+            assert (v.diff_with_start() if with_start else v.diff()) == 0
+            assert np.array_equal(v.data(), orc.diff(x, cplx, with_start)), (cplx, n, with_start)   # bit-exact
+        v = DspVec(x, is_complex=cplx)
+        assert v.cum_sum() == 0
+        ref = np.cumsum(x.astype(np.float64).reshape(-1, e), axis=0).reshape(-1)
+        scale = np.max(np.abs(ref)) + 1.0
+        # f32: the double running sum rounded once; f64: a different (blocked) summation order than numpy's
+        assert np.max(np.abs(v.data() - ref)) / scale < (2e-7 if dtype == np.float32 else 1e-13), (cplx, n)
+        # ... and the reference's running sum in T (its own rounding) stays within its error bound of ours
+        seq = orc.cum_sum(x, cplx)
+        assert np.max(np.abs(seq - ref)) / scale < (n * 1e-7 if dtype == np.float32 else n * 1e-16)
+    # unwrap: a phase ramp wrapped into (-pi, pi], and random data (the recurrence is sequential: bit-exact)
+    t = np.arange(50_001, dtype=np.float64) * 0.37
+    for data, div in ((np.angle(np.exp(1j * t)).astype(dtype), 2 * np.pi), (orc.fill_uniform(20_000, 5, -30, 30, dtype), 7.0),
+                      (orc.fill_uniform(9000, 6, -1, 1, dtype), 0.25)):
+        v = DspVec(data)
+        assert v.unwrap(dtype(div)) == 0
+        assert np.array_equal(v.data(), orc.unwrap(data, dtype(div)))
+    v = DspVec(np.angle(np.exp(1j * t)).astype(dtype))
+    v.unwrap(dtype(2 * np.pi))
+    np.testing.assert_allclose(v.data(), t, atol=2e-2 if dtype == np.float32 else 1e-9)
+    # empty vectors stay empty
+    e0 = DspVec(dtype=dtype, length=0)
+    assert e0.diff() == 0 and e0.cum_sum() == 0 and e0.unwrap(1.0) == 0 and len(e0) == 0
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_pairs_split_merge_map(dtype):
+    n = 70_001
+    x = orc.fill_uniform(2 * n, 51, -10, 10, dtype)
+    z = DspVec(x, is_complex=True)
+    a, b = DspVec(dtype=dtype, length=0), DspVec(dtype=dtype, length=3)
+    assert z.get_real_imag(a, b) == 9 and np.array_equal(a.data(), x[0::2]) and np.array_equal(b.data(), x[1::2])
+    assert z.get_mag_phase(a, b) == 9
+    mag, ph = orc.get_mag_phase(x.astype(np.float64))
+    tol = 2e-6 if dtype == np.float32 else 1e-14
+    assert rel_l2(a.data(), mag) < tol and np.max(np.abs(b.data() - ph)) < tol * 4
+    w = DspVec(dtype=dtype, length=0, is_complex=True)
+    assert w.set_mag_phase(a, b) == 0 and len(w) == 2 * n and rel_l2(w.data(), x) < tol * 4
+    assert w.set_real_imag(b, a) == 0 and np.array_equal(w.data()[0::2], b.data()) and np.array_equal(w.data()[1::2], a.data())
+    assert w.set_real_imag(a, DspVec(np.zeros(5, dtype))) == 7
+    c = DspVec(dtype=dtype, length=4, is_complex=True)
+    assert DspVec(x[:10]).get_real_imag(a, b) == 9 and len(a) == 0 and len(b) == 0     # real source empties both
+    assert z.get_real_imag(a, c) == 9 and len(a) == 0 and len(c) == 0                  # complex target too
+    # split_into / merge (data_reorganization.rs:185-212 and round trips)
+    v = DspVec(np.arange(1, 11, dtype=dtype))
+    t = [DspVec(dtype=dtype, length=0), DspVec(dtype=dtype, length=0)]
+    assert v.split_into(t) == 9 and list(t[0].data()) == [1, 3, 5, 7, 9] and list(t[1].data()) == [2, 4, 6, 8, 10]
+    m = DspVec(dtype=dtype, length=0)
+    assert m.merge([DspVec(np.array([1, 2], dtype)), DspVec(np.array([1, 2], dtype))]) == 0 and list(m.data()) == [1, 1, 2, 2]
+    assert DspVec(np.arange(9, dtype=dtype)).split_into(t) == 7 and v.split_into([]) == 7 and m.merge([]) == 7
+    assert m.merge([DspVec(np.zeros(2, dtype)), DspVec(np.zeros(3, dtype))]) == 7
+    for cplx, parts in ((False, 3), (True, 3), (True, 7), (False, 16)):
+        e = 2 if cplx else 1
+        xx = orc.fill_uniform(parts * 3001 * e, 60 + parts, -10, 10, dtype)
+        src = DspVec(xx, is_complex=cplx)
+        tg = [DspVec(dtype=dtype, length=0, is_complex=cplx) for _ in range(parts)]
+        assert src.split_into(tg) == 9
+        code, ref = orc.split_into(xx, cplx, parts)
+        assert code == 0 and all(np.array_equal(tg[k].data(), ref[k]) for k in range(parts))
+        back = DspVec(dtype=dtype, length=0, is_complex=cplx)
+        assert back.merge(tg) == 0 and np.array_equal(back.data(), xx)
+    # host callbacks: map_inplace / map_aggregate
+    r = DspVec(x[:1000])
+    assert r.map_inplace(lambda val, i: val * 2 + i) == 0
+    np.testing.assert_allclose(r.data(), x[:1000] * 2 + np.arange(1000), rtol=1e-6)
+    zc = DspVec(x[:1000], is_complex=True)
+    assert zc.map_inplace(lambda val, i: val * 1j + i) == 0
+    ref = (x[0:1000:2] + 1j * x[1:1000:2]) * 1j + np.arange(500)
+    np.testing.assert_allclose(zc.data()[0::2] + 1j * zc.data()[1::2], ref, rtol=1e-6)
+    assert DspVec(x[:10]).map_inplace(lambda val, i: val) == 0 and zc.clone().map_inplace(lambda val, i: val) == 0
+    code, total = DspVec(x[:1000]).map_aggregate(lambda val, i: val * i, lambda p, q: p + q)
+    assert code == 0 and abs(total - float(np.dot(x[:1000].astype(np.float64), np.arange(1000)))) < 1e-3 * 1000
+    code, best = zc.map_aggregate(lambda val, i: (abs(val), i), max)
+    assert code == 0 and best[1] == int(np.argmax(np.abs(ref)))
+    assert DspVec(dtype=dtype, length=0).map_aggregate(lambda val, i: val, max)[0] == 12
+    assert zc.clone()._fn("map_aggregate_real") is not None
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_callback_variants_of_convolution_and_interpolation(dtype):
+    tol = 5e-6 if dtype == np.float32 else 1e-11
+    sinc = lambda t: float(np.sinc(t))
+    x = orc.fill_uniform(2 * 3000, 71, -10, 10, dtype)
+    # complex impulse response: a real-valued one reproduces the built-in, a complex one the direct sum
+    for points, L in ((3000, 9), (11, 5), (7, 20)):
+        xx = x[: 2 * points]
+        v = DspVec(xx, is_complex=True)
+        assert v.convolve_complex(lambda t: complex(np.sinc(t), 0.0), 0.5, L) == 0
+        ref = orc.convolve_function(xx.astype(np.float64), True, 0, 0.0, 0.5, L)
+        assert rel_l2(v.data(), ref) < tol, (points, L)
+        h = lambda t: complex(np.sinc(t), 0.25 * t)
+        v = DspVec(xx, is_complex=True)
+        assert v.convolve_complex(h, 0.5, L) == 0
+        zz = xx[0::2].astype(np.float64) + 1j * xx[1::2]
+        Lc = min(L, points)
+        ref = np.array([sum(zz[(i + m) % points] * h(-m * 0.5) for m in range(-Lc, Lc + 1)) for i in range(points)])
+        got = v.data()[0::2] + 1j * v.data()[1::2]
+        assert np.linalg.norm(got - ref) / np.linalg.norm(ref) < tol, (points, L)
+    assert DspVec(x[:100]).convolve_complex(lambda t: 1.0, 0.5, 3) == -1                 # assert_complex!
+    # complex frequency response (natural-order axis j / max * ratio, scaled by ratio)
+    for points in (1000, 1001):
+        xx = x[: 2 * points]
+        f = DspVec(xx, is_complex=True, domain=V.FREQ)
+        fr = lambda t: complex(1.0 / (1.0 + t * t), 0.5 * t)
+        assert f.multiply_frequency_response_complex(fr, 0.5) == 0
+        maxv = (points - points % 2) / 2
+        hh = np.array([0.5 * fr((-maxv + i) / maxv * 0.5) for i in range(points)])
+        ref = (xx[0::2].astype(np.float64) + 1j * xx[1::2]) * hh
+        got = f.data()[0::2] + 1j * f.data()[1::2]
+        assert np.linalg.norm(got - ref) / np.linalg.norm(ref) < tol
+    assert DspVec(x[:100], is_complex=True).multiply_frequency_response_complex(lambda t: 1.0, 0.5) == -1
+    # interpolation with a callback equals the built-in function of the same shape
+    for cplx in (True, False):
+        e = 2 if cplx else 1
+        xx = x[: 600 * e]
+        a, b = DspVec(xx, is_complex=cplx), DspVec(xx, is_complex=cplx)
+        assert a.interpolatei_custom(lambda t: 1.0 if abs(t) <= 1.0 else 0.0, 3) == 0 and b.interpolatei(V.CONV_SINC, 3) == 0
+        assert rel_l2(a.data(), b.data()) < tol
+        a, b = DspVec(xx, is_complex=cplx), DspVec(xx, is_complex=cplx)
+        assert a.interpolate_custom(lambda t: 1.0 if abs(t) <= 1.0 else 0.0, 1500, 0.0) == 0
+        assert b.interpolate(V.CONV_SINC, 1500, 0.0) == 0
+        assert rel_l2(a.data(), b.data()) < tol and a.delta() == b.delta()
+        for factor, L in ((4.0, 12), (2.5, 8)):      # table path / scalar path
+            a, b = DspVec(xx, is_complex=cplx), DspVec(xx, is_complex=cplx)
+            assert a.interpolatef_custom(sinc, factor, 0.0, L) == 0 and b.interpolatef(V.CONV_SINC, factor, 0.0, L) == 0
+            assert len(a) == len(b) and rel_l2(a.data(), b.data()) < tol * 4, (cplx, factor)

@@ -470,3 +470,57 @@ def test_statistics_sums_dot_products_kats():
     r = orc.real_statistics(np.array([3, -1, 4, -1, 5], np.float32))
     assert (r["sum"], r["count"], r["min"], r["min_index"], r["max"], r["max_index"]) == (10, 5, -1, 1, 5, 4)
     assert r["average"] == 2 and abs(r["rms"] - np.sqrt(52 / 5)) < 1e-6
+
+
+def test_math_family_diff_sum_wrap_split_merge_kats():
+    """Doc-test values of trigonometry_and_powers.rs:14-189, real_ops.rs:21-65, diff_sum.rs:18-53,
+    data_reorganization.rs:185-212, plus identities that pin the complex (num-complex) formulas."""
+    f = np.float32
+    pi = np.float32(np.pi)
+    assert list(orc.math(np.array([pi / 2, -pi / 2], f), False, "sin")) == [1.0, -1.0]
+    assert list(orc.math(np.array([2 * pi, pi], f), False, "cos")) == [1.0, -1.0]
+    assert list(orc.math(np.array([1, 4, 9, 16, 25], f), False, "sqrt")) == [1, 2, 3, 4, 5]
+    assert np.isnan(orc.math(np.array([-1], f), False, "sqrt")[0])
+    assert list(orc.math(np.array([1, 2, 3, 4, 5], f), False, "square")) == [1, 4, 9, 16, 25]
+    np.testing.assert_allclose(orc.math(np.array([1, 8, 27], f), False, "powf", 1 / f(3)), [1, 2, 3], rtol=1e-6)
+    assert list(orc.math(np.array([1, 2, 3], f), False, "powf", 3.0)) == [1, 8, 27]
+    e = np.array([2.718281828459045, 7.389056, 20.085537])
+    for name in ("ln", ):
+        np.testing.assert_allclose(orc.math(e, False, name), [1, 2, 3], atol=1e-4)
+    np.testing.assert_allclose(orc.math(np.array([1.0, 2, 3]), False, "exp"), e, atol=1e-4)
+    np.testing.assert_allclose(orc.math(np.array([10.0, 100, 1000]), False, "log", 10.0), [1, 2, 3], atol=1e-4)
+    np.testing.assert_allclose(orc.math(np.array([1, 2, 3], f), False, "expf", 10.0), [10, 100, 1000], rtol=1e-6)
+    np.testing.assert_allclose(orc.math(np.array([1, 2, 3], f), False, "expf_approx", 10.0), [10, 100, 1000], rtol=1e-4)
+    np.testing.assert_allclose(orc.math(np.array([1, 2, 3], f), False, "powf_approx", 3.0), [1, 8, 27], rtol=1e-4)
+    assert list(orc.math(np.array([1, -2], f), False, "abs")) == [1, 2]
+    assert list(orc.math(np.arange(1, 9, dtype=f), False, "wrap", 4.0)) == [1, 2, 3, 0, 1, 2, 3, 0]
+    assert list(orc.unwrap(np.array([1, 2, 3, 0, 1, 2, 3, 0], f), 4.0)) == [1, 2, 3, 4, 5, 6, 7, 8]
+    assert list(orc.diff(np.array([2, 3, 2, 6], f), False)) == [1, -1, 4]
+    assert list(orc.diff(np.array([2, 2, 3, 3, 5, 5], f), True)) == [1, 1, 2, 2]
+    assert list(orc.diff(np.array([2, 3, 2, 6], f), False, True)) == [2, 1, -1, 4]
+    assert list(orc.diff(np.array([2, 2, 3, 3, 5, 5], f), True, True)) == [2, 2, 1, 1, 2, 2]
+    assert list(orc.cum_sum(np.array([2, 1, -1, 4], f), False)) == [2, 3, 2, 6]
+    assert list(orc.cum_sum(np.array([2, 2, 1, 1, 2, 2], f), True)) == [2, 2, 3, 3, 5, 5]
+    code, parts = orc.split_into(np.arange(1, 11, dtype=f), False, 2)
+    assert code == 0 and list(parts[0]) == [1, 3, 5, 7, 9] and list(parts[1]) == [2, 4, 6, 8, 10]
+    assert orc.split_into(np.arange(1, 10, dtype=f), False, 2)[0] == 7
+    assert list(orc.merge([np.array([1, 2], f), np.array([1, 2], f)], False)) == [1, 1, 2, 2]
+    # complex family against numpy's complex functions (same principal branches) on a seeded vector
+    x = orc.fill_uniform(2000, 77, -3, 3, np.float64)
+    z = x[0::2] + 1j * x[1::2]
+    ref = {"sqrt": np.sqrt, "square": lambda v: v * v, "ln": np.log, "exp": np.exp, "sin": np.sin, "cos": np.cos,
+           "tan": np.tan, "asin": np.arcsin, "acos": np.arccos, "atan": np.arctan, "sinh": np.sinh, "cosh": np.cosh,
+           "tanh": np.tanh, "asinh": np.arcsinh, "acosh": np.arccosh, "atanh": np.arctanh}
+    for name, fn in ref.items():
+        got = orc.math(x, True, name)
+        np.testing.assert_allclose(got[0::2] + 1j * got[1::2], fn(z), rtol=1e-9, atol=1e-9, err_msg=name)
+    got = orc.math(x, True, "powf", 2.5)
+    np.testing.assert_allclose(got[0::2] + 1j * got[1::2], z ** 2.5, rtol=1e-10, atol=1e-10)
+    got = orc.math(x, True, "log", 7.0)
+    np.testing.assert_allclose(got[0::2] + 1j * got[1::2], np.log(z) / np.log(7.0), rtol=1e-10, atol=1e-12)
+    got = orc.math(x, True, "expf", 7.0)
+    np.testing.assert_allclose(got[0::2] + 1j * got[1::2], 7.0 ** z, rtol=1e-10, atol=1e-12)
+    mag, ph = orc.get_mag_phase(x)
+    np.testing.assert_allclose(mag, np.abs(z), rtol=1e-14)
+    np.testing.assert_allclose(ph, np.angle(z), rtol=1e-14)
+    np.testing.assert_allclose(orc.set_mag_phase(mag, ph), x, atol=1e-13)
