@@ -45,6 +45,11 @@ size_t conv_fft_len(size_t) { return CONV_L; }
 //     80 us, one block per non-persistent workgroup 149 us, and a 512-thread workgroup of two
 //     anti-phased subgroups with hand-scheduled memory traffic (SGPR-base addressing, staged stores,
 //     explicit s_waitcnt; tools/experiments/conv_antiphase_kernel.hip.txt) 88 us;
+//     and ONE WAVEFRONT per block (lane t owns x[t + 64 r]: two DFT-64 register stages per transform, two
+//     LDS exchanges and no workgroup barrier at all, H and the split twiddles in the 512-register budget of a
+//     single wave per SIMD; tools/experiments/conv_wave_kernel.hip.txt) 100 us -- 87 us of it with the global
+//     loads removed: a lone wave per SIMD issues a dependent packed instruction only every ~11 clocks, and
+//     two waves per SIMD do not fit (8 x 33 KB of exchange space, 128 registers of H per wave);
 //   * two facts from that last experiment that any future prefetching version must respect: a store
 //     reads its address and data VGPRs LATE, so the compiler makes arithmetic that reuses one of them
 //     wait for the store to retire; and vmcnt counts loads and stores together, so with predicated
