@@ -166,15 +166,18 @@ template <typename T> int vm_diff(const T* in, T* out, size_t n_out, size_t step
 constexpr int SCAN_PER_THREAD = 16;
 constexpr int SCAN_CHUNK = 256 * SCAN_PER_THREAD; // elements per workgroup
 
+// chunk sums: order does not matter, so the chunk is read with unit stride across the workgroup
 template <typename T, int E>
 __global__ __launch_bounds__(256) void k_scan_sums(const T* __restrict__ x, size_t n, double* __restrict__ sums)
 {
     __shared__ double sh[E][256];
-    const size_t base = (size_t)blockIdx.x * SCAN_CHUNK + (size_t)threadIdx.x * SCAN_PER_THREAD;
+    const size_t base = (size_t)blockIdx.x * SCAN_CHUNK;
     double acc[E] = {};
-    for (int k = 0; k < SCAN_PER_THREAD; ++k)
-        if (base + k < n)
-            for (int c = 0; c < E; ++c) acc[c] += (double)x[(base + k) * E + c];
+    for (int k = 0; k < SCAN_PER_THREAD; ++k) {
+        const size_t i = base + (size_t)k * 256 + threadIdx.x;
+        if (i < n)
+            for (int c = 0; c < E; ++c) acc[c] += (double)x[i * E + c];
+    }
     for (int c = 0; c < E; ++c) sh[c][threadIdx.x] = acc[c];
     __syncthreads();
     for (int s = 128; s > 0; s >>= 1) {
@@ -209,18 +212,31 @@ __global__ __launch_bounds__(256) void k_scan_offsets(double* __restrict__ sums,
         for (int c = 0; c < E; ++c) { const double v = sums[i * E + c]; sums[i * E + c] = run[c]; run[c] += v; }
 }
 
+// A thread scans 16 CONSECUTIVE elements; the chunk travels global <-> LDS with unit stride across the workgroup
+// (element e lives at LDS slot e + e/16, so the per-thread runs start in different banks).  Reading the runs
+// straight from global memory -- every lane its own cache line -- measured 511 us for 16M complex f32 points.
 template <typename T, int E>
 __global__ __launch_bounds__(256) void k_scan_apply(T* __restrict__ x, size_t n, const double* __restrict__ offsets)
 {
+    struct El { T c[E]; };
+    __shared__ El tile[SCAN_CHUNK + SCAN_CHUNK / 16];
     __shared__ double sh[E][256];
-    const size_t base = (size_t)blockIdx.x * SCAN_CHUNK + (size_t)threadIdx.x * SCAN_PER_THREAD;
+    const size_t base = (size_t)blockIdx.x * SCAN_CHUNK;
+    El* xe = reinterpret_cast<El*>(x);
+    for (int k = 0; k < SCAN_PER_THREAD; ++k) {
+        const int e = k * 256 + threadIdx.x;
+        El v;
+        for (int c = 0; c < E; ++c) v.c[c] = T(0);
+        if (base + e < n) v = xe[base + e];
+        tile[e + (e >> 4)] = v;
+    }
+    __syncthreads();
     double v[SCAN_PER_THREAD][E];
     double acc[E] = {};
-    for (int k = 0; k < SCAN_PER_THREAD; ++k)
-        for (int c = 0; c < E; ++c) {
-            v[k][c] = base + k < n ? (double)x[(base + k) * E + c] : 0.0;
-            acc[c] += v[k][c];
-        }
+    for (int k = 0; k < SCAN_PER_THREAD; ++k) {
+        const El el = tile[threadIdx.x * 17 + k];
+        for (int c = 0; c < E; ++c) { v[k][c] = (double)el.c[c]; acc[c] += v[k][c]; }
+    }
     for (int c = 0; c < E; ++c) sh[c][threadIdx.x] = acc[c];
     __syncthreads();
     // Hillis-Steele inclusive scan of the 256 thread totals
@@ -233,9 +249,16 @@ __global__ __launch_bounds__(256) void k_scan_apply(T* __restrict__ x, size_t n,
     }
     double run[E];
     for (int c = 0; c < E; ++c) run[c] = offsets[(size_t)blockIdx.x * E + c] + (threadIdx.x ? sh[c][threadIdx.x - 1] : 0.0);
-    for (int k = 0; k < SCAN_PER_THREAD; ++k)
-        if (base + k < n)
-            for (int c = 0; c < E; ++c) { run[c] += v[k][c]; x[(base + k) * E + c] = (T)run[c]; }
+    for (int k = 0; k < SCAN_PER_THREAD; ++k) {
+        El el;
+        for (int c = 0; c < E; ++c) { run[c] += v[k][c]; el.c[c] = (T)run[c]; }
+        tile[threadIdx.x * 17 + k] = el;
+    }
+    __syncthreads();
+    for (int k = 0; k < SCAN_PER_THREAD; ++k) {
+        const int e = k * 256 + threadIdx.x;
+        if (base + e < n) xe[base + e] = tile[e + (e >> 4)];
+    }
 }
 
 // `scratch` holds E doubles per chunk of SCAN_CHUNK elements
@@ -266,31 +289,50 @@ template <typename T> int vm_cum_sum(T* x, size_t len, bool is_complex, void* sc
 // ---- unwrap (real_ops.rs:262-284) --------------------------------------------------------------------------------
 // y[j] = F(x[j], y[j-1]) with a data-dependent branch on the ALREADY UNWRAPPED neighbour: a genuinely sequential
 // recurrence (its state does not reduce to an associative operator), so one lane walks the vector while the
-// wavefront stages tiles through LDS with coalesced packets.  Exact, not fast (about 10 ns per sample).
+// wavefront stages tiles through LDS with coalesced packets.  Exact, not fast (see DESIGN.md for the rate).
+// fmod on the serial critical path: the remainder a - trunc(a/b)*b is exactly representable, so one fma returns it
+// exactly when the quotient is right; a quotient off by one (a/b rounded across an integer) shows as a remainder
+// outside [0, |b|) and is redone.  Huge quotients, infinities and NaNs go to the library function.
+template <typename T>
+__device__ __forceinline__ T fmod_exact(T a, T b, T inv_abs_b)
+{
+    const T A = fabs(a), Bv = fabs(b);
+    T q = trunc(A * inv_abs_b); // a guess within one of trunc(A / Bv): the checks below settle it
+    if (!(q < (T)(sizeof(T) == 4 ? 4194304.0 : 2251799813685248.0))) return fmod(a, b);
+    T r = fma(-q, Bv, A);
+    if (r < T(0)) r = fma(-(q - T(1)), Bv, A);
+    else if (r >= Bv) r = fma(-(q + T(1)), Bv, A);
+    return copysign(r, a);
+}
+
 template <typename T>
 __global__ __launch_bounds__(64) void k_unwrap(T* __restrict__ x, size_t len, T divisor)
 {
-    constexpr int TILE = 4096;
-    __shared__ T tile[TILE];
+    constexpr int TILE = 2048;
+    __shared__ T tin[TILE];
+    __shared__ T tout[TILE]; // a second array: the walker's reads never wait for its own writes
     const T half = divisor / T(2);
+    const T inv = T(1) / fabs(divisor);
     T prev = T(0);
     for (size_t base = 0; base < len; base += TILE) {
         const int m = len - base < (size_t)TILE ? (int)(len - base) : TILE;
-        for (int i = threadIdx.x; i < m; i += 64) tile[i] = x[base + i];
+        for (int i = threadIdx.x; i < m; i += 64) tin[i] = x[base + i];
         __syncthreads();
         if (threadIdx.x == 0) {
             int j = 0;
-            if (base == 0) { prev = tile[0]; j = 1; }
+            if (base == 0) { prev = tin[0]; tout[0] = prev; j = 1; }
+#pragma unroll 8
             for (; j < m; ++j) {
-                T cur = tile[j];
+                T cur = tin[j];
                 T diff = cur - prev;
-                if (diff > half) { diff = fmod(diff, divisor); diff = diff - divisor; cur = prev + diff; tile[j] = cur; }
-                else if (diff < -half) { diff = fmod(diff, divisor); diff = diff + divisor; cur = prev + diff; tile[j] = cur; }
+                if (diff > half) { diff = fmod_exact(diff, divisor, inv); diff = diff - divisor; cur = prev + diff; }
+                else if (diff < -half) { diff = fmod_exact(diff, divisor, inv); diff = diff + divisor; cur = prev + diff; }
+                tout[j] = cur;
                 prev = cur;
             }
         }
         __syncthreads();
-        for (int i = threadIdx.x; i < m; i += 64) x[base + i] = tile[i];
+        for (int i = threadIdx.x; i < m; i += 64) x[base + i] = tout[i];
         __syncthreads();
     }
 }

@@ -1126,6 +1126,13 @@ def test_diff_cum_sum_wrap_unwrap(dtype):
         v = DspVec(data)
         assert v.unwrap(dtype(div)) == 0
         assert np.array_equal(v.data(), orc.unwrap(data, dtype(div)))
+    # quotients near integers and large ratios exercise the exact-remainder path and its library fallback
+    big = (orc.fill_uniform(4000, 8, -1, 1, dtype) * dtype(1e6)).astype(dtype)
+    big[::7] = np.round(big[::7] / 3) * 3
+    for data, div in ((big, 3.0), (big, 1e-3), (orc.fill_uniform(3000, 9, -100, 100, dtype), 0.1)):
+        v = DspVec(data)
+        assert v.unwrap(dtype(div)) == 0
+        assert np.array_equal(v.data(), orc.unwrap(data, dtype(div)))
     v = DspVec(np.angle(np.exp(1j * t)).astype(dtype))
     v.unwrap(dtype(2 * np.pi))
     np.testing.assert_allclose(v.data(), t, atol=2e-2 if dtype == np.float32 else 1e-9)

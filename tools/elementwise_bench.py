@@ -66,10 +66,12 @@ bench("decimatei (/2)", cv, lambda v: v.decimatei(2, 0), B + B // 2)
 # reductions: read-only passes (the vector is not modified, the handle is reused)
 def bench_ro(name, v, op, bytes_moved, reps=10):
     op(v)
+    bd.lib.bdsp_hip_synchronize(None)
     ts = []
     for k in range(reps):
         t0 = time.perf_counter()
         op(v)
+        bd.lib.bdsp_hip_synchronize(None)
         ts.append(time.perf_counter() - t0)
     us = sorted(ts)[len(ts) // 2] * 1e6
     print("%-28s %8.1f us  %6.0f GB/s" % (name, us, bytes_moved / us / 1e3))
@@ -79,3 +81,25 @@ bench_ro("statistics (real 16M)", r, lambda v: v.statistics(), B // 2)
 bench_ro("sum_sq (complex 16M)", c, lambda v: v.sum_sq(), B)
 bench_ro("dot_product (complex 16M)", c, lambda v: v.dot_product(other), 2 * B)
 bench_ro("statistics_split(4)", c, lambda v: v.statistics_split(4), B)
+# per-element math family, differences / running sums, pairs, split / merge
+bench("sqrt (complex)", cv, lambda v: v.sqrt(), 2 * B)
+bench("square (complex)", cv, lambda v: v.square(), 2 * B)
+bench("exp (complex)", cv, lambda v: v.exp(), 2 * B)
+bench("sin (complex)", cv, lambda v: v.sin(), 2 * B)
+bench("ln (complex)", cv, lambda v: v.ln(), 2 * B)
+bench("powf(2.5) (complex)", cv, lambda v: v.powf(2.5), 2 * B)
+bench("atanh (complex)", cv, lambda v: v.atanh(), 2 * B)
+bench("sin (real 16M)", rv, lambda v: v.sin(), B)
+bench("abs (real 16M)", rv, lambda v: v.abs(), B)
+bench("cum_sum (complex)", cv, lambda v: v.cum_sum(), 3 * B)
+bench("cum_sum (real 16M)", rv, lambda v: v.cum_sum(), 3 * B // 2)
+bench("diff_with_start (complex)", cv, lambda v: v.diff_with_start(), 2 * B)
+parts = [DspVec(dtype=np.float32, length=0, is_complex=True) for _ in range(4)]
+bench_ro("split_into(4)", c, lambda v: v.split_into(parts), 2 * B)
+m = DspVec(dtype=np.float32, length=0, is_complex=True)
+bench_ro("merge(4)", m, lambda v: v.merge(parts), 2 * B)
+ga, gb = DspVec(dtype=np.float32, length=0), DspVec(dtype=np.float32, length=0)
+bench_ro("get_mag_phase", c, lambda v: v.get_mag_phase(ga, gb), 2 * B)   # includes the clone the wrapper makes
+bench_ro("set_mag_phase", m, lambda v: v.set_mag_phase(ga, gb), 2 * B)
+u = DspVec(x[: 1 << 20])
+bench_ro("unwrap (real 1M, serial)", u, lambda v: v.unwrap(7.0), (1 << 20) * 8, reps=3)
