@@ -5,10 +5,13 @@
 // The host-side logic here mirrors the reference's operator layer for the hot path: type-state
 // checks, result codes, delta/valid_len bookkeeping and the buffer "trade" of DspVec
 // (vector/src/vector_types/mod.rs:125-229, support_std.rs:78-124).
+#include <atomic>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <mutex>
+#include <thread>
 #include <vector>
 
 #include "bdsp_internal.h"
@@ -284,6 +287,102 @@ int conv_real_dev(const T* in, T* out, size_t points, const T* taps, size_t ntap
     return conv_run_blocks<T>(in, out, points, batch, hsb.as<T>(), ntaps, -(long long)(ntaps / 2), 0, 0, nullptr, s, true);
 }
 
+// gpu_convolve_vector on a long complex vector: the PCIe transfers dominate (128 MiB each way for 16M f32 points
+// against 0.1 ms of kernel time), so they are pipelined.  The input goes up in chunks on its own stream; as soon as
+// a chunk has landed the blocks whose 4096-point windows it completes run on the compute stream; a helper thread
+// brings their outputs down on a third stream while the next chunk is still going up -- PCIe is full duplex.
+// Block 0 and the last blocks read across the wrap-around point and run when the whole vector is resident.
+// *Measured* 16M f32 points x 1024 taps: 4.88 -> 3.94 ms (the two directions share ~68 GB/s on this host;
+// registering the caller's pages first changed nothing).
+template <typename T>
+int b1_convolve_pipelined(const T* src, T* dst, size_t points, const T* imp, size_t ntaps)
+{
+    hipStream_t s = lib_stream();
+    const size_t L = conv_fft_len(ntaps);
+    size_t V = L - (ntaps - 1);
+    if (V >= 16) V &= ~(size_t)15; // the block kernel's aligned step (conv.hip)
+    const size_t nb = (points + V - 1) / V;
+    const long long in_off = -(long long)(ntaps / 2);
+    WsBlock dx, dy, dh, hsb;
+    BDSP_TRY(dx.alloc(sizeof(T) * 2 * points, s));
+    BDSP_TRY(dy.alloc(sizeof(T) * 2 * points, s));
+    BDSP_TRY(dh.alloc(sizeof(T) * 2 * ntaps, s));
+    BDSP_TRY(hsb.alloc(sizeof(T) * 2 * L, s));
+    BDSP_HIP_TRY(hipMemcpyAsync(dh.p, imp, sizeof(T) * 2 * ntaps, hipMemcpyHostToDevice, s));
+    BDSP_TRY(conv_prepare_spectrum<T>(dh.as<T>(), ntaps, nullptr, hsb.as<T>(), s));
+    constexpr int K = 8;
+    size_t ch = ((points + K - 1) / K + 1023) & ~(size_t)1023;
+    int dev = 0;
+    BDSP_HIP_TRY(hipGetDevice(&dev));
+    hipStream_t up = nullptr, down = nullptr;
+    BDSP_HIP_TRY(hipStreamCreateWithFlags(&up, hipStreamNonBlocking));
+    BDSP_HIP_TRY(hipStreamCreateWithFlags(&down, hipStreamNonBlocking));
+    hipEvent_t landed[K], computed[K + 1];
+    for (int k = 0; k < K; ++k) (void)hipEventCreateWithFlags(&landed[k], hipEventDisableTiming);
+    for (int k = 0; k <= K; ++k) (void)hipEventCreateWithFlags(&computed[k], hipEventDisableTiming);
+    struct Piece { size_t first, count; bool valid; };
+    Piece pieces[K], tail[2] = {Piece{0, 0, false}, Piece{0, 0, false}}; // output ranges per stage
+    for (int k = 0; k < K; ++k) pieces[k] = Piece{0, 0, false};
+    std::atomic<int> stages_recorded{0}; // stage k may be waited for once its event has been recorded
+    int drc = BDSP_OK;
+    // downloads run on their own thread and stream, in step with the compute stream
+    std::thread downloader([&] {
+        (void)hipSetDevice(dev);
+        auto fetch = [&](const Piece& p) {
+            if (!p.valid || p.count == 0) return;
+            if (hipMemcpyAsync(dst + 2 * p.first, dy.as<T>() + 2 * p.first, sizeof(T) * 2 * p.count, hipMemcpyDeviceToHost, down) != hipSuccess) drc = BDSP_ERR_HIP;
+        };
+        for (int k = 0; k <= K; ++k) {
+            while (stages_recorded.load(std::memory_order_acquire) <= k) std::this_thread::yield();
+            (void)hipStreamWaitEvent(down, computed[k], 0);
+            if (k < K) fetch(pieces[k]);
+            else { fetch(tail[0]); fetch(tail[1]); }
+        }
+        if (hipStreamSynchronize(down) != hipSuccess) drc = BDSP_ERR_HIP;
+    });
+    int rc = BDSP_OK;
+    size_t next_block = 1; // block 0 reads x[-M/2 ...]: deferred
+    for (int k = 0; k < K; ++k) {
+        const size_t c0 = (size_t)k * ch, c1 = c0 + ch < points ? c0 + ch : points;
+        if (c0 < points && rc == BDSP_OK) {
+            if (hipMemcpyAsync(dx.as<T>() + 2 * c0, src + 2 * c0, sizeof(T) * 2 * (c1 - c0), hipMemcpyHostToDevice, up) != hipSuccess) rc = BDSP_ERR_HIP;
+            (void)hipEventRecord(landed[k], up);
+            (void)hipStreamWaitEvent(s, landed[k], 0);
+            // blocks whose window [b V + in_off, + L) lies inside the uploaded prefix [0, c1)
+            size_t bend = next_block;
+            while (bend < nb && (long long)(bend * V) + in_off + (long long)L <= (long long)c1) ++bend;
+            if (bend > next_block && rc == BDSP_OK) {
+                rc = conv_run_blocks<T>(dx.as<T>(), dy.as<T>(), points, 1, hsb.as<T>(), ntaps, in_off + (long long)(next_block * V),
+                                        (long long)(next_block * V), bend - next_block, nullptr, s, false);
+                const size_t o1 = bend * V < points ? bend * V : points;
+                if (rc == BDSP_OK) pieces[k] = Piece{next_block * V, o1 - next_block * V, true};
+                next_block = bend;
+            }
+        }
+        (void)hipEventRecord(computed[k], s);
+        stages_recorded.store(k + 1, std::memory_order_release);
+    }
+    // the wrap-around blocks: block 0 and everything from next_block on
+    if (rc == BDSP_OK) {
+        rc = conv_run_blocks<T>(dx.as<T>(), dy.as<T>(), points, 1, hsb.as<T>(), ntaps, in_off, 0, 1, nullptr, s, false);
+        if (rc == BDSP_OK) tail[0] = Piece{0, V < points ? V : points, true};
+        if (rc == BDSP_OK && next_block < nb) {
+            rc = conv_run_blocks<T>(dx.as<T>(), dy.as<T>(), points, 1, hsb.as<T>(), ntaps, in_off + (long long)(next_block * V),
+                                    (long long)(next_block * V), nb - next_block, nullptr, s, false);
+            if (rc == BDSP_OK) tail[1] = Piece{next_block * V, points - next_block * V, true};
+        }
+    }
+    (void)hipEventRecord(computed[K], s);
+    stages_recorded.store(K + 1, std::memory_order_release);
+    downloader.join();
+    if (hipStreamSynchronize(up) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) rc = rc == BDSP_OK ? BDSP_ERR_HIP : rc;
+    for (int k = 0; k < K; ++k) (void)hipEventDestroy(landed[k]);
+    for (int k = 0; k <= K; ++k) (void)hipEventDestroy(computed[k]);
+    (void)hipStreamDestroy(up);
+    (void)hipStreamDestroy(down);
+    return rc != BDSP_OK ? rc : drc;
+}
+
 template <typename T>
 int b1_convolve(int is_complex, const T* src, size_t src_len, T* dst, size_t dst_len, const T* imp,
                 size_t imp_len, size_t* range_start, size_t* range_end)
@@ -294,6 +393,13 @@ int b1_convolve(int is_complex, const T* src, size_t src_len, T* dst, size_t dst
     int c = check_device();
     if (c != BDSP_OK) return c;
     hipStream_t s = lib_stream();
+    static const bool no_pipeline = getenv("BDSP_B1_NO_PIPELINE") != nullptr;
+    if (is_complex && !no_pipeline && points >= (size_t(1) << 20) && ntaps <= FUSED_MAX_TAPS && points < (size_t(1) << 31)) {
+        BDSP_TRY(b1_convolve_pipelined<T>(src, dst, points, imp, ntaps));
+        if (range_start) *range_start = 0;
+        if (range_end) *range_end = src_len;
+        return 1;
+    }
     WsBlock dx, dy, dh;
     BDSP_TRY(dx.alloc(sizeof(T) * src_len, s));
     BDSP_TRY(dy.alloc(sizeof(T) * src_len, s));

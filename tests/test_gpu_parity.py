@@ -1242,3 +1242,19 @@ def test_callback_variants_of_convolution_and_interpolation(dtype):
             a, b = DspVec(xx, is_complex=cplx), DspVec(xx, is_complex=cplx)
             assert a.interpolatef_custom(sinc, factor, 0.0, L) == 0 and b.interpolatef(V.CONV_SINC, factor, 0.0, L) == 0
             assert len(a) == len(b) and rel_l2(a.data(), b.data()) < tol * 4, (cplx, factor)
+
+
+def test_b1_convolve_vector_pipelined_transfers():
+    """Above 2^20 complex points gpu_convolve_vector pipelines upload / blocks / download in chunks: the result must
+    equal the device-resident path bit for bit (same blocks, same kernel) and the oracle on windows incl. both ends."""
+    for n, m in (((1 << 20) + 12345, 257), ((1 << 21), 1024), (3_000_001, 3)):
+        x = orc.fill_uniform(2 * n, 77 + n, -10, 10, np.float32)
+        h = orc.fill_uniform(2 * m, 78, -1, 1, np.float32) / m
+        y, rng = V.gpu_convolve_vector(x, h, True)
+        assert rng == (0, 2 * n)
+        v = DspVec(x, is_complex=True)
+        assert v.convolve_signal(DspVec(h, is_complex=True)) == 0
+        assert np.array_equal(y, v.data()), (n, m)
+        for start in (0, n // 2 - 50, n - 300):
+            ref = orc.convolve_direct(x.astype(np.float64), h.astype(np.float64), True, start, 300)
+            assert rel_l2(y[2 * start: 2 * (start + 300)], ref) < 1e-6, (n, m, start)
