@@ -139,6 +139,11 @@ template <typename T> size_t interpolate_real_len(size_t len, T factor);
 template <typename T> int interpolate_real_dev(const T* in, T* out, size_t len, T factor, T delay, bool hermite, hipStream_t s);
 
 // reduce.hip: what one walk over a vector accumulates (sums in double; min / max with their keys and indices)
+// mixed_radix.hip: lengths 2^a 3^b 5^c 7^d that are not powers of two
+template <typename T> bool mr_supported(size_t n);
+template <typename T> int mr_fft(const T* in, T* out, T* scratch, size_t n, size_t batch, bool inverse, unsigned flags, T in_scale,
+                                 int window_id, T window_alpha, hipStream_t s);
+
 // per-element math family ids (vecmath.hip); the oracle uses the same numbering
 enum MathFn {
     MATH_SQRT = 0, MATH_SQUARE, MATH_POWF, MATH_LN, MATH_EXP, MATH_LOG, MATH_EXPF, MATH_SIN, MATH_COS, MATH_TAN,

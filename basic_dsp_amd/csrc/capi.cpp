@@ -133,8 +133,18 @@ template <typename T>
 int fft_any_len(T* a, T* b, size_t n, size_t batch, bool inverse, unsigned flags, T in_scale,
                 int window_id, T window_alpha, bool* in_b, hipStream_t s)
 {
-    (void)b;
-    *in_b = false; // the epilogue writes the result back over the (consumed) input buffer
+    *in_b = false;
+    static const bool no_mixed = getenv("BDSP_FFT_NO_MIXED_RADIX") != nullptr;
+    if (!no_mixed && mr_supported<T>(n) && batch <= 65535) {
+        // 2,3,5,7-smooth lengths: mixed-radix Stockham (mixed_radix.hip).  The four-step form goes a -> b -> a; the
+        // workgroup-resident form runs in place unless the output has another shape than the input.
+        const bool reshaping = (flags & (FFT_IN_REAL | BDSP_FFT_MAGNITUDE | FFT_OUT_REAL)) != 0;
+        const bool resident = n <= (sizeof(T) == 4 ? 4096u : 2048u);
+        T* out = (resident && reshaping) ? b : a;
+        *in_b = out == b;
+        return mr_fft<T>(a, out, b, n, batch, inverse, flags, in_scale, window_id, window_alpha, s);
+    }
+    // the Bluestein epilogue writes the result back over the (consumed) input buffer
     size_t m = 1;
     while (m < 2 * n - 1) m <<= 1;
     if (m < 512) m = 512; // the single-kernel path starts at 512-point workgroup transforms

@@ -1,0 +1,387 @@
+// mixed_radix.hip -- FFTs of lengths n = 2^a 3^b 5^c 7^d that are not powers of two (the reference takes any
+// length through rustfft's mixed-radix plans, time_freq/mod.rs:47-58; its OpenCL backend accepted the 2,3,5,7,11,13
+// smooth ones, ocl/mod.rs:277-299).  Bluestein (bluestein.hip) stays the path for everything else: it costs two
+// power-of-two transforms of >= 2n points plus three elementwise passes, about 5x a transform of similar size.
+//
+//   * n <= 4096 (f32) / 2048 (f64): one workgroup-resident Stockham transform (several small transforms per workgroup),
+//     ping-pong LDS buffers, radix 4/2/3/5/7 stages, stage twiddles from a copy of the cached exp(-2 pi i m / n) table in LDS;
+//   * larger n = n1 * n2 (both smooth, both <= MR_PASS_MAX): four-step --
+//       pass 1: tiles of W adjacent columns, FFT_n1 down the columns, x w_n^(k1 c), same layout out;
+//       pass 2: W adjacent rows per workgroup, FFT_n2 along the rows, transposed store X[k1 + n1 k2]
+//     -- two trips through HBM with 64-byte runs at worst (W complex values).
+// Both take the same fused options as the power-of-two and Bluestein paths: input rotation (ifft_shift), input
+// scale, window on the input or divided out of the output, real input, output rotation (fft_shift), real-part or
+// magnitude output.  Unnormalised in both directions.
+#include "bdsp_internal.h"
+#include "dsp_funcs.h"
+#include <cstdlib>
+
+namespace bdsp {
+
+constexpr int MR_MAX_STAGES = 24;
+constexpr int MR_THREADS = 1024; // an LDS-bound workgroup owns its CU: sixteen waves hide the exchange latency
+struct MrStages {
+    int count;
+    int radix[MR_MAX_STAGES];
+};
+
+static bool mr_factor(size_t n, MrStages* st)
+{
+    st->count = 0;
+    const int order[5] = {4, 2, 3, 5, 7};
+    for (int f : order)
+        while (n % (size_t)f == 0 && n > 1) {
+            if (st->count == MR_MAX_STAGES) return false;
+            st->radix[st->count++] = f;
+            n /= (size_t)f;
+        }
+    return n == 1;
+}
+
+// ---- small DFTs, natural order; DIR = -1 forward, +1 inverse ---------------------------------------------------
+template <int DIR, typename C> __device__ __forceinline__ void mr_dft3(C* v)
+{
+    using T = typename real_of<C>::type;
+    const T h = (T)0.86602540378443864676; // sin(pi/3)
+    C t1 = cadd(v[1], v[2]);
+    C m1 = csub(v[0], cscale(t1, (T)0.5));
+    C m2 = mul_dir_i<DIR>(cscale(csub(v[1], v[2]), h)); // (-/+ i) sin60 (v1 - v2)
+    v[0] = cadd(v[0], t1);
+    v[1] = cadd(m1, m2);
+    v[2] = csub(m1, m2);
+}
+template <int DIR, typename C> __device__ __forceinline__ void mr_dft5(C* v)
+{
+    using T = typename real_of<C>::type;
+    const T c1 = (T)0.30901699437494742410, c2 = (T)-0.80901699437494742410; // cos(2pi/5), cos(4pi/5)
+    const T s1 = (T)0.95105651629515357212, s2 = (T)0.58778525229247312917;  // sin(2pi/5), sin(4pi/5)
+    C t1 = cadd(v[1], v[4]), t2 = cadd(v[2], v[3]), t3 = csub(v[1], v[4]), t4 = csub(v[2], v[3]);
+    C a1 = cadd(v[0], cadd(cscale(t1, c1), cscale(t2, c2)));
+    C a2 = cadd(v[0], cadd(cscale(t1, c2), cscale(t2, c1)));
+    C b1 = mul_dir_i<DIR>(cadd(cscale(t3, s1), cscale(t4, s2)));
+    C b2 = mul_dir_i<DIR>(csub(cscale(t3, s2), cscale(t4, s1)));
+    v[0] = cadd(v[0], cadd(t1, t2));
+    v[1] = cadd(a1, b1); v[4] = csub(a1, b1);
+    v[2] = cadd(a2, b2); v[3] = csub(a2, b2);
+}
+template <int DIR, typename C> __device__ __forceinline__ void mr_dft7(C* v)
+{
+    using T = typename real_of<C>::type;
+    const T c1 = (T)0.62348980185873353053, c2 = (T)-0.22252093395631440429, c3 = (T)-0.90096886790241912624;
+    const T s1 = (T)0.78183148246802980871, s2 = (T)0.97492791218182360702, s3 = (T)0.43388373911755812048;
+    C t1 = cadd(v[1], v[6]), t2 = cadd(v[2], v[5]), t3 = cadd(v[3], v[4]);
+    C u1 = csub(v[1], v[6]), u2 = csub(v[2], v[5]), u3 = csub(v[3], v[4]);
+    // a_k = v0 + sum_m cos(2 pi k m / 7) t_m,   b_k = sum_m sin(2 pi k m / 7) u_m
+    C a1 = cadd(v[0], cadd(cscale(t1, c1), cadd(cscale(t2, c2), cscale(t3, c3))));
+    C a2 = cadd(v[0], cadd(cscale(t1, c2), cadd(cscale(t2, c3), cscale(t3, c1))));
+    C a3 = cadd(v[0], cadd(cscale(t1, c3), cadd(cscale(t2, c1), cscale(t3, c2))));
+    C b1 = mul_dir_i<DIR>(cadd(cscale(u1, s1), cadd(cscale(u2, s2), cscale(u3, s3))));
+    C b2 = mul_dir_i<DIR>(cadd(cscale(u1, s2), csub(cscale(u2, -s3), cscale(u3, s1))));
+    C b3 = mul_dir_i<DIR>(cadd(cscale(u1, s3), cadd(cscale(u2, -s1), cscale(u3, s2))));
+    v[0] = cadd(v[0], cadd(t1, cadd(t2, t3)));
+    v[1] = cadd(a1, b1); v[6] = csub(a1, b1);
+    v[2] = cadd(a2, b2); v[5] = csub(a2, b2);
+    v[3] = cadd(a3, b3); v[4] = csub(a3, b3);
+}
+template <int R, int DIR, typename C> __device__ __forceinline__ void mr_dft(C* v)
+{
+    if constexpr (R == 2) dft2<DIR>(v[0], v[1]);
+    else if constexpr (R == 3) mr_dft3<DIR>(v);
+    else if constexpr (R == 4) dft4<DIR>(v[0], v[1], v[2], v[3]);
+    else if constexpr (R == 5) mr_dft5<DIR>(v);
+    else mr_dft7<DIR>(v);
+}
+
+// One Stockham stage over `lanes` interleaved sequences of `len` points held as in[e * lanes + q]:
+//   j < len/R, k = j mod ns:  v[r] = in[j + r len/R] w_{ns R}^{r k};  out[(j / ns) ns R + k + r ns] = DFT_R(v)[r]
+// `tw` is the forward table exp(-2 pi i m / len).
+template <int R, int DIR, typename T>
+__device__ __forceinline__ void mr_stage(const cpx<T>* __restrict__ in, cpx<T>* __restrict__ out, int len, int lanes,
+                                         int ns, const cpx<T>* __restrict__ tw)
+{
+    const int nb = len / R, tstep = len / (ns * R);
+    for (int id = threadIdx.x; id < nb * lanes; id += blockDim.x) {
+        const int q = id % lanes, j = id / lanes, k = j % ns;
+        cpx<T> v[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) v[r] = in[(j + r * nb) * lanes + q];
+        if (ns > 1) {
+#pragma unroll
+            for (int r = 1; r < R; ++r) v[r] = twmul<DIR>(v[r], tw[r * k * tstep]);
+        }
+        mr_dft<R, DIR>(v);
+        const int o = (j / ns) * ns * R + k;
+#pragma unroll
+        for (int r = 0; r < R; ++r) out[(o + r * ns) * lanes + q] = v[r];
+    }
+}
+
+// the stage twiddles are read once per butterfly input: from L2 each read cost ~1 us of latency per loop trip
+// (*measured* 47 us for a 1000 x 8 tile); the workgroup keeps its own copy of the table in LDS
+template <typename T>
+__device__ __forceinline__ const cpx<T>* mr_table_to_lds(cpx<T>* dst, const cpx<T>* __restrict__ tw, int len)
+{
+    for (int i = threadIdx.x; i < len; i += MR_THREADS) dst[i] = tw[i];
+    return dst;
+}
+
+// all stages; returns the buffer that holds the result
+template <int DIR, typename T>
+__device__ __forceinline__ cpx<T>* mr_transform(cpx<T>* a, cpx<T>* b, int len, int lanes, const MrStages& st,
+                                                const cpx<T>* __restrict__ tw)
+{
+    int ns = 1;
+    for (int s = 0; s < st.count; ++s) {
+        __syncthreads();
+        const int R = st.radix[s];
+        if (R == 4) mr_stage<4, DIR, T>(a, b, len, lanes, ns, tw);
+        else if (R == 2) mr_stage<2, DIR, T>(a, b, len, lanes, ns, tw);
+        else if (R == 3) mr_stage<3, DIR, T>(a, b, len, lanes, ns, tw);
+        else if (R == 5) mr_stage<5, DIR, T>(a, b, len, lanes, ns, tw);
+        else mr_stage<7, DIR, T>(a, b, len, lanes, ns, tw);
+        ns *= R;
+        cpx<T>* t = a; a = b; b = t;
+    }
+    __syncthreads();
+    return a;
+}
+
+// ---- fused input / output options --------------------------------------------------------------------------------
+template <typename T>
+struct MrIo {
+    const T* in;
+    T* out;
+    unsigned long long n;       // points per vector
+    unsigned long long rot_in;  // input element i is x[(i + rot_in) mod n]
+    unsigned long long rot_out; // output element i is X[(i + rot_out) mod n]
+    T in_scale;
+    int in_real;                // the input holds n reals
+    int out_kind;               // 0 complex, 1 real part, 2 magnitude
+    int window_id;              // >= 0: multiply the input by the window ...
+    int window_div;             // ... or divide the output by it
+    T alpha;
+};
+
+template <typename T>
+__device__ __forceinline__ cpx<T> mr_load(const MrIo<T>& io, unsigned long long vec, unsigned long long i)
+{
+    unsigned long long j = i + io.rot_in;
+    if (j >= io.n) j -= io.n;
+    T re, im;
+    if (io.in_real) { re = io.in[vec * io.n + j]; im = (T)0; }
+    else { const T* p = io.in + 2 * (vec * io.n + j); re = p[0]; im = p[1]; }
+    T w = io.in_scale;
+    if (io.window_id >= 0 && !io.window_div) w = w * window_value_sym<T>(io.window_id, io.alpha, (size_t)i, (size_t)io.n);
+    return cpx<T>{re * w, im * w};
+}
+// stores spectrum bin k
+template <typename T>
+__device__ __forceinline__ void mr_store(const MrIo<T>& io, unsigned long long vec, unsigned long long k, cpx<T> z)
+{
+    unsigned long long i = k >= io.rot_out ? k - io.rot_out : k + io.n - io.rot_out;
+    T re = z.x, im = z.y;
+    if (io.window_id >= 0 && io.window_div) {
+        const T w = window_value_sym<T>(io.window_id, io.alpha, (size_t)i, (size_t)io.n);
+        re = re / w; im = im / w;
+    }
+    if (io.out_kind == 0) { T* p = io.out + 2 * (vec * io.n + i); p[0] = re; p[1] = im; }
+    else if (io.out_kind == 1) io.out[vec * io.n + i] = re;
+    else io.out[vec * io.n + i] = sizeof(T) == 4 ? (T)hypotf((float)re, (float)im) : (T)hypot((double)re, (double)im);
+}
+
+// ---- workgroup-resident transforms: `lanes` vectors per workgroup -----------------------------------------------
+template <typename T, int DIR>
+__global__ __launch_bounds__(MR_THREADS) void k_mr_wg(MrIo<T> io, MrStages st, const cpx<T>* __restrict__ tw, int lanes,
+                                               unsigned long long batch)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int n = (int)io.n;
+    cpx<T>* a = reinterpret_cast<cpx<T>*>(smem_raw);
+    cpx<T>* b = a + (size_t)n * lanes;
+    tw = mr_table_to_lds<T>(b + (size_t)n * lanes, tw, n);
+    const unsigned long long v0 = (unsigned long long)blockIdx.x * lanes;
+    const int live = batch - v0 < (unsigned long long)lanes ? (int)(batch - v0) : lanes;
+    for (int id = threadIdx.x; id < n * lanes; id += MR_THREADS) {
+        const int q = id / n, e = id % n; // consecutive threads read consecutive elements of one vector
+        a[e * lanes + q] = q < live ? mr_load<T>(io, v0 + q, (unsigned long long)e) : cpx<T>{(T)0, (T)0};
+    }
+    cpx<T>* r = mr_transform<DIR, T>(a, b, n, lanes, st, tw);
+    for (int id = threadIdx.x; id < n * lanes; id += MR_THREADS) {
+        const int q = id / n, e = id % n;
+        if (q < live) mr_store<T>(io, v0 + q, (unsigned long long)e, r[e * lanes + q]);
+    }
+}
+
+// ---- four-step, pass 1: W adjacent columns c of the n1 x n2 view x[r n2 + c]; FFT_n1 over r, times w_n^(k1 c) ----
+template <typename T, int DIR>
+__global__ __launch_bounds__(MR_THREADS) void k_mr_pass1(MrIo<T> io, cpx<T>* __restrict__ tmp, MrStages st,
+                                                  const cpx<T>* __restrict__ tw, int n1, int n2, int W)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    cpx<T>* a = reinterpret_cast<cpx<T>*>(smem_raw);
+    cpx<T>* b = a + (size_t)n1 * W;
+    tw = mr_table_to_lds<T>(b + (size_t)n1 * W, tw, n1);
+    const unsigned long long vec = blockIdx.y;
+    const int c0 = blockIdx.x * W;
+    const int live = n2 - c0 < W ? n2 - c0 : W;
+    for (int id = threadIdx.x; id < n1 * W; id += MR_THREADS) {
+        const int q = id % W, r = id / W;
+        a[id] = q < live ? mr_load<T>(io, vec, (unsigned long long)r * n2 + c0 + q) : cpx<T>{(T)0, (T)0};
+    }
+    cpx<T>* res = mr_transform<DIR, T>(a, b, n1, W, st, tw);
+    cpx<T>* tv = tmp + vec * io.n;
+    const double inv = 2.0 / (double)io.n;
+    for (int id = threadIdx.x; id < n1 * W; id += MR_THREADS) {
+        const int q = id % W, k1 = id / W;
+        if (q >= live) continue;
+        const unsigned long long m = ((unsigned long long)k1 * (unsigned long long)(c0 + q)) % io.n;
+        double sn, cs;
+        sincospi((double)m * inv, &sn, &cs); // exp(-/+ 2 pi i m / n)
+        const cpx<T> w{(T)cs, (T)(DIR < 0 ? -sn : sn)};
+        tv[(unsigned long long)k1 * n2 + c0 + q] = cmul(res[id], w);
+    }
+}
+
+// ---- pass 2: W adjacent rows k1 of tmp[k1 n2 + c]; FFT_n2 over c; X[k1 + n1 k2] ----------------------------------
+template <typename T, int DIR>
+__global__ __launch_bounds__(MR_THREADS) void k_mr_pass2(MrIo<T> io, const cpx<T>* __restrict__ tmp, MrStages st,
+                                                  const cpx<T>* __restrict__ tw, int n1, int n2, int W)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    cpx<T>* a = reinterpret_cast<cpx<T>*>(smem_raw);
+    cpx<T>* b = a + (size_t)n2 * W;
+    tw = mr_table_to_lds<T>(b + (size_t)n2 * W, tw, n2);
+    const unsigned long long vec = blockIdx.y;
+    const int r0 = blockIdx.x * W;
+    const int live = n1 - r0 < W ? n1 - r0 : W;
+    const cpx<T>* tv = tmp + vec * io.n;
+    for (int id = threadIdx.x; id < n2 * W; id += MR_THREADS) {
+        const int q = id / n2, c = id % n2; // unit stride along a row
+        a[c * W + q] = q < live ? tv[(unsigned long long)(r0 + q) * n2 + c] : cpx<T>{(T)0, (T)0};
+    }
+    cpx<T>* res = mr_transform<DIR, T>(a, b, n2, W, st, tw);
+    for (int id = threadIdx.x; id < n2 * W; id += MR_THREADS) {
+        const int q = id % W, k2 = id / W; // W adjacent k1 are adjacent bins
+        if (q < live) mr_store<T>(io, vec, (unsigned long long)(r0 + q) + (unsigned long long)n1 * k2, res[id]);
+    }
+}
+
+// ---- planning and launch ------------------------------------------------------------------------------------------
+constexpr size_t MR_LDS_BYTES = 128 * 1024;
+
+template <typename T> static size_t mr_wg_max() { return MR_LDS_BYTES / (4 * sizeof(cpx<T>)); } // 4096 f32, 2048 f64 (+ the table)
+template <typename T> static int mr_tile() { return sizeof(T) == 4 ? 8 : 4; }                    // 64-byte runs
+template <typename T> static size_t mr_pass_max() { return MR_LDS_BYTES / (2 * sizeof(cpx<T>) * mr_tile<T>()); }
+
+// n1 * n2 = n with both factors smooth and at most mr_pass_max: the most balanced split
+template <typename T>
+static bool mr_split(size_t n, size_t* n1, size_t* n2)
+{
+    const size_t pm = mr_pass_max<T>();
+    if (n > pm * pm) return false;
+    size_t best = 0;
+    for (size_t d = 2; d * d <= n; ++d) {
+        if (n % d) continue;
+        MrStages s;
+        if (d <= pm && n / d <= pm && mr_factor(d, &s) && mr_factor(n / d, &s)) best = d;
+    }
+    if (!best) return false;
+    *n1 = best;
+    *n2 = n / best;
+    return true;
+}
+
+template <typename T>
+bool mr_supported(size_t n)
+{
+    MrStages s;
+    if (n < 2 || is_pow2(n) || !mr_factor(n, &s)) return false;
+    if (n <= mr_wg_max<T>()) return true;
+    size_t n1, n2;
+    return mr_split<T>(n, &n1, &n2);
+}
+
+template <typename K>
+static int mr_set_lds(K kern, size_t lds)
+{
+    if (lds > 64 * 1024)
+        BDSP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    return BDSP_OK;
+}
+
+// in -> out (may alias for the workgroup-resident path; the four-step path needs `scratch` of n * batch complex)
+template <typename T>
+int mr_fft(const T* in, T* out, T* scratch, size_t n, size_t batch, bool inverse, unsigned flags, T in_scale,
+           int window_id, T window_alpha, hipStream_t s)
+{
+    MrIo<T> io{};
+    io.in = in; io.out = out; io.n = n;
+    io.rot_in = (flags & BDSP_FFT_SHIFT_IN) ? n / 2 : 0;
+    io.rot_out = (flags & BDSP_FFT_SHIFT_OUT) ? n - n / 2 : 0;
+    io.in_scale = in_scale;
+    io.in_real = (flags & FFT_IN_REAL) ? 1 : 0;
+    io.out_kind = (flags & BDSP_FFT_MAGNITUDE) ? 2 : ((flags & FFT_OUT_REAL) ? 1 : 0);
+    io.window_id = window_id;
+    io.window_div = (flags & FFT_WINDOW_OUT_DIV) ? 1 : 0;
+    io.alpha = window_alpha;
+    if (batch == 0) return BDSP_OK;
+    if (n <= mr_wg_max<T>()) {
+        MrStages st;
+        if (!mr_factor(n, &st)) return BDSP_ERR_UNSUPPORTED;
+        const cpx<T>* tw;
+        BDSP_TRY(twiddle_table<T>((int)n, &tw));
+        size_t lanes = 2048 / n; // small transforms share a workgroup
+        if (lanes < 1) lanes = 1;
+        if (lanes > 16) lanes = 16;
+        if (lanes > batch) lanes = batch;
+        const size_t lds = sizeof(cpx<T>) * (2 * n * lanes + n);
+        const unsigned grid = (unsigned)((batch + lanes - 1) / lanes);
+        if (inverse) {
+            BDSP_TRY(mr_set_lds(k_mr_wg<T, 1>, lds));
+            hipLaunchKernelGGL((k_mr_wg<T, 1>), dim3(grid), dim3(MR_THREADS), lds, s, io, st, tw, (int)lanes, (unsigned long long)batch);
+        } else {
+            BDSP_TRY(mr_set_lds(k_mr_wg<T, -1>, lds));
+            hipLaunchKernelGGL((k_mr_wg<T, -1>), dim3(grid), dim3(MR_THREADS), lds, s, io, st, tw, (int)lanes, (unsigned long long)batch);
+        }
+        BDSP_LAUNCH_CHECK();
+        return BDSP_OK;
+    }
+    size_t n1, n2;
+    if (!mr_split<T>(n, &n1, &n2) || batch > 65535) return BDSP_ERR_UNSUPPORTED;
+    MrStages s1, s2;
+    mr_factor(n1, &s1);
+    mr_factor(n2, &s2);
+    const cpx<T>*tw1, *tw2;
+    BDSP_TRY(twiddle_table<T>((int)n1, &tw1));
+    BDSP_TRY(twiddle_table<T>((int)n2, &tw2));
+    // tile width: W adjacent columns / rows per workgroup (64-byte runs); a lone transform narrows the tile until
+    // every CU has a workgroup -- each tile is a chain of dependent LDS stages, so latency, not bandwidth, rules
+    int W = mr_tile<T>();
+    const int wmin = n >= 200000 ? 4 : 2; // *measured* 10^6 points: W = 8 / 4 / 2 -> 45.7 / 36.5 / 48.5 us; 10^5: 18.0 / 14.7 / 14.1
+    while (W > wmin && ((n2 + W - 1) / W) * batch < (size_t)num_cus()) W /= 2;
+    static const int w_env = [] { const char* e = getenv("BDSP_MR_W"); return e ? atoi(e) : 0; }();
+    if (w_env > 0 && w_env <= mr_tile<T>()) W = w_env;
+    const size_t lds1 = sizeof(cpx<T>) * (2 * n1 * W + n1), lds2 = sizeof(cpx<T>) * (2 * n2 * W + n2);
+    cpx<T>* tmp = reinterpret_cast<cpx<T>*>(scratch);
+    const dim3 g1((unsigned)((n2 + W - 1) / W), (unsigned)batch), g2((unsigned)((n1 + W - 1) / W), (unsigned)batch);
+    if (inverse) {
+        BDSP_TRY(mr_set_lds(k_mr_pass1<T, 1>, lds1));
+        BDSP_TRY(mr_set_lds(k_mr_pass2<T, 1>, lds2));
+        hipLaunchKernelGGL((k_mr_pass1<T, 1>), g1, dim3(MR_THREADS), lds1, s, io, tmp, s1, tw1, (int)n1, (int)n2, W);
+        hipLaunchKernelGGL((k_mr_pass2<T, 1>), g2, dim3(MR_THREADS), lds2, s, io, tmp, s2, tw2, (int)n1, (int)n2, W);
+    } else {
+        BDSP_TRY(mr_set_lds(k_mr_pass1<T, -1>, lds1));
+        BDSP_TRY(mr_set_lds(k_mr_pass2<T, -1>, lds2));
+        hipLaunchKernelGGL((k_mr_pass1<T, -1>), g1, dim3(MR_THREADS), lds1, s, io, tmp, s1, tw1, (int)n1, (int)n2, W);
+        hipLaunchKernelGGL((k_mr_pass2<T, -1>), g2, dim3(MR_THREADS), lds2, s, io, tmp, s2, tw2, (int)n1, (int)n2, W);
+    }
+    BDSP_LAUNCH_CHECK();
+    return BDSP_OK;
+}
+
+template bool mr_supported<float>(size_t);
+template bool mr_supported<double>(size_t);
+template int mr_fft<float>(const float*, float*, float*, size_t, size_t, bool, unsigned, float, int, float, hipStream_t);
+template int mr_fft<double>(const double*, double*, double*, size_t, size_t, bool, unsigned, double, int, double, hipStream_t);
+
+} // namespace bdsp

@@ -1258,3 +1258,49 @@ def test_b1_convolve_vector_pipelined_transfers():
         for start in (0, n // 2 - 50, n - 300):
             ref = orc.convolve_direct(x.astype(np.float64), h.astype(np.float64), True, start, 300)
             assert rel_l2(y[2 * start: 2 * (start + 300)], ref) < 1e-6, (n, m, start)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_mixed_radix_fft_lengths_and_options(dtype):
+    """2,3,5,7-smooth lengths take the mixed-radix Stockham path (workgroup-resident up to 4096 / 2048 points, four-step
+    above): every radix, both forms, every fused option, batches through the matrix API -- against the oracle's DFT."""
+    from basic_dsp_amd import DspMat
+    tol = 1e-6 if dtype == np.float32 else 1e-12
+    for n in (6, 7, 9, 10, 12, 14, 15, 21, 35, 49, 60, 105, 210, 343, 625, 729, 1000, 1536, 2187, 2401, 3000, 3125, 4000,
+              4200, 5000, 6000, 6561, 10000, 16807, 30000, 65610, 100000, 250047, 360000):
+        x = orc.fill_uniform(2 * n, 300 + n, -10, 10, dtype)
+        v = DspVec(x, is_complex=True)
+        assert v.plain_fft() == 0
+        ref = orc.fft(x.astype(np.float64))
+        assert rel_l2(v.data(), ref) < tol, n
+        assert v.plain_ifft() == 0
+        assert rel_l2(v.data() / n, x) < tol * 2, n
+    for n in (30, 1000, 3000, 12000, 100000):
+        x = orc.fill_uniform(2 * n, 17 + n, -10, 10, dtype)
+        xf = x.astype(np.float64)
+        # fft (shifted), ifft (scaled, unshifted), windowed pair, magnitude, real input
+        v = DspVec(x, is_complex=True)
+        assert v.fft() == 0
+        ref = np.array(orc.fft(xf)); ref = orc.swap_halves(ref, True, True)
+        assert rel_l2(v.data(), ref) < tol, n
+        assert v.ifft() == 0 and rel_l2(v.data(), x) < tol * 2, n
+        v = DspVec(x, is_complex=True)
+        assert v.windowed_fft(V.WINDOW_HAMMING) == 0 and v.windowed_ifft(V.WINDOW_HAMMING) == 0
+        assert rel_l2(v.data(), x) < tol * 20, n
+        v = DspVec(x, is_complex=True)
+        assert v.plain_fft() == 0
+        spec = v.data().copy()
+        assert v.magnitude() == 0
+        np.testing.assert_allclose(v.data(), np.hypot(spec[0::2], spec[1::2]), rtol=1e-5)
+        r = DspVec(x[:n])
+        assert r.plain_fft() == 0 and len(r) == 2 * n
+        zr = np.zeros(2 * n); zr[0::2] = xf[:n]
+        assert rel_l2(r.data(), orc.fft(zr)) < tol, n
+    # batches of smooth lengths
+    for rows, n in ((37, 100), (5, 3000), (3, 50000)):
+        xs = orc.fill_uniform(2 * n * rows, 9, -10, 10, dtype).reshape(rows, 2 * n)
+        m = DspMat(xs, is_complex=True)
+        assert m.plain_fft() == 0
+        got = m.data()
+        for k in (0, rows // 2, rows - 1):
+            assert rel_l2(got[k], orc.fft(xs[k].astype(np.float64))) < tol, (rows, n, k)
