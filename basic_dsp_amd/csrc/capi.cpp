@@ -139,7 +139,7 @@ int fft_any_len(T* a, T* b, size_t n, size_t batch, bool inverse, unsigned flags
         // 2,3,5,7-smooth lengths: mixed-radix Stockham (mixed_radix.hip).  The four-step form goes a -> b -> a; the
         // workgroup-resident form runs in place unless the output has another shape than the input.
         const bool reshaping = (flags & (FFT_IN_REAL | BDSP_FFT_MAGNITUDE | FFT_OUT_REAL)) != 0;
-        const bool resident = n <= (sizeof(T) == 4 ? 4096u : 2048u);
+        const bool resident = mr_resident<T>(n);
         T* out = (resident && reshaping) ? b : a;
         *in_b = out == b;
         return mr_fft<T>(a, out, b, n, batch, inverse, flags, in_scale, window_id, window_alpha, s);

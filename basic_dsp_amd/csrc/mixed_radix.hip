@@ -267,28 +267,30 @@ __global__ __launch_bounds__(MR_THREADS) void k_mr_pass2(MrIo<T> io, const cpx<T
 }
 
 // ---- planning and launch ------------------------------------------------------------------------------------------
-constexpr size_t MR_LDS_BYTES = 128 * 1024;
+constexpr size_t MR_LDS_BYTES = 144 * 1024; // of the CU's 160 KB; one workgroup per CU either way
 
-template <typename T> static size_t mr_wg_max() { return MR_LDS_BYTES / (4 * sizeof(cpx<T>)); } // 4096 f32, 2048 f64 (+ the table)
+template <typename T> static size_t mr_wg_max() { return sizeof(T) == 4 ? 4096 : 2048; } // 2 buffers + the table: 96 KB
 template <typename T> static int mr_tile() { return sizeof(T) == 4 ? 8 : 4; }                    // 64-byte runs
-template <typename T> static size_t mr_pass_max() { return MR_LDS_BYTES / (2 * sizeof(cpx<T>) * mr_tile<T>()); }
+// longest sub-transform a tile of W lanes can hold: 2 ping-pong buffers of len * W points + the table
+template <typename T> static size_t mr_pass_max(int W) { return MR_LDS_BYTES / (sizeof(cpx<T>) * (2 * W + 1)); }
 
-// n1 * n2 = n with both factors smooth and at most mr_pass_max: the most balanced split
+// n1 * n2 = n with both factors smooth: the most balanced split, at the widest tile (W_max, W_max/2, ... 2) whose
+// LDS holds both factors (n <= 1024^2 at the full 64-byte tile, up to ~13M points with 2-wide tiles)
 template <typename T>
-static bool mr_split(size_t n, size_t* n1, size_t* n2)
+static bool mr_split(size_t n, size_t* n1, size_t* n2, int* wmax)
 {
-    const size_t pm = mr_pass_max<T>();
-    if (n > pm * pm) return false;
-    size_t best = 0;
-    for (size_t d = 2; d * d <= n; ++d) {
-        if (n % d) continue;
-        MrStages s;
-        if (d <= pm && n / d <= pm && mr_factor(d, &s) && mr_factor(n / d, &s)) best = d;
+    for (int W = mr_tile<T>(); W >= 2; W /= 2) {
+        const size_t pm = mr_pass_max<T>(W);
+        if (n > pm * pm) continue;
+        size_t best = 0;
+        for (size_t d = 2; d * d <= n; ++d) {
+            if (n % d) continue;
+            MrStages s;
+            if (n / d <= pm && mr_factor(d, &s) && mr_factor(n / d, &s)) best = d;
+        }
+        if (best) { *n1 = best; *n2 = n / best; *wmax = W; return true; }
     }
-    if (!best) return false;
-    *n1 = best;
-    *n2 = n / best;
-    return true;
+    return false;
 }
 
 template <typename T>
@@ -298,8 +300,13 @@ bool mr_supported(size_t n)
     if (n < 2 || is_pow2(n) || !mr_factor(n, &s)) return false;
     if (n <= mr_wg_max<T>()) return true;
     size_t n1, n2;
-    return mr_split<T>(n, &n1, &n2);
+    int w;
+    return mr_split<T>(n, &n1, &n2, &w);
 }
+
+template <typename T> bool mr_resident(size_t n) { return n <= mr_wg_max<T>(); }
+template bool mr_resident<float>(size_t);
+template bool mr_resident<double>(size_t);
 
 template <typename K>
 static int mr_set_lds(K kern, size_t lds)
@@ -347,7 +354,8 @@ int mr_fft(const T* in, T* out, T* scratch, size_t n, size_t batch, bool inverse
         return BDSP_OK;
     }
     size_t n1, n2;
-    if (!mr_split<T>(n, &n1, &n2) || batch > 65535) return BDSP_ERR_UNSUPPORTED;
+    int wmax = 0;
+    if (!mr_split<T>(n, &n1, &n2, &wmax) || batch > 65535) return BDSP_ERR_UNSUPPORTED;
     MrStages s1, s2;
     mr_factor(n1, &s1);
     mr_factor(n2, &s2);
@@ -356,11 +364,11 @@ int mr_fft(const T* in, T* out, T* scratch, size_t n, size_t batch, bool inverse
     BDSP_TRY(twiddle_table<T>((int)n2, &tw2));
     // tile width: W adjacent columns / rows per workgroup (64-byte runs); a lone transform narrows the tile until
     // every CU has a workgroup -- each tile is a chain of dependent LDS stages, so latency, not bandwidth, rules
-    int W = mr_tile<T>();
+    int W = wmax;
     const int wmin = n >= 200000 ? 4 : 2; // *measured* 10^6 points: W = 8 / 4 / 2 -> 45.7 / 36.5 / 48.5 us; 10^5: 18.0 / 14.7 / 14.1
     while (W > wmin && ((n2 + W - 1) / W) * batch < (size_t)num_cus()) W /= 2;
     static const int w_env = [] { const char* e = getenv("BDSP_MR_W"); return e ? atoi(e) : 0; }();
-    if (w_env > 0 && w_env <= mr_tile<T>()) W = w_env;
+    if (w_env > 0 && w_env <= wmax) W = w_env;
     const size_t lds1 = sizeof(cpx<T>) * (2 * n1 * W + n1), lds2 = sizeof(cpx<T>) * (2 * n2 * W + n2);
     cpx<T>* tmp = reinterpret_cast<cpx<T>*>(scratch);
     const dim3 g1((unsigned)((n2 + W - 1) / W), (unsigned)batch), g2((unsigned)((n1 + W - 1) / W), (unsigned)batch);

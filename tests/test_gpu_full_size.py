@@ -143,3 +143,19 @@ def test_c5_batch_of_1m_vectors_equals_single_vector_path():
         assert rel_l2(out[r], v.data()) < 1e-6
     ref = orc.fft(orc.convolve_signal(rows[1].astype(np.float64), taps.astype(np.float64), True)[1])
     assert rel_l2(out[1], ref) < 1e-6
+
+
+@pytest.mark.gpu
+def test_mixed_radix_three_million_points():
+    """3 000 000 = 2^6 3 5^6 points: the four-step mixed-radix form with 2-wide tiles (factors 1500 x 2000), against
+    the oracle's f64 transform of the same f32 input; round trip."""
+    n = 3_000_000
+    x = orc.fill_uniform(2 * n, 424242, -10, 10, np.float32)
+    v = DspVec(x, is_complex=True)
+    assert v.plain_fft() == 0
+    ref = orc.fft(x.astype(np.float64))
+    got = v.data().astype(np.float64)
+    assert np.linalg.norm(got - ref) / np.linalg.norm(ref) < 1e-6
+    assert v.plain_ifft() == 0
+    back = v.data().astype(np.float64) / n
+    assert np.linalg.norm(back - x) / np.linalg.norm(x) < 2e-6
