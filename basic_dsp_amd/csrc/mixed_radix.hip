@@ -1,10 +1,10 @@
-// mixed_radix.hip -- FFTs of lengths n = 2^a 3^b 5^c 7^d that are not powers of two (the reference takes any
+// mixed_radix.hip -- FFTs of lengths n = 2^a 3^b 5^c 7^d 11^e 13^f that are not powers of two (the reference takes any
 // length through rustfft's mixed-radix plans, time_freq/mod.rs:47-58; its OpenCL backend accepted the 2,3,5,7,11,13
 // smooth ones, ocl/mod.rs:277-299).  Bluestein (bluestein.hip) stays the path for everything else: it costs two
 // power-of-two transforms of >= 2n points plus three elementwise passes, about 5x a transform of similar size.
 //
 //   * n <= 4096 (f32) / 2048 (f64): one workgroup-resident Stockham transform (several small transforms per workgroup),
-//     ping-pong LDS buffers, radix 4/2/3/5/7 stages, stage twiddles from a copy of the cached exp(-2 pi i m / n) table in LDS;
+//     ping-pong LDS buffers, radix 4/2/3/5/7/11/13 stages, stage twiddles from a copy of the cached exp(-2 pi i m / n) table in LDS;
 //   * larger n = n1 * n2 (both smooth, both <= MR_PASS_MAX): four-step --
 //       pass 1: tiles of W adjacent columns, FFT_n1 down the columns, x w_n^(k1 c), same layout out;
 //       pass 2: W adjacent rows per workgroup, FFT_n2 along the rows, transposed store X[k1 + n1 k2]
@@ -28,7 +28,7 @@ struct MrStages {
 static bool mr_factor(size_t n, MrStages* st)
 {
     st->count = 0;
-    const int order[5] = {4, 2, 3, 5, 7};
+    const int order[7] = {4, 2, 3, 5, 7, 11, 13};
     for (int f : order)
         while (n % (size_t)f == 0 && n > 1) {
             if (st->count == MR_MAX_STAGES) return false;
@@ -83,13 +83,47 @@ template <int DIR, typename C> __device__ __forceinline__ void mr_dft7(C* v)
     v[2] = cadd(a2, b2); v[5] = csub(a2, b2);
     v[3] = cadd(a3, b3); v[4] = csub(a3, b3);
 }
+// odd radix R = 2h+1 (11, 13) in the same symmetric form, coefficients looked up by (k m) mod R at compile time
+template <int R> struct MrTrig;
+template <> struct MrTrig<11> {
+    static constexpr double c[11] = {1, 0.84125353283118120551, 0.41541501300188643508, -0.1423148382732850048, -0.65486073394528498959, -0.95949297361449736865, -0.95949297361449747967, -0.65486073394528521163, -0.14231483827328522684, 0.41541501300188604651, 0.84125353283118120551};
+    static constexpr double s[11] = {0, 0.54064081745559755543, 0.90963199535451833011, 0.98982144188093279524, 0.7557495743542582689, 0.28173255684142967104, -0.28173255684142939348, -0.75574957435425815788, -0.98982144188093268422, -0.90963199535451855215, -0.54064081745559744441};
+};
+template <> struct MrTrig<13> {
+    static constexpr double c[13] = {1, 0.88545602565320991051, 0.56806474673115592289, 0.12053668025532300601, -0.35460488704253545489, -0.74851074817110119231, -0.9709418174260520118, -0.97094181742605212282, -0.74851074817110130333, -0.35460488704253589898, 0.12053668025532320029, 0.56806474673115481266, 0.88545602565321002153};
+    static constexpr double s[13] = {0, 0.46472317204376850652, 0.82298386589365635224, 0.99270887409805397272, 0.93501624268541483342, 0.66312265824079519305, 0.23931566428755768339, -0.23931566428755743359, -0.66312265824079497101, -0.9350162426854147224, -0.99270887409805397272, -0.82298386589365701838, -0.4647231720437683955};
+};
+template <int R, int DIR, typename C> __device__ __forceinline__ void mr_dft_odd(C* v)
+{
+    using T = typename real_of<C>::type;
+    constexpr int H = (R - 1) / 2;
+    C t[H], u[H], x0 = v[0];
+#pragma unroll
+    for (int m = 1; m <= H; ++m) { t[m - 1] = cadd(v[m], v[R - m]); u[m - 1] = csub(v[m], v[R - m]); x0 = cadd(x0, t[m - 1]); }
+    C a[H], b[H];
+#pragma unroll
+    for (int k = 1; k <= H; ++k) {
+        C ak = v[0], bk = C{(T)0, (T)0};
+#pragma unroll
+        for (int m = 1; m <= H; ++m) {
+            ak = cadd(ak, cscale(t[m - 1], (T)MrTrig<R>::c[(k * m) % R]));
+            bk = cadd(bk, cscale(u[m - 1], (T)MrTrig<R>::s[(k * m) % R]));
+        }
+        a[k - 1] = ak;
+        b[k - 1] = mul_dir_i<DIR>(bk);
+    }
+    v[0] = x0;
+#pragma unroll
+    for (int k = 1; k <= H; ++k) { v[k] = cadd(a[k - 1], b[k - 1]); v[R - k] = csub(a[k - 1], b[k - 1]); }
+}
 template <int R, int DIR, typename C> __device__ __forceinline__ void mr_dft(C* v)
 {
     if constexpr (R == 2) dft2<DIR>(v[0], v[1]);
     else if constexpr (R == 3) mr_dft3<DIR>(v);
     else if constexpr (R == 4) dft4<DIR>(v[0], v[1], v[2], v[3]);
     else if constexpr (R == 5) mr_dft5<DIR>(v);
-    else mr_dft7<DIR>(v);
+    else if constexpr (R == 7) mr_dft7<DIR>(v);
+    else mr_dft_odd<R, DIR>(v);
 }
 
 // One Stockham stage over `lanes` interleaved sequences of `len` points held as in[e * lanes + q]:
@@ -138,7 +172,9 @@ __device__ __forceinline__ cpx<T>* mr_transform(cpx<T>* a, cpx<T>* b, int len, i
         else if (R == 2) mr_stage<2, DIR, T>(a, b, len, lanes, ns, tw);
         else if (R == 3) mr_stage<3, DIR, T>(a, b, len, lanes, ns, tw);
         else if (R == 5) mr_stage<5, DIR, T>(a, b, len, lanes, ns, tw);
-        else mr_stage<7, DIR, T>(a, b, len, lanes, ns, tw);
+        else if (R == 7) mr_stage<7, DIR, T>(a, b, len, lanes, ns, tw);
+        else if (R == 11) mr_stage<11, DIR, T>(a, b, len, lanes, ns, tw);
+        else mr_stage<13, DIR, T>(a, b, len, lanes, ns, tw);
         ns *= R;
         cpx<T>* t = a; a = b; b = t;
     }

@@ -1266,7 +1266,8 @@ def test_mixed_radix_fft_lengths_and_options(dtype):
     above): every radix, both forms, every fused option, batches through the matrix API -- against the oracle's DFT."""
     from basic_dsp_amd import DspMat
     tol = 1e-6 if dtype == np.float32 else 1e-12
-    for n in (6, 7, 9, 10, 12, 14, 15, 21, 35, 49, 60, 105, 210, 343, 625, 729, 1000, 1536, 2187, 2401, 3000, 3125, 4000,
+    for n in (6, 7, 9, 10, 11, 12, 13, 14, 15, 21, 22, 26, 35, 49, 60, 105, 121, 143, 169, 210, 343, 625, 729, 1000, 1001,
+              2002, 14641, 28561, 143000, 1536, 2187, 2401, 3000, 3125, 4000,
               4200, 5000, 6000, 6561, 10000, 16807, 30000, 65610, 100000, 250047, 360000):
         x = orc.fill_uniform(2 * n, 300 + n, -10, 10, dtype)
         v = DspVec(x, is_complex=True)
