@@ -135,7 +135,7 @@ int fft_any_len(T* a, T* b, size_t n, size_t batch, bool inverse, unsigned flags
 {
     *in_b = false;
     static const bool no_mixed = getenv("BDSP_FFT_NO_MIXED_RADIX") != nullptr;
-    if (!no_mixed && mr_supported<T>(n) && batch <= 65535) {
+    if (!no_mixed && mr_supported<T>(n) && (batch <= 65535 || mr_resident<T>(n))) {
         // 2,3,5,7-smooth lengths: mixed-radix Stockham (mixed_radix.hip).  The four-step form goes a -> b -> a; the
         // workgroup-resident form runs in place unless the output has another shape than the input.
         const bool reshaping = (flags & (FFT_IN_REAL | BDSP_FFT_MAGNITUDE | FFT_OUT_REAL)) != 0;

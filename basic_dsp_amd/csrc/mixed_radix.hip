@@ -25,17 +25,36 @@ struct MrStages {
     int radix[MR_MAX_STAGES];
 };
 
+// stage radices for n = 2^a 3^b 5^c 7^d 11^e 13^f: primes are paired into composite radices up to 16 so that the
+// transform crosses LDS as few times as possible (1000 -> 10 10 10, 360 -> 10 12 3, 4096 -> 16 16 16)
 static bool mr_factor(size_t n, MrStages* st)
 {
     st->count = 0;
-    const int order[7] = {4, 2, 3, 5, 7, 11, 13};
-    for (int f : order)
-        while (n % (size_t)f == 0 && n > 1) {
-            if (st->count == MR_MAX_STAGES) return false;
-            st->radix[st->count++] = f;
-            n /= (size_t)f;
-        }
-    return n == 1;
+    int e2 = 0, e3 = 0, e5 = 0, e7 = 0, e11 = 0, e13 = 0;
+    while (n % 2 == 0 && n > 1) { ++e2; n /= 2; }
+    while (n % 3 == 0 && n > 1) { ++e3; n /= 3; }
+    while (n % 5 == 0 && n > 1) { ++e5; n /= 5; }
+    while (n % 7 == 0 && n > 1) { ++e7; n /= 7; }
+    while (n % 11 == 0 && n > 1) { ++e11; n /= 11; }
+    while (n % 13 == 0 && n > 1) { ++e13; n /= 13; }
+    if (n != 1) return false;
+    auto push = [&](int r) { if (st->count < MR_MAX_STAGES) st->radix[st->count] = r; ++st->count; };
+    while (e5 > 0 && e2 > 0) { push(10); --e5; --e2; }
+    while (e5 > 0 && e3 > 0) { push(15); --e5; --e3; }
+    while (e7 > 0 && e2 > 0) { push(14); --e7; --e2; }
+    while (e3 > 0 && e2 > 1) { push(12); --e3; e2 -= 2; }
+    while (e3 > 0 && e2 > 0) { push(6); --e3; --e2; }
+    while (e3 > 1) { push(9); e3 -= 2; }
+    while (e2 > 3) { push(16); e2 -= 4; }
+    if (e2 == 3) { push(8); e2 = 0; }
+    if (e2 == 2) { push(4); e2 = 0; }
+    if (e2 == 1) { push(2); e2 = 0; }
+    while (e3-- > 0) push(3);
+    while (e5-- > 0) push(5);
+    while (e7-- > 0) push(7);
+    while (e11-- > 0) push(11);
+    while (e13-- > 0) push(13);
+    return st->count <= MR_MAX_STAGES;
 }
 
 // ---- small DFTs, natural order; DIR = -1 forward, +1 inverse ---------------------------------------------------
@@ -93,6 +112,30 @@ template <> struct MrTrig<13> {
     static constexpr double c[13] = {1, 0.88545602565320991051, 0.56806474673115592289, 0.12053668025532300601, -0.35460488704253545489, -0.74851074817110119231, -0.9709418174260520118, -0.97094181742605212282, -0.74851074817110130333, -0.35460488704253589898, 0.12053668025532320029, 0.56806474673115481266, 0.88545602565321002153};
     static constexpr double s[13] = {0, 0.46472317204376850652, 0.82298386589365635224, 0.99270887409805397272, 0.93501624268541483342, 0.66312265824079519305, 0.23931566428755768339, -0.23931566428755743359, -0.66312265824079497101, -0.9350162426854147224, -0.99270887409805397272, -0.82298386589365701838, -0.4647231720437683955};
 };
+template <> struct MrTrig<6> {
+    static constexpr double c[6] = {1, 0.50000000000000011102, -0.49999999999999977796, -1, -0.50000000000000044409, 0.50000000000000011102};
+    static constexpr double s[6] = {0, 0.86602540378443859659, 0.86602540378443870761, 1.2246467991473532072e-16, -0.86602540378443837454, -0.86602540378443859659};
+};
+template <> struct MrTrig<9> {
+    static constexpr double c[9] = {1, 0.76604444311897801345, 0.17364817766693041445, -0.49999999999999977796, -0.93969262078590831688, -0.93969262078590842791, -0.50000000000000044409, 0.17364817766692997036, 0.76604444311897779141};
+    static constexpr double s[9] = {0, 0.6427876096865392519, 0.98480775301220802032, 0.86602540378443870761, 0.34202014332566887944, -0.3420201433256686574, -0.86602540378443837454, -0.98480775301220813134, -0.64278760968653958496};
+};
+template <> struct MrTrig<10> {
+    static constexpr double c[10] = {1, 0.80901699437494745126, 0.30901699437494745126, -0.30901699437494734024, -0.80901699437494734024, -1, -0.80901699437494756229, -0.30901699437494756229, 0.30901699437494722922, 0.80901699437494734024};
+    static constexpr double s[10] = {0, 0.5877852522924731371, 0.95105651629515353118, 0.9510565162951536422, 0.58778525229247324813, 1.2246467991473532072e-16, -0.58778525229247302608, -0.95105651629515353118, -0.9510565162951536422, -0.58778525229247335915};
+};
+template <> struct MrTrig<12> {
+    static constexpr double c[12] = {1, 0.86602540378443870761, 0.50000000000000011102, 6.1232339957367660359e-17, -0.49999999999999977796, -0.86602540378443870761, -1, -0.86602540378443881863, -0.50000000000000044409, -1.8369701987210296875e-16, 0.50000000000000011102, 0.86602540378443837454};
+    static constexpr double s[12] = {0, 0.49999999999999994449, 0.86602540378443859659, 1, 0.86602540378443870761, 0.49999999999999994449, 1.2246467991473532072e-16, -0.49999999999999972244, -0.86602540378443837454, -1, -0.86602540378443859659, -0.50000000000000044409};
+};
+template <> struct MrTrig<14> {
+    static constexpr double c[14] = {1, 0.900968867902419146, 0.62348980185873359439, 0.22252093395631444839, -0.22252093395631433737, -0.62348980185873348336, -0.90096886790241903498, -1, -0.900968867902419146, -0.62348980185873370541, -0.22252093395631458717, 0.22252093395631333816, 0.62348980185873337234, 0.90096886790241936804};
+    static constexpr double s[14] = {0, 0.4338837391175581204, 0.78183148246802980363, 0.97492791218182361934, 0.97492791218182361934, 0.78183148246802991466, 0.43388373911755823142, 1.2246467991473532072e-16, -0.43388373911755800938, -0.78183148246802969261, -0.97492791218182361934, -0.97492791218182384139, -0.78183148246802991466, -0.43388373911755750978};
+};
+template <> struct MrTrig<15> {
+    static constexpr double c[15] = {1, 0.9135454576426008666, 0.66913060635885823757, 0.30901699437494745126, -0.10452846326765333207, -0.49999999999999977796, -0.80901699437494734024, -0.97814760073380568883, -0.97814760073380568883, -0.80901699437494756229, -0.50000000000000044409, -0.10452846326765423413, 0.30901699437494722922, 0.66913060635885845961, 0.91354545764260097762};
+    static constexpr double s[15] = {0, 0.40673664307580015276, 0.7431448254773941331, 0.95105651629515353118, 0.99452189536827340088, 0.86602540378443870761, 0.58778525229247324813, 0.20791169081775931482, -0.20791169081775906502, -0.58778525229247302608, -0.86602540378443837454, -0.99452189536827328986, -0.9510565162951536422, -0.74314482547739402207, -0.40673664307580015276};
+};
 template <int R, int DIR, typename C> __device__ __forceinline__ void mr_dft_odd(C* v)
 {
     using T = typename real_of<C>::type;
@@ -116,13 +159,55 @@ template <int R, int DIR, typename C> __device__ __forceinline__ void mr_dft_odd
 #pragma unroll
     for (int k = 1; k <= H; ++k) { v[k] = cadd(a[k - 1], b[k - 1]); v[R - k] = csub(a[k - 1], b[k - 1]); }
 }
-template <int R, int DIR, typename C> __device__ __forceinline__ void mr_dft(C* v)
+template <int R, int DIR, typename C> __device__ __forceinline__ void mr_dft_base(C* v)
 {
     if constexpr (R == 2) dft2<DIR>(v[0], v[1]);
     else if constexpr (R == 3) mr_dft3<DIR>(v);
     else if constexpr (R == 4) dft4<DIR>(v[0], v[1], v[2], v[3]);
     else if constexpr (R == 5) mr_dft5<DIR>(v);
-    else if constexpr (R == 7) mr_dft7<DIR>(v);
+    else mr_dft7<DIR>(v);
+}
+// composite radix R = RA * RB in registers (6, 9, 10, 12, 14, 15): m = RB m1 + m2, k = k1 + RA k2,
+//   DFT_RA over m1 for every m2, constants w_R^(m2 k1), DFT_RB over m2 for every k1 -- fewer LDS round trips and
+//   barriers than separate stages (1000 = 10 10 10 instead of 4 2 5 5 5)
+template <int RA, int RB, int DIR, typename C> __device__ __forceinline__ void mr_dft_comp(C* v)
+{
+    using T = typename real_of<C>::type;
+    constexpr int R = RA * RB;
+    C a[R];
+#pragma unroll
+    for (int m2 = 0; m2 < RB; ++m2) {
+        C u[RA];
+#pragma unroll
+        for (int m1 = 0; m1 < RA; ++m1) u[m1] = v[RB * m1 + m2];
+        mr_dft_base<RA, DIR>(u);
+#pragma unroll
+        for (int k1 = 0; k1 < RA; ++k1) {
+            const int j = (m2 * k1) % R;
+            a[k1 * RB + m2] = j == 0 ? u[k1] : twmul<DIR>(u[k1], C{(T)MrTrig<R>::c[j], (T)-MrTrig<R>::s[j]});
+        }
+    }
+#pragma unroll
+    for (int k1 = 0; k1 < RA; ++k1) {
+        C u[RB];
+#pragma unroll
+        for (int m2 = 0; m2 < RB; ++m2) u[m2] = a[k1 * RB + m2];
+        mr_dft_base<RB, DIR>(u);
+#pragma unroll
+        for (int k2 = 0; k2 < RB; ++k2) v[k1 + RA * k2] = u[k2];
+    }
+}
+template <int R, int DIR, typename C> __device__ __forceinline__ void mr_dft(C* v)
+{
+    if constexpr (R == 2 || R == 3 || R == 4 || R == 5 || R == 7) mr_dft_base<R, DIR>(v);
+    else if constexpr (R == 8) dft8<DIR>(v);
+    else if constexpr (R == 16) dft16<DIR>(v);
+    else if constexpr (R == 6) mr_dft_comp<2, 3, DIR>(v);
+    else if constexpr (R == 9) mr_dft_comp<3, 3, DIR>(v);
+    else if constexpr (R == 10) mr_dft_comp<2, 5, DIR>(v);
+    else if constexpr (R == 12) mr_dft_comp<4, 3, DIR>(v);
+    else if constexpr (R == 14) mr_dft_comp<2, 7, DIR>(v);
+    else if constexpr (R == 15) mr_dft_comp<3, 5, DIR>(v);
     else mr_dft_odd<R, DIR>(v);
 }
 
@@ -155,7 +240,7 @@ __device__ __forceinline__ void mr_stage(const cpx<T>* __restrict__ in, cpx<T>* 
 template <typename T>
 __device__ __forceinline__ const cpx<T>* mr_table_to_lds(cpx<T>* dst, const cpx<T>* __restrict__ tw, int len)
 {
-    for (int i = threadIdx.x; i < len; i += MR_THREADS) dst[i] = tw[i];
+    for (int i = threadIdx.x; i < len; i += blockDim.x) dst[i] = tw[i];
     return dst;
 }
 
@@ -168,13 +253,23 @@ __device__ __forceinline__ cpx<T>* mr_transform(cpx<T>* a, cpx<T>* b, int len, i
     for (int s = 0; s < st.count; ++s) {
         __syncthreads();
         const int R = st.radix[s];
-        if (R == 4) mr_stage<4, DIR, T>(a, b, len, lanes, ns, tw);
-        else if (R == 2) mr_stage<2, DIR, T>(a, b, len, lanes, ns, tw);
-        else if (R == 3) mr_stage<3, DIR, T>(a, b, len, lanes, ns, tw);
-        else if (R == 5) mr_stage<5, DIR, T>(a, b, len, lanes, ns, tw);
-        else if (R == 7) mr_stage<7, DIR, T>(a, b, len, lanes, ns, tw);
-        else if (R == 11) mr_stage<11, DIR, T>(a, b, len, lanes, ns, tw);
-        else mr_stage<13, DIR, T>(a, b, len, lanes, ns, tw);
+        switch (R) {
+        case 16: mr_stage<16, DIR, T>(a, b, len, lanes, ns, tw); break;
+        case 15: mr_stage<15, DIR, T>(a, b, len, lanes, ns, tw); break;
+        case 14: mr_stage<14, DIR, T>(a, b, len, lanes, ns, tw); break;
+        case 13: mr_stage<13, DIR, T>(a, b, len, lanes, ns, tw); break;
+        case 12: mr_stage<12, DIR, T>(a, b, len, lanes, ns, tw); break;
+        case 11: mr_stage<11, DIR, T>(a, b, len, lanes, ns, tw); break;
+        case 10: mr_stage<10, DIR, T>(a, b, len, lanes, ns, tw); break;
+        case 9: mr_stage<9, DIR, T>(a, b, len, lanes, ns, tw); break;
+        case 8: mr_stage<8, DIR, T>(a, b, len, lanes, ns, tw); break;
+        case 7: mr_stage<7, DIR, T>(a, b, len, lanes, ns, tw); break;
+        case 6: mr_stage<6, DIR, T>(a, b, len, lanes, ns, tw); break;
+        case 5: mr_stage<5, DIR, T>(a, b, len, lanes, ns, tw); break;
+        case 4: mr_stage<4, DIR, T>(a, b, len, lanes, ns, tw); break;
+        case 3: mr_stage<3, DIR, T>(a, b, len, lanes, ns, tw); break;
+        default: mr_stage<2, DIR, T>(a, b, len, lanes, ns, tw); break;
+        }
         ns *= R;
         cpx<T>* t = a; a = b; b = t;
     }
@@ -237,12 +332,12 @@ __global__ __launch_bounds__(MR_THREADS) void k_mr_wg(MrIo<T> io, MrStages st, c
     tw = mr_table_to_lds<T>(b + (size_t)n * lanes, tw, n);
     const unsigned long long v0 = (unsigned long long)blockIdx.x * lanes;
     const int live = batch - v0 < (unsigned long long)lanes ? (int)(batch - v0) : lanes;
-    for (int id = threadIdx.x; id < n * lanes; id += MR_THREADS) {
+    for (int id = threadIdx.x; id < n * lanes; id += blockDim.x) {
         const int q = id / n, e = id % n; // consecutive threads read consecutive elements of one vector
         a[e * lanes + q] = q < live ? mr_load<T>(io, v0 + q, (unsigned long long)e) : cpx<T>{(T)0, (T)0};
     }
     cpx<T>* r = mr_transform<DIR, T>(a, b, n, lanes, st, tw);
-    for (int id = threadIdx.x; id < n * lanes; id += MR_THREADS) {
+    for (int id = threadIdx.x; id < n * lanes; id += blockDim.x) {
         const int q = id / n, e = id % n;
         if (q < live) mr_store<T>(io, v0 + q, (unsigned long long)e, r[e * lanes + q]);
     }
@@ -260,14 +355,14 @@ __global__ __launch_bounds__(MR_THREADS) void k_mr_pass1(MrIo<T> io, cpx<T>* __r
     const unsigned long long vec = blockIdx.y;
     const int c0 = blockIdx.x * W;
     const int live = n2 - c0 < W ? n2 - c0 : W;
-    for (int id = threadIdx.x; id < n1 * W; id += MR_THREADS) {
+    for (int id = threadIdx.x; id < n1 * W; id += blockDim.x) {
         const int q = id % W, r = id / W;
         a[id] = q < live ? mr_load<T>(io, vec, (unsigned long long)r * n2 + c0 + q) : cpx<T>{(T)0, (T)0};
     }
     cpx<T>* res = mr_transform<DIR, T>(a, b, n1, W, st, tw);
     cpx<T>* tv = tmp + vec * io.n;
     const double inv = 2.0 / (double)io.n;
-    for (int id = threadIdx.x; id < n1 * W; id += MR_THREADS) {
+    for (int id = threadIdx.x; id < n1 * W; id += blockDim.x) {
         const int q = id % W, k1 = id / W;
         if (q >= live) continue;
         const unsigned long long m = ((unsigned long long)k1 * (unsigned long long)(c0 + q)) % io.n;
@@ -291,12 +386,12 @@ __global__ __launch_bounds__(MR_THREADS) void k_mr_pass2(MrIo<T> io, const cpx<T
     const int r0 = blockIdx.x * W;
     const int live = n1 - r0 < W ? n1 - r0 : W;
     const cpx<T>* tv = tmp + vec * io.n;
-    for (int id = threadIdx.x; id < n2 * W; id += MR_THREADS) {
+    for (int id = threadIdx.x; id < n2 * W; id += blockDim.x) {
         const int q = id / n2, c = id % n2; // unit stride along a row
         a[c * W + q] = q < live ? tv[(unsigned long long)(r0 + q) * n2 + c] : cpx<T>{(T)0, (T)0};
     }
     cpx<T>* res = mr_transform<DIR, T>(a, b, n2, W, st, tw);
-    for (int id = threadIdx.x; id < n2 * W; id += MR_THREADS) {
+    for (int id = threadIdx.x; id < n2 * W; id += blockDim.x) {
         const int q = id % W, k2 = id / W; // W adjacent k1 are adjacent bins
         if (q < live) mr_store<T>(io, vec, (unsigned long long)(r0 + q) + (unsigned long long)n1 * k2, res[id]);
     }
@@ -344,6 +439,13 @@ template <typename T> bool mr_resident(size_t n) { return n <= mr_wg_max<T>(); }
 template bool mr_resident<float>(size_t);
 template bool mr_resident<double>(size_t);
 
+// threads per workgroup: about eight points of the tile per thread (a radix-8..16 butterfly each), 64 ... 1024
+static unsigned mr_threads(size_t tile_points)
+{
+    size_t t = ((tile_points / 8 + 63) / 64) * 64;
+    return (unsigned)(t < 64 ? 64 : (t > (size_t)MR_THREADS ? (size_t)MR_THREADS : t));
+}
+
 template <typename K>
 static int mr_set_lds(K kern, size_t lds)
 {
@@ -379,12 +481,15 @@ int mr_fft(const T* in, T* out, T* scratch, size_t n, size_t batch, bool inverse
         if (lanes > batch) lanes = batch;
         const size_t lds = sizeof(cpx<T>) * (2 * n * lanes + n);
         const unsigned grid = (unsigned)((batch + lanes - 1) / lanes);
+        // many small transforms: 256-thread workgroups, several per CU, interleave their barriers; a few large ones:
+        // 1024 threads each
+        const unsigned threads = grid >= 2u * (unsigned)num_cus() ? (mr_threads(n * lanes) > 256u ? 256u : mr_threads(n * lanes)) : mr_threads(4 * n * lanes);
         if (inverse) {
             BDSP_TRY(mr_set_lds(k_mr_wg<T, 1>, lds));
-            hipLaunchKernelGGL((k_mr_wg<T, 1>), dim3(grid), dim3(MR_THREADS), lds, s, io, st, tw, (int)lanes, (unsigned long long)batch);
+            hipLaunchKernelGGL((k_mr_wg<T, 1>), dim3(grid), dim3(threads), lds, s, io, st, tw, (int)lanes, (unsigned long long)batch);
         } else {
             BDSP_TRY(mr_set_lds(k_mr_wg<T, -1>, lds));
-            hipLaunchKernelGGL((k_mr_wg<T, -1>), dim3(grid), dim3(MR_THREADS), lds, s, io, st, tw, (int)lanes, (unsigned long long)batch);
+            hipLaunchKernelGGL((k_mr_wg<T, -1>), dim3(grid), dim3(threads), lds, s, io, st, tw, (int)lanes, (unsigned long long)batch);
         }
         BDSP_LAUNCH_CHECK();
         return BDSP_OK;
@@ -407,17 +512,20 @@ int mr_fft(const T* in, T* out, T* scratch, size_t n, size_t batch, bool inverse
     if (w_env > 0 && w_env <= wmax) W = w_env;
     const size_t lds1 = sizeof(cpx<T>) * (2 * n1 * W + n1), lds2 = sizeof(cpx<T>) * (2 * n2 * W + n2);
     cpx<T>* tmp = reinterpret_cast<cpx<T>*>(scratch);
+    // a lone transform wants every wave it can get per tile; a batch has parallelism across tiles already
+    const bool lone = ((n2 + W - 1) / W) * batch < 4 * (size_t)num_cus();
+    const unsigned t1 = lone ? mr_threads(4 * n1 * W) : mr_threads(n1 * W), t2 = lone ? mr_threads(4 * n2 * W) : mr_threads(n2 * W);
     const dim3 g1((unsigned)((n2 + W - 1) / W), (unsigned)batch), g2((unsigned)((n1 + W - 1) / W), (unsigned)batch);
     if (inverse) {
         BDSP_TRY(mr_set_lds(k_mr_pass1<T, 1>, lds1));
         BDSP_TRY(mr_set_lds(k_mr_pass2<T, 1>, lds2));
-        hipLaunchKernelGGL((k_mr_pass1<T, 1>), g1, dim3(MR_THREADS), lds1, s, io, tmp, s1, tw1, (int)n1, (int)n2, W);
-        hipLaunchKernelGGL((k_mr_pass2<T, 1>), g2, dim3(MR_THREADS), lds2, s, io, tmp, s2, tw2, (int)n1, (int)n2, W);
+        hipLaunchKernelGGL((k_mr_pass1<T, 1>), g1, dim3(t1), lds1, s, io, tmp, s1, tw1, (int)n1, (int)n2, W);
+        hipLaunchKernelGGL((k_mr_pass2<T, 1>), g2, dim3(t2), lds2, s, io, tmp, s2, tw2, (int)n1, (int)n2, W);
     } else {
         BDSP_TRY(mr_set_lds(k_mr_pass1<T, -1>, lds1));
         BDSP_TRY(mr_set_lds(k_mr_pass2<T, -1>, lds2));
-        hipLaunchKernelGGL((k_mr_pass1<T, -1>), g1, dim3(MR_THREADS), lds1, s, io, tmp, s1, tw1, (int)n1, (int)n2, W);
-        hipLaunchKernelGGL((k_mr_pass2<T, -1>), g2, dim3(MR_THREADS), lds2, s, io, tmp, s2, tw2, (int)n1, (int)n2, W);
+        hipLaunchKernelGGL((k_mr_pass1<T, -1>), g1, dim3(t1), lds1, s, io, tmp, s1, tw1, (int)n1, (int)n2, W);
+        hipLaunchKernelGGL((k_mr_pass2<T, -1>), g2, dim3(t2), lds2, s, io, tmp, s2, tw2, (int)n1, (int)n2, W);
     }
     BDSP_LAUNCH_CHECK();
     return BDSP_OK;
