@@ -50,6 +50,7 @@ struct WsBlock { // RAII workspace
 // Forward twiddle table exp(-2*pi*i*m/n), m in [0, n), generated on the host in double precision,
 // rounded once, cached per (device, n, precision).  n <= 8192.
 template <typename T> int twiddle_table(int n, const cpx<T>** table);
+template <typename T> bool twiddle_table_available(int n); // cached already, or the cache still has room
 
 // ---------------------------------------------------------------- fused FFT prologue / epilogue
 template <typename T>

@@ -429,10 +429,10 @@ bool mr_supported(size_t n)
 {
     MrStages s;
     if (n < 2 || is_pow2(n) || !mr_factor(n, &s)) return false;
-    if (n <= mr_wg_max<T>()) return true;
+    if (n <= mr_wg_max<T>()) return twiddle_table_available<T>((int)n);
     size_t n1, n2;
     int w;
-    return mr_split<T>(n, &n1, &n2, &w);
+    return mr_split<T>(n, &n1, &n2, &w) && twiddle_table_available<T>((int)n1) && twiddle_table_available<T>((int)n2);
 }
 
 template <typename T> bool mr_resident(size_t n) { return n <= mr_wg_max<T>(); }

@@ -193,6 +193,20 @@ int twiddle_table(int n, const cpx<T>** table)
     return BDSP_OK;
 }
 
+// The tables are never freed (kernels in flight may be reading them), so callers that can live without one
+// (mixed_radix.hip falls back to Bluestein, whose plan cache is LRU-bounded) ask first: a program that walks
+// through thousands of distinct lengths must not grow the cache without bound.
+template <typename T>
+bool twiddle_table_available(int n)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    DeviceCtx* c;
+    if (ctx_locked(&c) != BDSP_OK) return false;
+    return c->twiddles.size() < 1024 || c->twiddles.count(std::make_pair(n, (int)sizeof(T))) != 0;
+}
+template bool twiddle_table_available<float>(int);
+template bool twiddle_table_available<double>(int);
+
 template int twiddle_table<float>(int, const cpx<float>**);
 template int twiddle_table<double>(int, const cpx<double>**);
 
