@@ -22,6 +22,10 @@ template <typename T> __device__ __forceinline__ T dev_floor(T x);
 template <> __device__ __forceinline__ float dev_floor<float>(float x) { return floorf(x); }
 template <> __device__ __forceinline__ double dev_floor<double>(double x) { return floor(x); }
 
+template <typename T> __device__ __forceinline__ T dev_fma(T a, T b, T c);
+template <> __device__ __forceinline__ float dev_fma<float>(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+template <> __device__ __forceinline__ double dev_fma<double>(double a, double b, double c) { return __builtin_fma(a, b, c); }
+
 template <typename T>
 size_t interpolatef_new_len(size_t len, T factor)
 {
@@ -163,8 +167,10 @@ __global__ __launch_bounds__(256) void k_interp_inner(const T* __restrict__ x, T
         for (int s = 0; s < FACTOR; ++s)
 #pragma unroll
             for (int k = 0; k < QB; ++k) {
-                ar[k][s] = ar[k][s] + wr[k] * w[s];
-                if (CPLX) ai[k][s] = ai[k][s] + wi[k] * w[s];
+                // fused multiply-add: one rounding instead of the reference's two per tap (the result is compared with
+                // tolerance) and half the VALU work of this VALU-heavy kernel
+                ar[k][s] = dev_fma<T>(wr[k], w[s], ar[k][s]);
+                if (CPLX) ai[k][s] = dev_fma<T>(wi[k], w[s], ai[k][s]);
             }
         // slide the window by one sample
 #pragma unroll
