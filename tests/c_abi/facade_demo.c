@@ -48,6 +48,22 @@ int main(void)
     CHECK(fabsf(get_value32(r.vector, 500) - 1.0f) < 1e-5f, "moving average of ones is one");
     delete_vector32(r.vector);
     delete_vector32(h);
+
+    /* statistics / math family / running sums: struct returns by value, and the facade names that collide with
+     * <math.h> (included above) through their bdsp_ declarations */
+    VecBuf32 *w = new32(0, 0, 2.0f, 1000, 1.0f);
+    Statistics32 st = real_statistics32(w);
+    CHECK(st.count == 1000 && fabsf(st.sum - 2000.0f) < 1e-3f && st.min == 2.0f && st.max_index == 0, "real_statistics32");
+    r = bdsp_powf32(w, 3.0f);                     CHECK(r.result_code == 0, "powf32");
+    CHECK(fabsf(get_value32(r.vector, 7) - 8.0f) < 1e-5f, "2^3");
+    r = cum_sum32(r.vector);                      CHECK(r.result_code == 0, "cum_sum32");
+    CHECK(fabsf(get_value32(r.vector, 999) - 8000.0f) < 1e-2f, "running sum of 1000 eights");
+    r = sqrt32(r.vector);                         CHECK(r.result_code == 0, "sqrt32");
+    ScalarInteropResult32 dp = real_dot_product32(r.vector, r.vector);
+    CHECK(dp.result_code == 0 && fabsf(dp.result - 8.0f * 500500.0f) < 1.0f, "dot product of sqrt(8k) with itself");
+    r = plain_fft32(r.vector);                    CHECK(r.result_code == 0, "1000-point (2^3 5^3) real-input fft");
+    CHECK(get_len32(r.vector) == 2000, "real -> complex");
+    delete_vector32(r.vector);
     free(sig); free(host);
     printf("c abi demo ok (%s)\n", bdsp_hip_version());
     return 0;
