@@ -1276,7 +1276,7 @@ def test_mixed_radix_fft_lengths_and_options(dtype):
         assert rel_l2(v.data(), ref) < tol, n
         assert v.plain_ifft() == 0
         assert rel_l2(v.data() / n, x) < tol * 2, n
-    for n in (30, 1000, 3000, 12000, 100000):
+    for n in (30, 1000, 2187, 3000, 12000, 16807, 100000):      # 2187 = 3^7 and 16807 = 7^5 are odd: rotations by n/2 and n - n/2
         x = orc.fill_uniform(2 * n, 17 + n, -10, 10, dtype)
         xf = x.astype(np.float64)
         # fft (shifted), ifft (scaled, unshifted), windowed pair, magnitude, real input
