@@ -351,7 +351,10 @@ int b1_convolve_pipelined(const T* src, T* dst, size_t points, const T* imp, siz
         if (hipStreamSynchronize(down) != hipSuccess) drc = BDSP_ERR_HIP;
     });
     int rc = BDSP_OK;
-    size_t next_block = 1; // block 0 reads x[-M/2 ...]: deferred
+    // blocks whose window starts before x[0] (block 0 always; more of them when M/2 exceeds the block step) read the
+    // END of the vector through the wrap-around: deferred until everything is resident
+    const size_t head = (size_t)((-in_off + (long long)V - 1) / (long long)V) > nb ? nb : (size_t)((-in_off + (long long)V - 1) / (long long)V);
+    size_t next_block = head < 1 ? 1 : head;
     for (int k = 0; k < K; ++k) {
         const size_t c0 = (size_t)k * ch, c1 = c0 + ch < points ? c0 + ch : points;
         if (c0 < points && rc == BDSP_OK) {
@@ -374,8 +377,9 @@ int b1_convolve_pipelined(const T* src, T* dst, size_t points, const T* imp, siz
     }
     // the wrap-around blocks: block 0 and everything from next_block on
     if (rc == BDSP_OK) {
-        rc = conv_run_blocks<T>(dx.as<T>(), dy.as<T>(), points, 1, hsb.as<T>(), ntaps, in_off, 0, 1, nullptr, s, false);
-        if (rc == BDSP_OK) tail[0] = Piece{0, V < points ? V : points, true};
+        const size_t nh = next_block < nb ? next_block : nb; // the deferred head blocks [0, nh)
+        rc = conv_run_blocks<T>(dx.as<T>(), dy.as<T>(), points, 1, hsb.as<T>(), ntaps, in_off, 0, nh, nullptr, s, false);
+        if (rc == BDSP_OK) tail[0] = Piece{0, nh * V < points ? nh * V : points, true};
         if (rc == BDSP_OK && next_block < nb) {
             rc = conv_run_blocks<T>(dx.as<T>(), dy.as<T>(), points, 1, hsb.as<T>(), ntaps, in_off + (long long)(next_block * V),
                                     (long long)(next_block * V), nb - next_block, nullptr, s, false);

@@ -1247,7 +1247,7 @@ def test_callback_variants_of_convolution_and_interpolation(dtype):
 def test_b1_convolve_vector_pipelined_transfers():
     """Above 2^20 complex points gpu_convolve_vector pipelines upload / blocks / download in chunks: the result must
     equal the device-resident path bit for bit (same blocks, same kernel) and the oracle on windows incl. both ends."""
-    for n, m in (((1 << 20) + 12345, 257), ((1 << 21), 1024), (3_000_001, 3)):
+    for n, m in (((1 << 20) + 12345, 257), ((1 << 21), 1024), (3_000_001, 3), ((1 << 20) + 77, 3073), ((1 << 20) + 5, 2500)):
         x = orc.fill_uniform(2 * n, 77 + n, -10, 10, np.float32)
         h = orc.fill_uniform(2 * m, 78, -1, 1, np.float32) / m
         y, rng = V.gpu_convolve_vector(x, h, True)
