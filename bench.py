@@ -141,7 +141,10 @@ def main():
         if ev:
             lib.bdsp_hip_event_record(ev[2], sp)
 
-    events = [[lib.bdsp_hip_event_create() for _ in range(3)] for _ in range(args.steps)]
+    # per-kernel durations come from HIP events inside the timed region; an event record costs about 2 us of stream
+    # time, so only every `ev_stride`-th step carries the three events (at least eight steps do)
+    ev_stride = max(1, min(8, args.steps // 8))
+    events = {i: [lib.bdsp_hip_event_create() for _ in range(3)] for i in range(0, args.steps, ev_stride)}
     # Untimed clock pre-warm: the GPU idles at a few hundred MHz and needs tens of milliseconds of load to reach its
     # sustained clock (*measured*: the same step runs 233 us right after start-up and 216 us once the clock has
     # settled, tools/clock_probe.sh: 2.39 GHz, 1.37 kW under this kernel mix).  Then the W warm-up steps of the contract.
@@ -160,7 +163,7 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        step(i, events[i])
+        step(i, events.get(i))
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -188,7 +191,7 @@ def main():
     event_overhead = sorted(empty)[len(empty) // 2]
 
     conv_ms, fft_ms = [], []
-    for e in events:
+    for e in events.values():
         lib.bdsp_hip_event_elapsed_ms(e[0], e[1], C.byref(ms))
         conv_ms.append(ms.value)
         lib.bdsp_hip_event_elapsed_ms(e[1], e[2], C.byref(ms))
@@ -222,6 +225,7 @@ def main():
                             "overlap-save) -> plain_fft(%d-pt), one vector per GPU" % (n, m, n),
                 "points": n, "taps": m, "vectors_per_gpu": 1, "input_buffers_rotated": len(xs),
                 "untimed_clock_prewarm_s": args.prewarm, "untimed_prewarm_steps": pre,
+                "steps_with_kernel_events": len(events),
                 "parallelism": "independent vectors per GPU, no data-path collective",
             },
             "roofline": {
