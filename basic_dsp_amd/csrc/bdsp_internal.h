@@ -93,7 +93,7 @@ int conv_prepare_spectrum(const T* taps_dev, size_t taps, const T* h_freq_dev, T
 template <typename T>
 int conv_run_blocks(const T* in, T* out, size_t points, size_t batch, const T* hs, size_t taps,
                     long long in_off, long long out_off, size_t nblocks_limit, T* last_block_out,
-                    hipStream_t s, bool real_data = false);
+                    hipStream_t s, bool real_data = false, bool hs_is_taps = false);
 // real_data: in/out are REAL vectors of `points` samples and hs is the spectrum of REAL taps; two real
 // blocks share one complex transform pair
 // the spectrum handed to conv_run_blocks is UNSCALED; the kernel multiplies by 1/L while it loads it

@@ -319,7 +319,11 @@ int b1_convolve_pipelined(const T* src, T* dst, size_t points, const T* imp, siz
     BDSP_TRY(dh.alloc(sizeof(T) * 2 * ntaps, s));
     BDSP_TRY(hsb.alloc(sizeof(T) * 2 * L, s));
     BDSP_HIP_TRY(hipMemcpyAsync(dh.p, imp, sizeof(T) * 2 * ntaps, hipMemcpyHostToDevice, s));
-    BDSP_TRY(conv_prepare_spectrum<T>(dh.as<T>(), ntaps, nullptr, hsb.as<T>(), s));
+    // f32: the block kernel transforms the taps itself (as convolve_signal on a device vector does, so the two
+    // paths stay bit-identical); f64: a prepared spectrum
+    constexpr bool fused_taps = sizeof(T) == 4;
+    if (!fused_taps) BDSP_TRY(conv_prepare_spectrum<T>(dh.as<T>(), ntaps, nullptr, hsb.as<T>(), s));
+    const T* hsp = fused_taps ? dh.as<T>() : hsb.as<T>();
     constexpr int K = 8;
     size_t ch = ((points + K - 1) / K + 1023) & ~(size_t)1023;
     int dev = 0;
@@ -365,8 +369,8 @@ int b1_convolve_pipelined(const T* src, T* dst, size_t points, const T* imp, siz
             size_t bend = next_block;
             while (bend < nb && (long long)(bend * V) + in_off + (long long)L <= (long long)c1) ++bend;
             if (bend > next_block && rc == BDSP_OK) {
-                rc = conv_run_blocks<T>(dx.as<T>(), dy.as<T>(), points, 1, hsb.as<T>(), ntaps, in_off + (long long)(next_block * V),
-                                        (long long)(next_block * V), bend - next_block, nullptr, s, false);
+                rc = conv_run_blocks<T>(dx.as<T>(), dy.as<T>(), points, 1, hsp, ntaps, in_off + (long long)(next_block * V),
+                                        (long long)(next_block * V), bend - next_block, nullptr, s, false, fused_taps);
                 const size_t o1 = bend * V < points ? bend * V : points;
                 if (rc == BDSP_OK) pieces[k] = Piece{next_block * V, o1 - next_block * V, true};
                 next_block = bend;
@@ -378,11 +382,11 @@ int b1_convolve_pipelined(const T* src, T* dst, size_t points, const T* imp, siz
     // the wrap-around blocks: block 0 and everything from next_block on
     if (rc == BDSP_OK) {
         const size_t nh = next_block < nb ? next_block : nb; // the deferred head blocks [0, nh)
-        rc = conv_run_blocks<T>(dx.as<T>(), dy.as<T>(), points, 1, hsb.as<T>(), ntaps, in_off, 0, nh, nullptr, s, false);
+        rc = conv_run_blocks<T>(dx.as<T>(), dy.as<T>(), points, 1, hsp, ntaps, in_off, 0, nh, nullptr, s, false, fused_taps);
         if (rc == BDSP_OK) tail[0] = Piece{0, nh * V < points ? nh * V : points, true};
         if (rc == BDSP_OK && next_block < nb) {
-            rc = conv_run_blocks<T>(dx.as<T>(), dy.as<T>(), points, 1, hsb.as<T>(), ntaps, in_off + (long long)(next_block * V),
-                                    (long long)(next_block * V), nb - next_block, nullptr, s, false);
+            rc = conv_run_blocks<T>(dx.as<T>(), dy.as<T>(), points, 1, hsp, ntaps, in_off + (long long)(next_block * V),
+                                    (long long)(next_block * V), nb - next_block, nullptr, s, false, fused_taps);
             if (rc == BDSP_OK) tail[1] = Piece{next_block * V, points - next_block * V, true};
         }
     }

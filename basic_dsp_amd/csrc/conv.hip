@@ -17,6 +17,7 @@
 // transform's first stage wants, so the spectrum never visits LDS.  Inner-stage twiddles live in
 // registers for the whole (persistent) workgroup in the f32 build.
 #include "bdsp_internal.h"
+#include <cstdlib>
 
 namespace bdsp {
 
@@ -92,10 +93,12 @@ __global__ __launch_bounds__(256, sizeof(T) == 4 ? (BDSP_CONV_HL2 ? 4 : 3) : 2) 
     if constexpr (FAST) {
         F::template load_twiddles16_split<256>(tw3a, tw3b, t, tw);
         if constexpr (HREG) {
+            if (!(store_all & 2)) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                cpx<T> hv = hs[ut + 256u * r];
-                hreg[r] = cpx<T>{hv.x * hscale, hv.y * hscale};
+                for (int r = 0; r < 16; ++r) {
+                    cpx<T> hv = hs[ut + 256u * r];
+                    hreg[r] = cpx<T>{hv.x * hscale, hv.y * hscale};
+                }
             }
         }
     }
@@ -106,6 +109,33 @@ __global__ __launch_bounds__(256, sizeof(T) == 4 ? (BDSP_CONV_HL2 ? 4 : 3) : 2) 
     }
     __syncthreads();
     const cpx<T>* tw2p = tw2l + (t & 15) * 17;
+    if constexpr (HREG) {
+        // store_all bit 1: `hs` holds the TAPS, not their spectrum -- every workgroup transforms the zero-padded taps
+        // itself (half a block of extra work per workgroup, in parallel) and keeps the result where the block loop wants
+        // it: X[t + 256 r] in register r.  Saves the separate 7 us spectrum launch and its round trip through memory.
+        if (store_all & 2) {
+            cpx<T> hv[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const unsigned i = ut + 256u * r;
+                hv[r] = i < (unsigned)m_taps ? hs[i] : cpx<T>{(T)0, (T)0};
+            }
+            auto twh = [&](int mm) { return wtab[mm]; };
+            F::template compute<16, 1, -1>(hv, t, twh);
+            F::scatter_a(hv, t, lds);
+            __syncthreads();
+            F::gather_a(hv, t, lds);
+            F::template compute_pre<16, 16, -1>(hv, tw2p);
+            __syncthreads();
+            F::scatter_b(hv, t, lds);
+            __syncthreads();
+            F::gather_b(hv, t, lds);
+            F::template compute_pre16_split<256, -1>(hv, tw3a, tw3b);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) hreg[r] = cpx<T>{hv[r].x * hscale, hv[r].y * hscale};
+            __syncthreads();
+        }
+    }
     const size_t vec = blockIdx.y;
     // per-vector bases; a REAL vector has n real samples (half the bytes of n complex ones)
     const cpx<T>* __restrict__ xv = REAL
@@ -113,7 +143,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 4 ? (BDSP_CONV_HL2 ? 4 : 3) : 2) 
         : reinterpret_cast<const cpx<T>*>(x_) + vec * (size_t)n;
     cpx<T>* __restrict__ yv = REAL
         ? reinterpret_cast<cpx<T>*>(reinterpret_cast<T*>(y_) + vec * (size_t)n)
-        : reinterpret_cast<cpx<T>*>(y_) + vec * (size_t)(store_all ? (unsigned)L : n);
+        : reinterpret_cast<cpx<T>*>(y_) + vec * (size_t)((store_all & 1) ? (unsigned)L : n);
 
     // block b reads x[(b*V + in_off + i) mod n], i = t + 256 r.  Global addressing is
     // uniform 64-bit base (scalar registers) + small unsigned lane index.
@@ -235,7 +265,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 4 ? (BDSP_CONV_HL2 ? 4 : 3) : 2) 
                     if (np >= (unsigned)ov && np < lim) yb[np] = half ? v[r].y : v[r].x;
                 }
             }
-        } else if (store_all) {
+        } else if (store_all & 1) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) yv[ut + 256u * r] = v[r];
         } else {
@@ -339,7 +369,7 @@ int conv_prepare_spectrum(const T* taps_dev, size_t taps, const T* h_freq_dev, T
 template <typename T>
 int conv_run_blocks(const T* in, T* out, size_t points, size_t batch, const T* hs, size_t taps,
                     long long in_off, long long out_off, size_t nblocks_limit, T* last_block_out,
-                    hipStream_t s, bool real_data)
+                    hipStream_t s, bool real_data, bool hs_is_taps)
 {
     constexpr int L = CONV_L;
     if (taps == 0 || taps - 1 > 3 * (size_t)L / 4 || points == 0) {
@@ -377,7 +407,7 @@ int conv_run_blocks(const T* in, T* out, size_t points, size_t batch, const T* h
         hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)batch), dim3(256), lds, s,
                            static_cast<const void*>(in), static_cast<void*>(out),
                            reinterpret_cast<const cpx<T>*>(hs), wtab, (unsigned)points, (int)taps,
-                           in_off, out_off, (unsigned)per_vec, (unsigned)points, 0);
+                           in_off, out_off, (unsigned)per_vec, (unsigned)points, hs_is_taps ? 2 : 0);
         BDSP_LAUNCH_CHECK();
     }
     if (last_block_out) {
@@ -397,11 +427,16 @@ int convolve_overlap_save(const T* in, T* out, size_t points, size_t batch, cons
                           size_t taps, long long in_off, long long out_off, size_t nblocks_limit,
                           T* last_block_out, const T* h_freq_dev, hipStream_t s)
 {
+    // f32 with the taps in hand: the block kernel transforms them itself (one launch for the whole convolution)
+    static const bool no_fused_taps = getenv("BDSP_CONV_NO_FUSED_TAPS") != nullptr;
+    if (sizeof(T) == 4 && !BDSP_CONV_HL2 && taps_dev && !h_freq_dev && !last_block_out && !no_fused_taps)
+        return conv_run_blocks<T>(in, out, points, batch, taps_dev, taps, in_off, out_off, nblocks_limit, nullptr, s,
+                                  false, true);
     WsBlock hsb;
     BDSP_TRY(hsb.alloc(sizeof(cpx<T>) * CONV_L, s));
     BDSP_TRY(conv_prepare_spectrum<T>(taps_dev, taps, h_freq_dev, hsb.as<T>(), s));
     return conv_run_blocks<T>(in, out, points, batch, hsb.as<T>(), taps, in_off, out_off,
-                              nblocks_limit, last_block_out, s, false);
+                              nblocks_limit, last_block_out, s, false, false);
 }
 
 template <typename T>
@@ -436,8 +471,8 @@ template int convolve_overlap_save<double>(const double*, double*, size_t, size_
                                            long long, long long, size_t, double*, const double*, hipStream_t);
 template int conv_prepare_spectrum<float>(const float*, size_t, const float*, float*, hipStream_t);
 template int conv_prepare_spectrum<double>(const double*, size_t, const double*, double*, hipStream_t);
-template int conv_run_blocks<float>(const float*, float*, size_t, size_t, const float*, size_t, long long, long long, size_t, float*, hipStream_t, bool);
-template int conv_run_blocks<double>(const double*, double*, size_t, size_t, const double*, size_t, long long, long long, size_t, double*, hipStream_t, bool);
+template int conv_run_blocks<float>(const float*, float*, size_t, size_t, const float*, size_t, long long, long long, size_t, float*, hipStream_t, bool, bool);
+template int conv_run_blocks<double>(const double*, double*, size_t, size_t, const double*, size_t, long long, long long, size_t, double*, hipStream_t, bool, bool);
 template int convolve_direct<float>(const float*, float*, size_t, size_t, const float*, size_t, bool, hipStream_t);
 template int convolve_direct<double>(const double*, double*, size_t, size_t, const double*, size_t, bool, hipStream_t);
 

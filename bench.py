@@ -127,12 +127,11 @@ def main():
 
     def step(i, ev=None):
         x = xs[i % len(xs)]
-        # convolve_signal: spectrum of the taps (tiny) + ONE fused overlap-save launch
-        bd._lib.check(lib.bdsp_hip_dev_conv_prepare(0, taps.data_ptr(), m, spec.data_ptr(), sp))
+        # convolve_signal: ONE fused overlap-save launch; every workgroup transforms the zero-padded taps itself
+        # before it starts on its blocks (no separate spectrum launch)
         if ev:
             lib.bdsp_hip_event_record(ev[0], sp)
-        bd._lib.check(lib.bdsp_hip_dev_convolve_prepared(0, x.data_ptr(), y.data_ptr(), n, 1,
-                                                         spec.data_ptr(), m, sp))
+        bd._lib.check(lib.bdsp_hip_dev_convolve(0, x.data_ptr(), y.data_ptr(), n, 1, taps.data_ptr(), m, sp))
         if ev:
             lib.bdsp_hip_event_record(ev[1], sp)
         # plain_fft of the filtered vector (3 Stockham passes at 2^24), y <-> scratch ping-pong
