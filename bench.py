@@ -120,7 +120,6 @@ def main():
     taps = (torch.rand(2 * m, generator=gen, device=dev, dtype=torch.float32) * 2 - 1) / m
     y = torch.empty(2 * n, device=dev, dtype=torch.float32)     # convolution result
     scratch = torch.empty(2 * n, device=dev, dtype=torch.float32)  # FFT ping-pong partner
-    spec = torch.empty(2 * lib.bdsp_hip_conv_spectrum_points(), device=dev, dtype=torch.float32)
     stream = torch.cuda.current_stream().cuda_stream
     sp = C.c_void_p(stream)
     in_scratch = C.c_int(0)
