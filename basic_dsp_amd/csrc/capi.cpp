@@ -289,6 +289,8 @@ int conv_real_dev(const T* in, T* out, size_t points, const T* taps, size_t ntap
     }
     if (!(ntaps >= 1 && ntaps <= FUSED_MAX_TAPS && ntaps <= points))
         return convolve_direct<T>(in, out, points, batch, taps, ntaps, false, s);
+    if (sizeof(T) == 4) // f32: one launch, the block kernel reads the real taps and transforms them itself
+        return conv_run_blocks<T>(in, out, points, batch, taps, ntaps, -(long long)(ntaps / 2), 0, 0, nullptr, s, true, true);
     WsBlock hc, hsb;
     BDSP_TRY(hc.alloc(sizeof(T) * 2 * ntaps, s));
     BDSP_TRY(hsb.alloc(sizeof(T) * 2 * conv_fft_len(ntaps), s));

@@ -118,7 +118,9 @@ __global__ __launch_bounds__(256, sizeof(T) == 4 ? (BDSP_CONV_HL2 ? 4 : 3) : 2) 
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const unsigned i = ut + 256u * r;
-                hv[r] = i < (unsigned)m_taps ? hs[i] : cpx<T>{(T)0, (T)0};
+                // bit 2: the taps are REAL scalars (real signal, real filter)
+                if (store_all & 4) hv[r] = i < (unsigned)m_taps ? cpx<T>{reinterpret_cast<const T*>(hs)[i], (T)0} : cpx<T>{(T)0, (T)0};
+                else hv[r] = i < (unsigned)m_taps ? hs[i] : cpx<T>{(T)0, (T)0};
             }
             auto twh = [&](int mm) { return wtab[mm]; };
             F::template compute<16, 1, -1>(hv, t, twh);
@@ -407,7 +409,7 @@ int conv_run_blocks(const T* in, T* out, size_t points, size_t batch, const T* h
         hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)batch), dim3(256), lds, s,
                            static_cast<const void*>(in), static_cast<void*>(out),
                            reinterpret_cast<const cpx<T>*>(hs), wtab, (unsigned)points, (int)taps,
-                           in_off, out_off, (unsigned)per_vec, (unsigned)points, hs_is_taps ? 2 : 0);
+                           in_off, out_off, (unsigned)per_vec, (unsigned)points, hs_is_taps ? (real_data ? 6 : 2) : 0);
         BDSP_LAUNCH_CHECK();
     }
     if (last_block_out) {
