@@ -1305,3 +1305,22 @@ def test_mixed_radix_fft_lengths_and_options(dtype):
         got = m.data()
         for k in (0, rows // 2, rows - 1):
             assert rel_l2(got[k], orc.fft(xs[k].astype(np.float64))) < tol, (rows, n, k)
+
+
+def test_b1_convolve_vector_from_concurrent_threads():
+    """GpuSupport functions are called from whatever thread owns the vector: four threads run the pipelined
+    gpu_convolve_vector (its own streams and helper thread per call) at once; results equal the sequential ones."""
+    import threading
+    n = (1 << 20) + 333
+    xs = [orc.fill_uniform(2 * n, 10 + k, -10, 10, np.float32) for k in range(4)]
+    h = orc.fill_uniform(2 * 700, 99, -1, 1, np.float32) / 700
+    ref = [V.gpu_convolve_vector(x, h, True)[0] for x in xs]
+    out = [None] * 4
+
+    def work(k):
+        for _ in range(3):
+            out[k] = V.gpu_convolve_vector(xs[k], h, True)[0]
+    ts = [threading.Thread(target=work, args=(k,)) for k in range(4)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert all(np.array_equal(out[k], ref[k]) for k in range(4))
