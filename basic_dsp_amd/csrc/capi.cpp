@@ -289,7 +289,7 @@ int conv_real_dev(const T* in, T* out, size_t points, const T* taps, size_t ntap
     }
     if (!(ntaps >= 1 && ntaps <= FUSED_MAX_TAPS && ntaps <= points))
         return convolve_direct<T>(in, out, points, batch, taps, ntaps, false, s);
-    if (sizeof(T) == 4) // f32: one launch, the block kernel reads the real taps and transforms them itself
+    if (true) // one launch: the block kernel reads the real taps and transforms them itself
         return conv_run_blocks<T>(in, out, points, batch, taps, ntaps, -(long long)(ntaps / 2), 0, 0, nullptr, s, true, true);
     WsBlock hc, hsb;
     BDSP_TRY(hc.alloc(sizeof(T) * 2 * ntaps, s));
@@ -323,7 +323,7 @@ int b1_convolve_pipelined(const T* src, T* dst, size_t points, const T* imp, siz
     BDSP_HIP_TRY(hipMemcpyAsync(dh.p, imp, sizeof(T) * 2 * ntaps, hipMemcpyHostToDevice, s));
     // f32: the block kernel transforms the taps itself (as convolve_signal on a device vector does, so the two
     // paths stay bit-identical); f64: a prepared spectrum
-    constexpr bool fused_taps = sizeof(T) == 4;
+    constexpr bool fused_taps = true;
     if (!fused_taps) BDSP_TRY(conv_prepare_spectrum<T>(dh.as<T>(), ntaps, nullptr, hsb.as<T>(), s));
     const T* hsp = fused_taps ? dh.as<T>() : hsb.as<T>();
     constexpr int K = 8;

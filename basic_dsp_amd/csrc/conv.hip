@@ -55,7 +55,8 @@ size_t conv_fft_len(size_t) { return CONV_L; }
 //     reads its address and data VGPRs LATE, so the compiler makes arithmetic that reuses one of them
 //     wait for the store to retire; and vmcnt counts loads and stores together, so with predicated
 //     (variable-count) stores "wait for the prefetched loads" degenerates to "wait for everything";
-//   * the generic build (f64) keeps H and the stage-3 twiddles in L2, no prefetch (214 VGPRs, 2 per CU).
+//   * the f64 build keeps H (64 registers) and the split stage-3 twiddles in registers as well (240 VGPRs, 2 per CU):
+//     161 us for 16M complex f64 points against 253 us with both re-read from L2 every block.
 //   * REAL: the vector is REAL (and so are the taps): two consecutive blocks travel through the
 //     complex transform pair as real and imaginary part (convolution with a real filter is
 //     real-linear, so they come out separated) -- half the butterflies and 8 B of traffic per sample
@@ -87,11 +88,11 @@ __global__ __launch_bounds__(256, sizeof(T) == 4 ? (BDSP_CONV_HL2 ? 4 : 3) : 2) 
     const T hscale = (T)1 / (T)L; // the inverse transform below is unnormalised
     auto tw = [&](int mm) { return wtab[mm]; };
 
-    constexpr bool HREG = FAST && !BDSP_CONV_HL2;
-    cpx<T> tw3a[FAST ? 3 : 1], tw3b[FAST ? 3 : 1], hreg[HREG ? 16 : 1];
+    constexpr bool HREG = !BDSP_CONV_HL2;
+    cpx<T> tw3a[3], tw3b[3], hreg[HREG ? 16 : 1];
     cpx<T>* tw2l = lds + F::LDS_ELEMS;
-    if constexpr (FAST) {
-        F::template load_twiddles16_split<256>(tw3a, tw3b, t, tw);
+    F::template load_twiddles16_split<256>(tw3a, tw3b, t, tw);
+    {
         if constexpr (HREG) {
             if (!(store_all & 2)) {
 #pragma unroll
@@ -225,8 +226,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 4 ? (BDSP_CONV_HL2 ? 4 : 3) : 2) 
         F::scatter_b(v, t, lds);
         __syncthreads();
         F::gather_b(v, t, lds);
-        if constexpr (FAST) F::template compute_pre16_split<256, -1>(v, tw3a, tw3b);
-        else F::template compute<16, 256, -1>(v, t, twl);
+        F::template compute_pre16_split<256, -1>(v, tw3a, tw3b);
 
         // ---- spectrum product
 #pragma unroll
@@ -249,8 +249,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 4 ? (BDSP_CONV_HL2 ? 4 : 3) : 2) 
         F::scatter_b(v, t, lds);
         __syncthreads();
         F::gather_b(v, t, lds);
-        if constexpr (FAST) F::template compute_pre16_split<256, 1>(v, tw3a, tw3b);
-        else F::template compute<16, 256, 1>(v, t, twl);
+        F::template compute_pre16_split<256, 1>(v, tw3a, tw3b);
 
         // ---- store: z[n'] for n' >= M-1 is output b*V + out_off + (n' - (M-1))
         if constexpr (REAL) {
@@ -429,9 +428,9 @@ int convolve_overlap_save(const T* in, T* out, size_t points, size_t batch, cons
                           size_t taps, long long in_off, long long out_off, size_t nblocks_limit,
                           T* last_block_out, const T* h_freq_dev, hipStream_t s)
 {
-    // f32 with the taps in hand: the block kernel transforms them itself (one launch for the whole convolution)
+    // with the taps in hand the block kernel transforms them itself (one launch for the whole convolution)
     static const bool no_fused_taps = getenv("BDSP_CONV_NO_FUSED_TAPS") != nullptr;
-    if (sizeof(T) == 4 && !BDSP_CONV_HL2 && taps_dev && !h_freq_dev && !last_block_out && !no_fused_taps)
+    if (!BDSP_CONV_HL2 && taps_dev && !h_freq_dev && !last_block_out && !no_fused_taps)
         return conv_run_blocks<T>(in, out, points, batch, taps_dev, taps, in_off, out_off, nblocks_limit, nullptr, s,
                                   false, true);
     WsBlock hsb;
