@@ -61,6 +61,12 @@ spec = torch.empty(2 * lib.bdsp_hip_conv_spectrum_points(), device=dev, dtype=to
 lib.bdsp_hip_dev_conv_prepare(0, taps.data_ptr(), m, spec.data_ptr(), sp)
 us = timeit(lambda i: lib.bdsp_hip_dev_convolve_prepared(0, xs[i % 3].data_ptr(), y.data_ptr(), n, 1, spec.data_ptr(), m, sp))
 report("C3 complex f32 16M (*) 1024 taps: fused overlap-save", us, n, 16, "samples")
+us = timeit(lambda i: lib.bdsp_hip_dev_convolve(0, xs[i % 3].data_ptr(), y.data_ptr(), n, 1, taps.data_ptr(), m, sp))
+report("C3 as ONE launch (taps transformed in the kernel): convolve_signal", us, n, 16, "samples")
+xd = rnd(2 * n, torch.float64, 2); yd = torch.empty(2 * n, device=dev, dtype=torch.float64); td = taps.double()
+us = timeit(lambda i: lib.bdsp_hip_dev_convolve(1, xd[i % 2].data_ptr(), yd.data_ptr(), n, 1, td.data_ptr(), m, sp), 10)
+report("C3 in f64: complex f64 16M (*) 1024 taps", us, n, 32, "samples")
+del xd, yd
 us = timeit(lambda i: lib.bdsp_hip_dev_fft(0, xs[i % 3].data_ptr(), y.data_ptr(), n, 1, 0, 1.0, -1, 0.0, C.byref(flag), sp))
 report("FFT complex f32 16M: plain_fft (3 passes)", us, n, 16, "points")
 del xs, y
@@ -77,8 +83,7 @@ del xs, sc, out
 n, b = 1 << 20, 64
 xs = rnd(2 * n * b, torch.float32, 2); y = torch.empty(2 * n * b, device=dev, dtype=torch.float32)
 def c5(i):
-    lib.bdsp_hip_dev_conv_prepare(0, taps.data_ptr(), m, spec.data_ptr(), sp)
-    lib.bdsp_hip_dev_convolve_prepared(0, xs[i % 2].data_ptr(), y.data_ptr(), n, b, spec.data_ptr(), m, sp)
+    lib.bdsp_hip_dev_convolve(0, xs[i % 2].data_ptr(), y.data_ptr(), n, b, taps.data_ptr(), m, sp)
     lib.bdsp_hip_dev_fft(0, y.data_ptr(), xs[i % 2].data_ptr(), n, b, 0, 1.0, -1, 0.0, C.byref(flag), sp)
 us = timeit(c5, 10)
 report("C5/GPU 64 x complex f32 1M: convolve_signal -> fft (compute only)", us, n * b, 32, "samples")
