@@ -159,3 +159,28 @@ def test_mixed_radix_three_million_points():
     assert v.plain_ifft() == 0
     back = v.data().astype(np.float64) / n
     assert np.linalg.norm(back - x) / np.linalg.norm(x) < 2e-6
+
+
+@pytest.mark.gpu
+def test_f64_and_real_convolution_4m_whole_output():
+    """The f64 block kernel (filter spectrum and twiddles in registers, taps transformed in the kernel) and the real
+    two-for-one variant at 4M points: whole output against the oracle's f64 overlap-save, windows against the direct form."""
+    n, m = 1 << 22, 1024
+    x = orc.fill_uniform(2 * n, SEED_C3_X + 1, -10, 10, np.float64)
+    h = orc.fill_uniform(2 * m, SEED_C3_H + 1, -1, 1, np.float64) / m
+    v = DspVec(x, is_complex=True)
+    assert v.convolve_signal(DspVec(h, is_complex=True)) == 0
+    y = v.data()
+    code, ref = orc.overlap_discard(x, h, orc.next_power_of_two(m), fair=True)
+    assert code == 0 and rel_l2(y, ref) < 1e-12
+    for first in (0, 3072 - 8, n // 2, n - 4096):
+        assert rel_l2(y[2 * first:2 * (first + 4096)], orc.convolve_direct(x, h, True, first, 4096)) < 1e-12, first
+    for dtype, tol in ((np.float32, 1e-6), (np.float64, 1e-12)):
+        xr = orc.fill_uniform(n, SEED_C3_X + 2, -10, 10, dtype)
+        hr = (orc.fill_uniform(m - 1, SEED_C3_H + 2, -1, 1, dtype) / dtype(m)).astype(dtype)   # odd tap count
+        r = DspVec(xr)
+        assert r.convolve_signal(DspVec(hr)) == 0
+        yr = r.data()
+        for first in (0, n // 3, n - 4096):
+            ref = orc.convolve_direct(xr.astype(np.float64), hr.astype(np.float64), False, first, 4096)
+            assert rel_l2(yr[first:first + 4096], ref) < tol, (dtype, first)
