@@ -36,7 +36,7 @@ while time.time() < t_end:
     tol = 2e-6 if dtype == np.float32 else 1e-11
     cplx = rng.random() < 0.7
     e = 2 if cplx else 1
-    op = rng.integers(0, 4)
+    op = rng.integers(0, 8)
     seed = int(rng.integers(1, 1 << 30))
     if op == 0:    # fft / ifft of any length
         n = pick_n(300000)
@@ -86,6 +86,62 @@ while time.time() < t_end:
         r = rel(v.data(), ref) if len(ref) == len(v.data()) else 1.0
         lim = tol * 3 if exact else (3e-5 if dtype == np.float32 else 1e-10)
         ok, what = r < lim, ("interpolatef", n, factor, L, fid, cplx, dtype.__name__, r)
+    elif op == 4:  # windowed_fft with every window, any length
+        n = pick_n(100000)
+        if n < 2: n = 2
+        w = int(rng.choice([V.WINDOW_TRIANGULAR, V.WINDOW_HAMMING, V.WINDOW_BLACKMAN_HARRIS, V.WINDOW_RECTANGULAR]))
+        x = orc.fill_uniform(2 * n, seed, -10, 10, dtype)
+        v = DspVec(x, is_complex=True)
+        assert v.windowed_fft(w) == 0
+        # the window itself in T, like the reference (Blackman-Harris at its end points is a cancellation of four
+        # terms down to 6e-5: an f64 window differs from the f32 one by 1e-3 relative there); the transform in f64
+        ref = orc.swap_halves(np.array(orc.fft(orc.apply_window(x, True, w).astype(np.float64))), True, True)
+        r = rel(v.data(), ref)
+        ok, what = r < tol * 4, ("windowed_fft", w, n, dtype.__name__, r)
+    elif op == 5:  # correlate with a padded argument
+        n = int(rng.integers(2, 30000))
+        x = orc.fill_uniform(2 * n, seed, -10, 10, dtype)
+        y = orc.fill_uniform(2 * n, seed + 1, -10, 10, dtype)
+        arg = DspVec(y, is_complex=True)
+        assert arg.prepare_argument_padded() == 0
+        _, ref_arg = orc.prepare_argument(y.astype(np.float64), True)
+        v = DspVec(x, is_complex=True)
+        code = v.correlate(arg)
+        rc, ref = orc.correlate(x.astype(np.float64), ref_arg)
+        r = rel(v.data(), ref) if code == rc == 0 else 1.0
+        ok, what = r < tol * 4, ("correlate", n, dtype.__name__, code, rc, r)
+    elif op == 6:  # interpolate to a random number of points (FFT -> pad / crop -> IFFT), interpolatei
+        n = int(rng.integers(8, 20000))
+        x = orc.fill_uniform(e * n, seed, -10, 10, dtype)
+        v = DspVec(x, is_complex=cplx)
+        if rng.random() < 0.5:
+            dest = int(rng.integers(max(2, n // 3), 3 * n))
+            fid = int(rng.choice([0, 1]))
+            code = v.interpolate(fid, dest, 0.0, rolloff=0.35)
+            # in the vector's precision: the brick-wall response compares the T-valued axis with 1, and a bin on the
+            # edge can fall either way in another precision
+            rc, ref = orc.interpolate(x, cplx, fid, 0.35, dest, 0.0)[:2]
+            what = ("interpolate", n, dest, fid, cplx, dtype.__name__)
+        else:
+            fac = int(rng.integers(2, 6))
+            fid = int(rng.choice([0, 1]))
+            code = v.interpolatei(fid, fac, rolloff=0.35)
+            rc, ref = orc.interpolatei(x, cplx, fid, 0.35, fac)[:2]
+            what = ("interpolatei", n, fac, fid, cplx, dtype.__name__)
+        r = rel(v.data(), ref) if (code == rc == 0 and len(ref) == len(v.data())) else (0.0 if code == rc != 0 else 1.0)
+        ok, what = r < (1e-4 if dtype == np.float32 else 1e-9), what + (code, rc, r)
+    elif op == 7:  # statistics and the running sum
+        n = int(rng.integers(1, 400000))
+        x = orc.fill_uniform(e * n, seed, -10, 10, dtype)
+        v = DspVec(x, is_complex=cplx)
+        st = v.statistics()
+        rs = (orc.complex_statistics if cplx else orc.real_statistics)(x.astype(np.float64))
+        okst = st["count"] == rs["count"] and st["max_index"] == rs["max_index"] and st["min_index"] == rs["min_index"] \
+            and abs(st["sum"] - rs["sum"]) <= (1e-4 if dtype == np.float32 else 1e-9) * (abs(rs["sum"]) + n)
+        assert v.cum_sum() == 0
+        cs = np.cumsum(x.astype(np.float64).reshape(-1, e), axis=0).reshape(-1)
+        okcs = np.max(np.abs(v.data() - cs)) <= (3e-7 if dtype == np.float32 else 1e-13) * (np.max(np.abs(cs)) + 1)
+        ok, what = okst and okcs, ("statistics/cum_sum", n, cplx, dtype.__name__, okst, okcs)
     else:          # elementwise chain, bit-exact
         n = int(rng.integers(1, 300000))
         x = orc.fill_uniform(e * n, seed, -10, 10, dtype)
