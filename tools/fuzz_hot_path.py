@@ -36,7 +36,7 @@ while time.time() < t_end:
     tol = 2e-6 if dtype == np.float32 else 1e-11
     cplx = rng.random() < 0.7
     e = 2 if cplx else 1
-    op = rng.integers(0, 8)
+    op = rng.integers(0, 9)
     seed = int(rng.integers(1, 1 << 30))
     if op == 0:    # fft / ifft of any length
         n = pick_n(300000)
@@ -142,6 +142,15 @@ while time.time() < t_end:
         cs = np.cumsum(x.astype(np.float64).reshape(-1, e), axis=0).reshape(-1)
         okcs = np.max(np.abs(v.data() - cs)) <= (3e-7 if dtype == np.float32 else 1e-13) * (np.max(np.abs(cs)) + 1)
         ok, what = okst and okcs, ("statistics/cum_sum", n, cplx, dtype.__name__, okst, okcs)
+    elif op == 8:  # B1 gpu_convolve_vector on host slices, around the threshold of the pipelined-transfer path
+        n = int(rng.integers((1 << 20) - 3000, (1 << 20) + 300000)) if rng.random() < 0.7 else int(rng.integers(1, 50000))
+        m = int(rng.integers(1, min(n, 3500) + 1))
+        x = orc.fill_uniform(e * n, seed, -10, 10, dtype)
+        h = orc.fill_uniform(e * m, seed + 1, -1, 1, dtype) / dtype(m)
+        y, rg = V.gpu_convolve_vector(x, h, cplx)
+        v = DspVec(x, is_complex=cplx)
+        assert v.convolve_signal(DspVec(h, is_complex=cplx)) == 0
+        ok, what = (y is not None and np.array_equal(y, v.data())), ("b1 convolve", n, m, cplx, dtype.__name__)
     else:          # elementwise chain, bit-exact
         n = int(rng.integers(1, 300000))
         x = orc.fill_uniform(e * n, seed, -10, 10, dtype)
