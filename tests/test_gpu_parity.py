@@ -1324,3 +1324,12 @@ def test_b1_convolve_vector_from_concurrent_threads():
     [t.start() for t in ts]
     [t.join() for t in ts]
     assert all(np.array_equal(out[k], ref[k]) for k in range(4))
+
+
+def test_randomised_differential_run_of_the_hot_path():
+    """Fifteen seconds of tools/fuzz_hot_path.py (seeded): random lengths, tap counts, factors, precisions, families."""
+    import subprocess, sys as _sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([_sys.executable, os.path.join(root, "tools", "fuzz_hot_path.py"), "15", "2024"],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "fuzz ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
