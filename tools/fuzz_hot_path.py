@@ -36,7 +36,7 @@ while time.time() < t_end:
     tol = 2e-6 if dtype == np.float32 else 1e-11
     cplx = rng.random() < 0.7
     e = 2 if cplx else 1
-    op = rng.integers(0, 9)
+    op = rng.integers(0, 11)
     seed = int(rng.integers(1, 1 << 30))
     if op == 0:    # fft / ifft of any length
         n = pick_n(300000)
@@ -151,6 +151,40 @@ while time.time() < t_end:
         v = DspVec(x, is_complex=cplx)
         assert v.convolve_signal(DspVec(h, is_complex=cplx)) == 0
         ok, what = (y is not None and np.array_equal(y, v.data())), ("b1 convolve", n, m, cplx, dtype.__name__)
+    elif op == 9:  # index moves, bit-exact: any length incl. odd point counts and tiny vectors
+        n = int(rng.integers(1, 100000)) if rng.random() < 0.8 else int(rng.integers(1, 12))
+        x = orc.fill_uniform(e * n, seed, -10, 10, dtype)
+        v = DspVec(x, is_complex=cplx)
+        k = rng.integers(0, 6)
+        if k == 0:
+            assert v.swap_halves() == 0; ref = orc.swap_halves(x, cplx, True)
+        elif k == 1:
+            assert v.reverse() == 0; ref = orc.reverse(x, cplx)
+        elif k == 2:
+            pts = n + int(rng.integers(1, 2 * n + 3)); opt = int(rng.integers(0, 3))
+            code = v.zero_pad(pts, opt); rc, ref = orc.zero_pad(x, cplx, pts, opt, buffered=True)  # the facade calls zero_pad_b
+            assert code == rc, (code, rc)
+        elif k == 3:
+            f = int(rng.integers(2, 6)); assert v.zero_interleave(f) == 0; ref = orc.zero_interleave(x, cplx, f)
+        elif k == 4:
+            f = int(rng.integers(1, 7)); d = int(rng.integers(0, f)); assert v.decimatei(f, d) == 0; ref = orc.decimatei(x, cplx, f, d)
+        else:
+            y2 = orc.fill_uniform(e * n, seed + 3, -10, 10, dtype)
+            o = int(rng.integers(0, 4)); code = [v.add, v.sub, v.mul, v.div][o](DspVec(y2, is_complex=cplx))
+            rc, ref = orc.binary(x, y2, cplx, o); assert code == rc == 0
+        got = v.data()
+        ok, what = (len(got) == len(ref) and np.array_equal(got, ref)), ("index move / binary", int(k), n, cplx, dtype.__name__)
+    elif op == 10:  # complex -> real maps and the math family on random lengths
+        n = int(rng.integers(1, 200000))
+        x = orc.fill_uniform(2 * n, seed, -3, 3, dtype)
+        # (tan / tanh have poles inside the sampled square: near them f32 and f64 evaluations of the same formula part ways)
+        name = str(rng.choice(["sqrt", "square", "exp", "sin", "cos", "ln", "sinh", "cosh", "asinh"]))
+        v = DspVec(x, is_complex=True)
+        assert getattr(v, name)() == 0
+        r = rel(v.data(), orc.math(x.astype(np.float64), True, name))
+        m2 = DspVec(x, is_complex=True); assert m2.magnitude_squared() == 0
+        okm = np.array_equal(m2.data(), orc.complex_to_real(x, 1))
+        ok, what = (r < (2e-5 if dtype == np.float32 else 1e-12) and okm), ("math/c2r", name, n, dtype.__name__, r, okm)
     else:          # elementwise chain, bit-exact
         n = int(rng.integers(1, 300000))
         x = orc.fill_uniform(e * n, seed, -10, 10, dtype)
