@@ -524,3 +524,27 @@ def test_math_family_diff_sum_wrap_split_merge_kats():
     np.testing.assert_allclose(mag, np.abs(z), rtol=1e-14)
     np.testing.assert_allclose(ph, np.angle(z), rtol=1e-14)
     np.testing.assert_allclose(orc.set_mag_phase(mag, ph), x, atol=1e-13)
+
+
+def test_reference_overlap_discard_schedule_leaves_a_gap_for_some_sizes():
+    """A property of the REFERENCE algorithm, restated faithfully by orc_convolve_signal and documented as a deviation
+    in DESIGN.md: when the scalar tail (remainder_len / 2 points, convolution.rs:337, 388-399) starts after the last
+    block's results end (:453-458) the outputs in between are never written.  N = 14744, M = 1186: fft_len 8192, one
+    block -> outputs [593, 7600), tail [10648, 14744), nothing in [7600, 10648).  The tail-free schedule and the
+    direct form (the yardsticks of the GPU parity tests) agree everywhere."""
+    n, m = 14744, 1186
+    x = orc.fill_uniform(2 * n, 3, -10, 10, np.float64)
+    h = orc.fill_uniform(2 * m, 9, -1, 1, np.float64) / m
+    direct = orc.convolve_direct(x, h, True)
+    code, y, path = orc.convolve_signal(x, h, True)
+    assert code == 0 and path == 3            # the overlap_discard branch of the dispatcher
+    bad = np.nonzero(np.abs(y - direct) > 1e-9)[0] // 2
+    assert bad.min() == 7600 and bad.max() == 10647
+    ok = np.ones(n, bool); ok[7600:10648] = False
+    assert np.max(np.abs((y - direct).reshape(-1, 2)[ok])) < 1e-9
+    code, fair = orc.overlap_discard(x, h, orc.next_power_of_two(m), fair=True)
+    assert code == 0 and np.max(np.abs(fair - direct)) < 1e-9
+    # ... and no gap at the headline shape of the same length
+    h2 = orc.fill_uniform(2 * 1024, 9, -1, 1, np.float64) / 1024
+    code, y2, _ = orc.convolve_signal(x, h2, True)
+    assert code == 0 and np.max(np.abs(y2 - orc.convolve_direct(x, h2, True))) < 1e-9

@@ -7,7 +7,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import numpy as np
 import oracle_lib as orc
-from basic_dsp_amd import DspVec, vector as V
+from basic_dsp_amd import DspVec, DspMat, vector as V
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 12345)
@@ -36,7 +36,7 @@ while time.time() < t_end:
     tol = 2e-6 if dtype == np.float32 else 1e-11
     cplx = rng.random() < 0.7
     e = 2 if cplx else 1
-    op = rng.integers(0, 11)
+    op = rng.integers(0, 12)
     seed = int(rng.integers(1, 1 << 30))
     if op == 0:    # fft / ifft of any length
         n = pick_n(300000)
@@ -185,6 +185,36 @@ while time.time() < t_end:
         m2 = DspVec(x, is_complex=True); assert m2.magnitude_squared() == 0
         okm = np.array_equal(m2.data(), orc.complex_to_real(x, 1))
         ok, what = (r < (2e-5 if dtype == np.float32 else 1e-12) and okm), ("math/c2r", name, n, dtype.__name__, r, okm)
+    elif op == 11:  # matrix API: every row of a batched operation equals the oracle's result for that row
+        rows = int(rng.integers(1, 40)); n = pick_n(20000)
+        if n < 2: n = 2
+        xs = orc.fill_uniform(2 * n * rows, seed, -10, 10, dtype).reshape(rows, 2 * n)
+        mt = DspMat(xs, is_complex=True)
+        k = rng.integers(0, 4)
+        probe = sorted(set([0, rows - 1, int(rng.integers(0, rows))]))
+        m = 0
+        if k == 0:
+            assert mt.plain_fft() == 0
+            refs = {q: orc.fft(xs[q].astype(np.float64)) for q in probe}
+        elif k == 1:
+            w = int(rng.choice([V.WINDOW_HAMMING, V.WINDOW_TRIANGULAR]))
+            assert mt.windowed_fft(w) == 0
+            refs = {q: orc.swap_halves(np.array(orc.fft(orc.apply_window(xs[q], True, w).astype(np.float64))), True, True) for q in probe}
+        elif k == 2:
+            m = int(rng.integers(1, min(n, 1500) + 1))
+            h = orc.fill_uniform(2 * m, seed + 9, -1, 1, dtype) / dtype(m)
+            assert mt.convolve_signal(DspVec(h, is_complex=True)) == 0
+            # the direct form is the yardstick: the reference's own overlap_discard schedule (which the oracle's
+            # convolve_signal restates faithfully) leaves a GAP of never-computed outputs for some (N, M), e.g.
+            # N = 14744, M = 1186: outputs 7600 .. 10647 (convolution.rs:337, 388-399, 453-458)
+            refs = {q: orc.convolve_direct(xs[q].astype(np.float64), h.astype(np.float64), True) for q in probe} if n * m <= 4_000_000 else \
+                   {q: orc.overlap_discard(xs[q].astype(np.float64), h.astype(np.float64), orc.next_power_of_two(m), fair=True)[1] for q in probe}
+        else:
+            assert mt.swap_halves() == 0 and mt.magnitude_squared() == 0
+            refs = {q: orc.complex_to_real(orc.swap_halves(xs[q], True, True), 1) for q in probe}
+        got = mt.data()
+        r = max(rel(got[q], refs[q]) for q in probe)
+        ok, what = r < tol * 4, ("matrix", int(k), rows, n, m, dtype.__name__, r, [rel(got[q], refs[q]) for q in probe])
     else:          # elementwise chain, bit-exact
         n = int(rng.integers(1, 300000))
         x = orc.fill_uniform(e * n, seed, -10, 10, dtype)
