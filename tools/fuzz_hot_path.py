@@ -36,7 +36,7 @@ while time.time() < t_end:
     tol = 2e-6 if dtype == np.float32 else 1e-11
     cplx = rng.random() < 0.7
     e = 2 if cplx else 1
-    op = rng.integers(0, 12)
+    op = rng.integers(0, 14)
     seed = int(rng.integers(1, 1 << 30))
     if op == 0:    # fft / ifft of any length
         n = pick_n(300000)
@@ -215,6 +215,27 @@ while time.time() < t_end:
         got = mt.data()
         r = max(rel(got[q], refs[q]) for q in probe)
         ok, what = r < tol * 4, ("matrix", int(k), rows, n, m, dtype.__name__, r, [rel(got[q], refs[q]) for q in probe])
+    elif op == 12:  # interpolate_lin / interpolate_hermite: bit-exact against the oracle in the same precision
+        n = int(rng.integers(2, 60000))
+        x = orc.fill_uniform(n, seed, -10, 10, dtype)
+        factor = float(rng.choice([0.5, 1.37, 2.0, 2.5, 3.0, 4.0, 7.0, 0.9]))
+        delay = float(rng.choice([0.0, 0.0, 0.25, -0.4]))
+        v = DspVec(x)
+        herm = rng.random() < 0.5
+        assert (v.interpolate_hermite(factor, delay) if herm else v.interpolate_lin(factor, delay)) == 0
+        ref = (orc.interpolate_hermite if herm else orc.interpolate_lin)(x, dtype(factor), dtype(delay))
+        got = v.data()
+        ok, what = (len(got) == len(ref) and np.array_equal(got, ref)), ("interpolate_lin/hermite", bool(herm), n, factor, delay, dtype.__name__)
+    elif op == 13:  # convolve(function, ratio, len) with the built-in impulse responses
+        n = int(rng.integers(2, 50000))
+        x = orc.fill_uniform(e * n, seed, -10, 10, dtype)
+        L = int(rng.integers(1, 400)); ratio = float(rng.choice([0.1, 0.25, 0.5, 0.3]))
+        fid, ro = (0, 0.0) if rng.random() < 0.5 else (1, 0.35)
+        v = DspVec(x, is_complex=cplx)
+        assert v.convolve(fid, ratio, L, rolloff=ro) == 0
+        ref = orc.convolve_function(x.astype(np.float64), cplx, fid, ro, ratio, L)
+        r = rel(v.data(), ref)
+        ok, what = r < tol * 2, ("convolve(function)", n, L, ratio, fid, cplx, dtype.__name__, r)
     else:          # elementwise chain, bit-exact
         n = int(rng.integers(1, 300000))
         x = orc.fill_uniform(e * n, seed, -10, 10, dtype)
