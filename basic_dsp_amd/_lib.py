@@ -301,6 +301,22 @@ _proto("bdsp_hip_graph_destroy", None, _P)
 
 FFT_INVERSE, FFT_SHIFT_OUT, FFT_SHIFT_IN, FFT_MAGNITUDE = 1, 2, 4, 8
 
+STREAM_DEFAULT = 1  # BDSP_HIP_STREAM_DEFAULT: HIP's null stream (NULL means the library's own stream)
+
+
+def stream_arg(handle):
+    """B3 `stream` argument for a framework stream handle (e.g. torch.cuda.current_stream().cuda_stream).
+    A framework's default stream has handle 0, which the C ABI reads as "the library's own stream" -- work queued
+    there would run unordered against the framework's.  0 is therefore forwarded as BDSP_HIP_STREAM_DEFAULT."""
+    return C.c_void_p(int(handle) if handle else STREAM_DEFAULT)
+
+
+def torch_stream_arg():
+    """The B3 `stream` argument naming torch's current stream."""
+    import torch
+    return stream_arg(torch.cuda.current_stream().cuda_stream)
+
+
 
 class Graph:
     """A captured sequence of library calls (HIP graph).  Usage:

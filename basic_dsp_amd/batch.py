@@ -11,6 +11,12 @@ One process per GPU (torchrun); scatter/gather use torch.distributed (backend "n
 xGMI on the GPU box, "gloo" in the CPU unit tests).  Vector v goes to rank v // ceil(V / world):
 contiguous blocks, so each peer's shard is ONE contiguous message on its own xGMI link.
 
+`scatter_process_gather` moves whole shards (scatter, compute, gather one after the other);
+`scatter_process_gather_chunked` cuts every shard into chunks of a few vectors and runs the three
+stages as a pipeline: chunk k+1 travels to the peer while chunk k is transformed there and the
+result of chunk k-1 travels back (a shard is 512 MiB = ~3.5 ms per
+direction per xGMI link, about ten times its compute time).
+
 The compute step (`process_shard_gpu`) calls the C ABI of libbasic_dsp_hip.so and needs a GPU; the
 sharding logic takes the compute step as a parameter so it can be exercised without one.
 """
@@ -40,7 +46,9 @@ def process_shard_gpu(shard, taps, points, stream=None):
     elem = 0 if shard.dtype == torch.float32 else 1
     nvec = shard.shape[0]
     m = taps.numel() // 2
-    sp = C.c_void_p(stream if stream is not None else torch.cuda.current_stream().cuda_stream)
+    # torch's default stream has handle 0 = "library stream" in the C ABI: stream_arg() forwards it as HIP's null
+    # stream, so the kernels are ordered after the receive that filled `shard` and before whatever reads `out`
+    sp = _lib.stream_arg(stream if stream is not None else torch.cuda.current_stream().cuda_stream)
     spec = torch.empty(2 * lib.bdsp_hip_conv_spectrum_points(), device=shard.device, dtype=shard.dtype)
     out = torch.empty_like(shard)
     _lib.check(lib.bdsp_hip_dev_conv_prepare(elem, taps.data_ptr(), m, spec.data_ptr(), sp), "conv_prepare")
@@ -107,4 +115,97 @@ def scatter_process_gather(batch, taps, points, process_fn, group=None, device=N
     if ops:
         for w in dist.batch_isend_irecv(ops):
             w.wait()
+    return out
+
+
+def scatter_process_gather_chunked(batch, taps, points, process_fn, chunk_vectors=8, group=None, device=None):
+    """The pipelined form of scatter_process_gather.  Every rank's shard is cut into chunks of `chunk_vectors`
+    vectors.  Communication runs in lock-step ROUNDS, one grouped batch of point-to-point operations per round
+    and rank (the same content on both sides, so the grouped calls cannot deadlock):
+
+        round r:   rank 0 -> peer : chunk r            peer -> rank 0 : result of chunk r - 2
+
+    and the peer transforms chunk r on a SIDE stream while round r + 1 is in flight (on CUDA; the CPU/gloo path
+    of the unit tests computes in line).  The two-round lag of the results keeps a round's issue from waiting for
+    the transform that has just been queued.  Rank 0 transforms its own shard chunk by chunk between rounds.
+    Returns the gathered [V, 2*points] tensor on rank 0, None elsewhere.
+    """
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    meta = [None]
+    if rank == 0:
+        meta = [(batch.shape[0], str(batch.dtype).split(".")[-1], int(taps.numel()))]
+    dist.broadcast_object_list(meta, src=0, group=group)
+    nvec, dtype_name, ntaps = meta[0]
+    dtype = getattr(torch, dtype_name)
+    if device is None:
+        device = batch.device if rank == 0 else torch.device("cpu")
+    if rank != 0:
+        taps = torch.empty(ntaps, dtype=dtype, device=device)
+    dist.broadcast(taps, src=0, group=group)
+    cuda = torch.device(device).type == "cuda"
+    side = torch.cuda.Stream(device=device) if cuda else None
+
+    def chunks_of(r):
+        f, l = shard_bounds(nvec, world, r)
+        return [(a, min(a + chunk_vectors, l)) for a in range(f, l, chunk_vectors)]
+
+    per_rank = [chunks_of(r) for r in range(world)]
+    nrounds = max([len(c) for c in per_rank[1:]] + [0]) + 2  # + the two-round lag of the results
+    mine = per_rank[rank]
+    out = torch.empty((nvec, 2 * points), dtype=dtype, device=device) if rank == 0 else None
+    recv_buf = [torch.empty((b - a, 2 * points), dtype=dtype, device=device) for a, b in mine] if rank != 0 else []
+    results = [None] * len(mine)
+    done = [None] * len(mine)  # CUDA events: result k is complete on the side stream
+
+    def run_chunk(k, x):
+        if cuda:
+            side.wait_stream(torch.cuda.current_stream(device))
+            with torch.cuda.stream(side):
+                results[k] = process_fn(x, taps, points)
+                done[k] = torch.cuda.Event()
+                done[k].record(side)
+        else:
+            results[k] = process_fn(x, taps, points)
+
+    own_next = 0
+    for r in range(nrounds):
+        ops = []
+        if rank == 0:
+            for peer in range(1, world):
+                pc = per_rank[peer]
+                if r < len(pc):
+                    a, b = pc[r]
+                    ops.append(dist.P2POp(dist.isend, batch[a:b], peer, group))
+                if 0 <= r - 2 < len(pc):
+                    a, b = pc[r - 2]
+                    ops.append(dist.P2POp(dist.irecv, out[a:b], peer, group))
+        else:
+            if r < len(mine):
+                ops.append(dist.P2POp(dist.irecv, recv_buf[r], 0, group))
+            if 0 <= r - 2 < len(mine):
+                if cuda:
+                    torch.cuda.current_stream(device).wait_event(done[r - 2])
+                ops.append(dist.P2POp(dist.isend, results[r - 2], 0, group))
+        works = dist.batch_isend_irecv(ops) if ops else []
+        # rank 0 transforms a chunk of its own shard while the round is in flight
+        if rank == 0 and own_next < len(mine):
+            a, b = mine[own_next]
+            run_chunk(own_next, batch[a:b])
+            own_next += 1
+        for w in works:
+            w.wait()
+        if rank != 0 and r < len(mine):
+            run_chunk(r, recv_buf[r])
+    if rank == 0:
+        while own_next < len(mine):
+            a, b = mine[own_next]
+            run_chunk(own_next, batch[a:b])
+            own_next += 1
+        if cuda:
+            torch.cuda.current_stream(device).wait_stream(side)
+        for k, (a, b) in enumerate(mine):
+            out[a:b] = results[k]
+    elif cuda:
+        torch.cuda.current_stream(device).wait_stream(side)
     return out

@@ -34,7 +34,15 @@ int hip_fail(hipError_t e, const char* what, const char* file, int line);
 // stream is never handed to work queued on another.
 int device_ready();                       // BDSP_OK or BDSP_ERR_NO_DEVICE
 hipStream_t lib_stream();                 // library stream of the current device
-inline hipStream_t pick_stream(void* s) { return s ? reinterpret_cast<hipStream_t>(s) : lib_stream(); }
+// B3 `stream` argument: NULL = the library's own (non-blocking) stream; BDSP_HIP_STREAM_DEFAULT = (void*)1, the value
+// of hipStreamLegacy = HIP's null stream, which is what a framework's "default stream" handle 0 means -- a caller
+// that forwards such a handle must map 0 to it, or its work would run unordered on the library stream.
+inline hipStream_t pick_stream(void* s)
+{
+    if (!s) return lib_stream();
+    if (s == reinterpret_cast<void*>(1)) return nullptr;
+    return reinterpret_cast<hipStream_t>(s);
+}
 int ws_alloc(void** p, size_t bytes, hipStream_t stream);
 void ws_free(void* p, hipStream_t stream);
 int num_cus();
@@ -88,6 +96,13 @@ template <typename T>
 int convolve_direct(const T* in, T* out, size_t points, size_t batch, const T* taps_dev,
                     size_t taps, bool is_complex, hipStream_t s);
 size_t conv_fft_len(size_t taps);
+// block step (valid outputs per 4096-point block) of the kernel conv_run_blocks<T> will use for these taps
+template <typename T> size_t conv_block_step(size_t points, size_t taps, bool real_data);
+// conv_v2.hip: the second-generation block kernel (complex f32)
+size_t conv_v2_block_step(size_t taps);
+bool conv_v2_applies(size_t points, size_t taps);
+int conv_v2_run(const float* in, float* out, size_t points, size_t batch, const float* hs, size_t taps,
+                size_t first_block, size_t nblocks, bool hs_is_taps, hipStream_t s);
 template <typename T>
 int conv_prepare_spectrum(const T* taps_dev, size_t taps, const T* h_freq_dev, T* hs, hipStream_t s);
 template <typename T>

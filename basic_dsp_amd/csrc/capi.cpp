@@ -6,6 +6,7 @@
 // checks, result codes, delta/valid_len bookkeeping and the buffer "trade" of DspVec
 // (vector/src/vector_types/mod.rs:125-229, support_std.rs:78-124).
 #include <atomic>
+#include <condition_variable>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -306,100 +307,147 @@ int conv_real_dev(const T* in, T* out, size_t points, const T* taps, size_t ntap
 // Block 0 and the last blocks read across the wrap-around point and run when the whole vector is resident.
 // *Measured* 16M f32 points x 1024 taps: 4.88 -> 3.94 ms (the two directions share ~68 GB/s on this host;
 // registering the caller's pages first changed nothing).
+//
+// The two transfer streams and the stage events are created once per calling thread and device and reused by
+// every later call (the OpenCL backend this replaces built a context, a queue and a plan per call,
+// ocl/mod.rs:301-357); the downloader waits on a condition variable, not a spin.
+namespace {
+constexpr int B1_STAGES = 8;
+struct B1Pipe {
+    int dev = -1;
+    hipStream_t up = nullptr, down = nullptr;
+    hipEvent_t landed[B1_STAGES] = {}, computed[B1_STAGES + 1] = {}, ready = nullptr;
+    bool ok = false;
+    int init(int device)
+    {
+        if (ok && dev == device) return BDSP_OK;
+        release();
+        dev = device;
+        BDSP_HIP_TRY(hipStreamCreateWithFlags(&up, hipStreamNonBlocking));
+        BDSP_HIP_TRY(hipStreamCreateWithFlags(&down, hipStreamNonBlocking));
+        for (auto& e : landed) BDSP_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        for (auto& e : computed) BDSP_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        BDSP_HIP_TRY(hipEventCreateWithFlags(&ready, hipEventDisableTiming));
+        ok = true;
+        return BDSP_OK;
+    }
+    void release()
+    {
+        for (auto& e : landed) if (e) { (void)hipEventDestroy(e); e = nullptr; }
+        for (auto& e : computed) if (e) { (void)hipEventDestroy(e); e = nullptr; }
+        if (ready) { (void)hipEventDestroy(ready); ready = nullptr; }
+        if (up) { (void)hipStreamDestroy(up); up = nullptr; }
+        if (down) { (void)hipStreamDestroy(down); down = nullptr; }
+        ok = false;
+    }
+    // no destructor work: at thread exit the HIP runtime may already be gone, and the handles die with the process
+};
+thread_local B1Pipe t_b1pipe;
+} // namespace
+
 template <typename T>
 int b1_convolve_pipelined(const T* src, T* dst, size_t points, const T* imp, size_t ntaps)
 {
     hipStream_t s = lib_stream();
     const size_t L = conv_fft_len(ntaps);
-    size_t V = L - (ntaps - 1);
-    if (V >= 16) V &= ~(size_t)15; // the block kernel's aligned step (conv.hip)
+    const size_t V = conv_block_step<T>(points, ntaps, false); // the block kernel's step (conv.hip / conv_v2.hip)
     const size_t nb = (points + V - 1) / V;
     const long long in_off = -(long long)(ntaps / 2);
-    WsBlock dx, dy, dh, hsb;
+    constexpr int K = B1_STAGES;
+    int dev = 0;
+    BDSP_HIP_TRY(hipGetDevice(&dev));
+    B1Pipe& pipe = t_b1pipe;
+    {
+        int c = pipe.init(dev);
+        if (c != BDSP_OK) { pipe.release(); return c; }
+    }
+    WsBlock dx, dy, dh;
     BDSP_TRY(dx.alloc(sizeof(T) * 2 * points, s));
     BDSP_TRY(dy.alloc(sizeof(T) * 2 * points, s));
     BDSP_TRY(dh.alloc(sizeof(T) * 2 * ntaps, s));
-    BDSP_TRY(hsb.alloc(sizeof(T) * 2 * L, s));
     BDSP_HIP_TRY(hipMemcpyAsync(dh.p, imp, sizeof(T) * 2 * ntaps, hipMemcpyHostToDevice, s));
-    // f32: the block kernel transforms the taps itself (as convolve_signal on a device vector does, so the two
-    // paths stay bit-identical); f64: a prepared spectrum
-    constexpr bool fused_taps = true;
-    if (!fused_taps) BDSP_TRY(conv_prepare_spectrum<T>(dh.as<T>(), ntaps, nullptr, hsb.as<T>(), s));
-    const T* hsp = fused_taps ? dh.as<T>() : hsb.as<T>();
-    constexpr int K = 8;
-    size_t ch = ((points + K - 1) / K + 1023) & ~(size_t)1023;
-    int dev = 0;
-    BDSP_HIP_TRY(hipGetDevice(&dev));
-    hipStream_t up = nullptr, down = nullptr;
-    BDSP_HIP_TRY(hipStreamCreateWithFlags(&up, hipStreamNonBlocking));
-    BDSP_HIP_TRY(hipStreamCreateWithFlags(&down, hipStreamNonBlocking));
-    hipEvent_t landed[K], computed[K + 1];
-    for (int k = 0; k < K; ++k) (void)hipEventCreateWithFlags(&landed[k], hipEventDisableTiming);
-    for (int k = 0; k <= K; ++k) (void)hipEventCreateWithFlags(&computed[k], hipEventDisableTiming);
+    // the workspace blocks come from the library stream's cache: earlier (asynchronous) work on that stream may still
+    // be using them, so the transfer streams start behind everything queued on it so far
+    BDSP_HIP_TRY(hipEventRecord(pipe.ready, s));
+    BDSP_HIP_TRY(hipStreamWaitEvent(pipe.up, pipe.ready, 0));
+    BDSP_HIP_TRY(hipStreamWaitEvent(pipe.down, pipe.ready, 0));
+    // the block kernel transforms the taps itself (as convolve_signal on a device vector does, so the two paths stay
+    // bit-identical)
+    const T* hsp = dh.as<T>();
+    const size_t ch = ((points + K - 1) / K + 1023) & ~(size_t)1023;
     struct Piece { size_t first, count; bool valid; };
     Piece pieces[K], tail[2] = {Piece{0, 0, false}, Piece{0, 0, false}}; // output ranges per stage
     for (int k = 0; k < K; ++k) pieces[k] = Piece{0, 0, false};
-    std::atomic<int> stages_recorded{0}; // stage k may be waited for once its event has been recorded
+    std::mutex mu;
+    std::condition_variable cv;
+    int stages_recorded = 0; // stage k may be waited for once its event has been recorded (guarded by mu)
     int drc = BDSP_OK;
-    // downloads run on their own thread and stream, in step with the compute stream
+    auto publish = [&](int n) {
+        { std::lock_guard<std::mutex> lk(mu); stages_recorded = n; }
+        cv.notify_one();
+    };
+    // downloads run on their own thread and stream, in step with the compute stream (a device-to-host copy into
+    // pageable memory blocks its caller, so it cannot share the thread that feeds the uploads)
     std::thread downloader([&] {
-        (void)hipSetDevice(dev);
+        if (hipSetDevice(dev) != hipSuccess) { drc = BDSP_ERR_HIP; return; }
         auto fetch = [&](const Piece& p) {
             if (!p.valid || p.count == 0) return;
-            if (hipMemcpyAsync(dst + 2 * p.first, dy.as<T>() + 2 * p.first, sizeof(T) * 2 * p.count, hipMemcpyDeviceToHost, down) != hipSuccess) drc = BDSP_ERR_HIP;
+            if (hipMemcpyAsync(dst + 2 * p.first, dy.as<T>() + 2 * p.first, sizeof(T) * 2 * p.count, hipMemcpyDeviceToHost, pipe.down) != hipSuccess) drc = BDSP_ERR_HIP;
         };
         for (int k = 0; k <= K; ++k) {
-            while (stages_recorded.load(std::memory_order_acquire) <= k) std::this_thread::yield();
-            (void)hipStreamWaitEvent(down, computed[k], 0);
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return stages_recorded > k; });
+            }
+            if (hipStreamWaitEvent(pipe.down, pipe.computed[k], 0) != hipSuccess) drc = BDSP_ERR_HIP;
             if (k < K) fetch(pieces[k]);
             else { fetch(tail[0]); fetch(tail[1]); }
         }
-        if (hipStreamSynchronize(down) != hipSuccess) drc = BDSP_ERR_HIP;
+        if (hipStreamSynchronize(pipe.down) != hipSuccess) drc = BDSP_ERR_HIP;
     });
     int rc = BDSP_OK;
+    auto hip_ok = [&](hipError_t e) { if (e != hipSuccess && rc == BDSP_OK) { set_last_error(hipGetErrorString(e)); rc = BDSP_ERR_HIP; } };
     // blocks whose window starts before x[0] (block 0 always; more of them when M/2 exceeds the block step) read the
     // END of the vector through the wrap-around: deferred until everything is resident
-    const size_t head = (size_t)((-in_off + (long long)V - 1) / (long long)V) > nb ? nb : (size_t)((-in_off + (long long)V - 1) / (long long)V);
-    size_t next_block = head < 1 ? 1 : head;
+    size_t head = (size_t)((-in_off + (long long)V - 1) / (long long)V);
+    if (head > nb) head = nb;
+    const size_t nhead = head < 1 ? (nb < 1 ? nb : 1) : head; // the deferred head blocks are [0, nhead)
+    size_t next_block = nhead;
     for (int k = 0; k < K; ++k) {
         const size_t c0 = (size_t)k * ch, c1 = c0 + ch < points ? c0 + ch : points;
         if (c0 < points && rc == BDSP_OK) {
-            if (hipMemcpyAsync(dx.as<T>() + 2 * c0, src + 2 * c0, sizeof(T) * 2 * (c1 - c0), hipMemcpyHostToDevice, up) != hipSuccess) rc = BDSP_ERR_HIP;
-            (void)hipEventRecord(landed[k], up);
-            (void)hipStreamWaitEvent(s, landed[k], 0);
+            hip_ok(hipMemcpyAsync(dx.as<T>() + 2 * c0, src + 2 * c0, sizeof(T) * 2 * (c1 - c0), hipMemcpyHostToDevice, pipe.up));
+            hip_ok(hipEventRecord(pipe.landed[k], pipe.up));
+            hip_ok(hipStreamWaitEvent(s, pipe.landed[k], 0));
             // blocks whose window [b V + in_off, + L) lies inside the uploaded prefix [0, c1)
             size_t bend = next_block;
             while (bend < nb && (long long)(bend * V) + in_off + (long long)L <= (long long)c1) ++bend;
             if (bend > next_block && rc == BDSP_OK) {
                 rc = conv_run_blocks<T>(dx.as<T>(), dy.as<T>(), points, 1, hsp, ntaps, in_off + (long long)(next_block * V),
-                                        (long long)(next_block * V), bend - next_block, nullptr, s, false, fused_taps);
+                                        (long long)(next_block * V), bend - next_block, nullptr, s, false, true);
                 const size_t o1 = bend * V < points ? bend * V : points;
                 if (rc == BDSP_OK) pieces[k] = Piece{next_block * V, o1 - next_block * V, true};
                 next_block = bend;
             }
         }
-        (void)hipEventRecord(computed[k], s);
-        stages_recorded.store(k + 1, std::memory_order_release);
+        hip_ok(hipEventRecord(pipe.computed[k], s));
+        publish(k + 1);
     }
-    // the wrap-around blocks: block 0 and everything from next_block on
+    // the wrap-around blocks: the deferred head [0, nhead) and everything from next_block on
     if (rc == BDSP_OK) {
-        const size_t nh = next_block < nb ? next_block : nb; // the deferred head blocks [0, nh)
-        rc = conv_run_blocks<T>(dx.as<T>(), dy.as<T>(), points, 1, hsp, ntaps, in_off, 0, nh, nullptr, s, false, fused_taps);
-        if (rc == BDSP_OK) tail[0] = Piece{0, nh * V < points ? nh * V : points, true};
+        rc = conv_run_blocks<T>(dx.as<T>(), dy.as<T>(), points, 1, hsp, ntaps, in_off, 0, nhead, nullptr, s, false, true);
+        if (rc == BDSP_OK) tail[0] = Piece{0, nhead * V < points ? nhead * V : points, true};
         if (rc == BDSP_OK && next_block < nb) {
             rc = conv_run_blocks<T>(dx.as<T>(), dy.as<T>(), points, 1, hsp, ntaps, in_off + (long long)(next_block * V),
-                                    (long long)(next_block * V), nb - next_block, nullptr, s, false, fused_taps);
+                                    (long long)(next_block * V), nb - next_block, nullptr, s, false, true);
             if (rc == BDSP_OK) tail[1] = Piece{next_block * V, points - next_block * V, true};
         }
     }
-    (void)hipEventRecord(computed[K], s);
-    stages_recorded.store(K + 1, std::memory_order_release);
+    hip_ok(hipEventRecord(pipe.computed[K], s));
+    publish(K + 1);
     downloader.join();
-    if (hipStreamSynchronize(up) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) rc = rc == BDSP_OK ? BDSP_ERR_HIP : rc;
-    for (int k = 0; k < K; ++k) (void)hipEventDestroy(landed[k]);
-    for (int k = 0; k <= K; ++k) (void)hipEventDestroy(computed[k]);
-    (void)hipStreamDestroy(up);
-    (void)hipStreamDestroy(down);
+    hip_ok(hipStreamSynchronize(pipe.up));
+    hip_ok(hipStreamSynchronize(s));
     return rc != BDSP_OK ? rc : drc;
 }
 
@@ -946,6 +994,13 @@ int op_sifft(DevVec<T>* v, bool shift, int window)
 {
     if (!v->freq || !v->complex_) { v->poison(); v->complex_ = true; v->freq = true; return BDSP_ERR_MUST_BE_FREQ; }
     hipStream_t s = lib_stream();
+    if (shift) {
+        // sifft: scale(1/points) and ifft_shift come first (freq_to_time.rs:226-236), so the symmetry test of
+        // plain_sifft below sees the first bin of the SHIFTED half spectrum, as in the reference
+        const size_t p = v->points();
+        if (p) BDSP_TRY(ew_real_scale<T>(v->data, v->valid_len, (T)1 / (T)p, s));
+        BDSP_TRY(op_swap<T>(v, false));
+    }
     if (v->points() > 0) {
         // The first bin must be real (freq_to_time.rs:203-211 tests |im| > 1e-10).  A spectrum that
         // was COMPUTED (e.g. by plain_sfft through Bluestein) carries rounding noise of a few
@@ -960,12 +1015,6 @@ int op_sifft(DevVec<T>* v, bool shift, int window)
             v->poison(); v->complex_ = true; v->freq = true;
             return BDSP_ERR_CONJ_SYMMETRIC;
         }
-    }
-    if (shift) {
-        // sifft: scale(1/points) and ifft_shift BEFORE mirroring (freq_to_time.rs:226-236)
-        const size_t p = v->points();
-        if (p) BDSP_TRY(ew_real_scale<T>(v->data, v->valid_len, (T)1 / (T)p, s));
-        BDSP_TRY(op_swap<T>(v, false));
     }
     BDSP_TRY(op_mirror<T>(v));
     BDSP_TRY(op_fft<T>(v, true, false, -1));

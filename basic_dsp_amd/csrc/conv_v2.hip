@@ -1,0 +1,288 @@
+// conv_v2.hip -- the fused overlap-save block kernel for complex f32 vectors, second generation.
+//
+// Same mathematics as conv.hip's k_overlap_save (reference: overlap_discard, convolution.rs:304-461; result
+// y[i] = sum_k x[(i + ceil(M/2) - 1 - k) mod N] h[k], time_freq/mod.rs:455-473): per 4096-point block
+// load -> FFT -> x H -> IFFT -> store of the valid part, one launch.  What changed, each item measured on MI355X
+// with tools/lab/conv_lab.hip (16M points x 1024 taps, random data, three rotating inputs; the first-generation
+// kernel runs 74-76 us on the same boxes):
+//   * NO MERGE POINTS IN THE BLOCK LOOP.  The first generation chose per block between plain and wrap-around loads
+//     and predicated every store; hipcc's code around those joins cost 4.5 us (loads) and 3.9 us (stores) per launch
+//     although the branches themselves are free.  Here the few blocks whose window wraps around the end of the
+//     vector are taken first, by the first workgroups, through the general code; the loop over interior blocks has
+//     plain contiguous loads and stores whole 256-point rows without a predicate.
+//   * WHOLE-ROW STORES need the first valid output of a block on a row boundary: the taps are DELAYED by
+//     d = 256 R0 - (M-1) samples (R0 = ceil((M-1)/256), a template parameter: a run-time R0 measured 7 us slower), so
+//     z[256 R0 ...] are the block's outputs and V = 4096 - 256 R0.  Every store is then a full 128-byte line as well
+//     (the first generation's started 8 bytes into one).
+//   * A STATIC SKEW OF THE BLOCK COUNT.  A CU holds three workgroups; the hardware issues the OLDEST wave first, so
+//     the workgroup dispatched first runs ~1.5x faster than the third and, with equal shares, finished 20 us before it
+//     (per-workgroup timelines: 41 / 50 / 63 us), leaving the CU a third full.  Equalising the PROGRESS (a dynamic
+//     ticket queue per XCD) measured slower (74-76 us): the CU is at its best with one workgroup running unimpeded and
+//     the others filling its gaps.  So the shares follow the dispatch order instead: the first third of the grid
+//     takes ~43 % of the blocks, the second ~37 %, the last ~20 % (whole rounds of G/3 blocks: 9 / 8 / 4.3 rounds at
+//     16M points).  Only speed depends on the dispatch order.  62-63 us = 0.53-0.54 of the 8 TB/s roofline.
+//   * measured and NOT adopted: decimation-in-frequency / -time transforms with a wave-private second exchange
+//     (4 barriers per block instead of 8: 65-68 us with the skew, 2 workgroups per CU), all twiddles in registers at
+//     2 per CU (64.4-66.8), register or LDS-DMA prefetch of the next block (72-77), 4 workgroups per CU with 9
+//     spilled registers (70).
+#include "bdsp_internal.h"
+#include <cstdlib>
+
+namespace bdsp {
+
+namespace {
+
+constexpr int L2 = 4096;
+using C32 = cpx<float>;
+
+struct ConvV2Args {
+    const C32* x;
+    C32* y;
+    const C32* hs;   // taps (hs_is_taps) or the UNSCALED, undelayed L-point spectrum of the taps
+    const C32* wtab; // exp(-2 pi i m / 4096)
+    unsigned n;      // points per vector
+    unsigned taps;
+    unsigned b_first, b_end; // blocks of each vector to compute
+    unsigned nb_lo, nb_hi;   // the interior ones among them: window inside [0, n), all V outputs below n
+    unsigned batch;
+    unsigned na, nbb;        // interior blocks (all vectors together) given to dispatch groups 0 and 1
+    int hs_is_taps;
+};
+
+__device__ __forceinline__ unsigned xcd_contiguous(unsigned bid, unsigned g)
+{
+    // workgroup w runs on XCD w % 8 (observed; only speed depends on it): give every XCD a contiguous run of the
+    // blocks of a round, so that the M-1 input samples neighbouring blocks share are an L2 hit
+    return (g & 7) == 0 ? (bid & 7) * (g >> 3) + (bid >> 3) : bid;
+}
+
+template <int R0, bool BATCHED>
+__global__ __launch_bounds__(256, 3) void k_overlap_save_v2(ConvV2Args a)
+{
+    constexpr int L = L2;
+    constexpr unsigned V = L - 256 * R0, OV = 256 * R0;
+    using F = WgFft<float, L, 256>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    C32* lds = reinterpret_cast<C32*>(smem_raw);
+    const int t = threadIdx.x;
+    const unsigned ut = t;
+    const float hscale = 1.0f / L;
+    auto tww = [&](int mm) { return a.wtab[mm]; };
+    C32 hreg[16], tw3a[3], tw3b[3];
+    C32* tw2l = lds + F::LDS_ELEMS;
+    const C32* tw2p = tw2l + (t & 15) * 17;
+    if (t < 240) {
+        int k = t / 15, r = t % 15 + 1;
+        tw2l[k * 17 + r - 1] = a.wtab[r * k * 16];
+    }
+    F::template load_twiddles16_split<256>(tw3a, tw3b, t, tww);
+    __syncthreads();
+
+    auto forward = [&](C32 (&v)[16]) {
+        F::template compute<16, 1, -1>(v, t, tww);
+        __syncthreads(); // the previous transform's last gather is done
+        F::scatter_a(v, t, lds);
+        __syncthreads();
+        F::gather_a(v, t, lds);
+        F::template compute_pre<16, 16, -1>(v, tw2p);
+        __syncthreads();
+        F::scatter_b(v, t, lds);
+        __syncthreads();
+        F::gather_b(v, t, lds);
+        F::template compute_pre16_split<256, -1>(v, tw3a, tw3b);
+    };
+    auto inverse = [&](C32 (&v)[16]) {
+        F::template compute<16, 1, 1>(v, t, tww);
+        __syncthreads();
+        F::scatter_a(v, t, lds);
+        __syncthreads();
+        F::gather_a(v, t, lds);
+        F::template compute_pre<16, 16, 1>(v, tw2p);
+        __syncthreads();
+        F::scatter_b(v, t, lds);
+        __syncthreads();
+        F::gather_b(v, t, lds);
+        F::template compute_pre16_split<256, 1>(v, tw3a, tw3b);
+    };
+
+    // ---- the filter spectrum, delayed by d samples, x 1/L, in register r of thread t: H'[t + 256 r]
+    const unsigned d = OV - (a.taps - 1);
+    if (a.hs_is_taps) {
+        C32 hv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const unsigned i = ut + 256u * r;
+            hv[r] = (i >= d && i - d < a.taps) ? a.hs[i - d] : C32{0.0f, 0.0f};
+        }
+        forward(hv);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) hreg[r] = C32{hv[r].x * hscale, hv[r].y * hscale};
+    } else {
+        // a delay by d samples is the linear phase exp(-2 pi i k d / L) on bin k
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const unsigned k = ut + 256u * r;
+            const C32 hv = a.hs[k];
+            hreg[r] = cmul(C32{hv.x * hscale, hv.y * hscale}, a.wtab[(k * d) & (L - 1)]);
+        }
+    }
+    auto transform = [&](C32 (&v)[16]) {
+        forward(v);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = cmul(v[r], hreg[r]);
+        inverse(v);
+    };
+
+    const long long in_off = -(long long)(a.taps / 2);
+    const unsigned G = gridDim.x;
+    // ---- blocks that wrap around the ends of their vector (or whose outputs run past it): general code, taken first
+    {
+        const unsigned nw = (a.nb_lo - a.b_first) + (a.b_end - a.nb_hi), total_w = nw * a.batch;
+        for (unsigned w = blockIdx.x; w < total_w; w += G) {
+            const unsigned vec = w / nw, k = w % nw;
+            const unsigned b = k < a.nb_lo - a.b_first ? a.b_first + k : a.nb_hi + (k - (a.nb_lo - a.b_first));
+            const C32* xv = a.x + (size_t)vec * a.n;
+            C32* yv = a.y + (size_t)vec * a.n;
+            C32 v[16];
+            long long sb = ((long long)b * V + in_off) % (long long)a.n;
+            if (sb < 0) sb += a.n;
+            const unsigned idx = (unsigned)sb + ut;
+            if (a.n >= (unsigned)L) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    unsigned i = idx + 256u * r;
+                    if (i >= a.n) i -= a.n;
+                    v[r] = xv[i];
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] = xv[(idx + 256u * r) % a.n];
+            }
+            transform(v);
+            // z[np], OV <= np < OV + V, is output b V + np - OV; only outputs below n exist
+            const long long obase = (long long)b * V - OV;
+            const long long room = (long long)a.n - obase;
+            const unsigned lim = room <= 0 ? 0u : (room > L ? (unsigned)L : (unsigned)room);
+            C32* yb = yv + obase;
+#pragma unroll
+            for (int r = R0; r < 16; ++r) {
+                const unsigned np = ut + 256u * r;
+                if (np < lim) yb[np] = v[r];
+            }
+        }
+    }
+    // ---- interior blocks: three dispatch groups with skewed shares (see the header)
+    const unsigned ni = a.nb_hi - a.nb_lo, total = ni * a.batch, gs = G / 3;
+    const unsigned grp = blockIdx.x / gs;
+    if (grp >= 3) return;
+    const unsigned lo = grp == 0 ? 0u : (grp == 1 ? a.na : a.na + a.nbb);
+    const unsigned hi = grp == 0 ? a.na : (grp == 1 ? a.na + a.nbb : total);
+    const unsigned w2 = xcd_contiguous(blockIdx.x - grp * gs, gs);
+    for (unsigned id = lo + w2; id < hi; id += gs) {
+        unsigned vec = 0, b = a.nb_lo + id;
+        if (BATCHED) { vec = id / ni; b = a.nb_lo + id % ni; }
+        const C32* xb = a.x + ((size_t)vec * a.n + ((long long)b * V + in_off));
+        C32* yb = a.y + ((size_t)vec * a.n + ((long long)b * V - OV));
+        C32 v[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = xb[ut + 256u * r];
+        transform(v);
+#pragma unroll
+        for (int r = R0; r < 16; ++r) yb[ut + 256u * r] = v[r];
+    }
+}
+
+template <int R0>
+int launch_v2(const ConvV2Args& a, unsigned grid, size_t lds, hipStream_t s)
+{
+    if (a.batch > 1) {
+        auto kern = k_overlap_save_v2<R0, true>;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, a);
+    } else {
+        auto kern = k_overlap_save_v2<R0, false>;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, a);
+    }
+    BDSP_LAUNCH_CHECK();
+    return BDSP_OK;
+}
+
+} // namespace
+
+// block step of the second-generation kernel: V = 4096 - 256 ceil((M-1)/256)
+size_t conv_v2_block_step(size_t taps)
+{
+    const size_t r0 = taps <= 1 ? 1 : (taps - 1 + 255) / 256;
+    return (size_t)L2 - 256 * r0;
+}
+
+bool conv_v2_applies(size_t points, size_t taps)
+{
+    static const bool off = getenv("BDSP_CONV_V1") != nullptr;
+    return !off && taps >= 1 && taps - 1 <= 3 * (size_t)L2 / 4 && points >= 1 && points < (size_t(1) << 31);
+}
+
+// Blocks [first_block, first_block + nblocks) (nblocks = 0: all from first_block on) of every vector of the batch.
+int conv_v2_run(const float* in, float* out, size_t points, size_t batch, const float* hs, size_t taps,
+                size_t first_block, size_t nblocks, bool hs_is_taps, hipStream_t s)
+{
+    const cpx<float>* wtab;
+    BDSP_TRY(twiddle_table<float>(L2, &wtab));
+    const unsigned r0 = taps <= 1 ? 1u : (unsigned)((taps - 1 + 255) / 256);
+    const long long V = L2 - 256 * (long long)r0;
+    const long long nb_all = ((long long)points + V - 1) / V;
+    long long b0 = (long long)first_block, b1 = nblocks ? b0 + (long long)nblocks : nb_all;
+    if (b1 > nb_all) b1 = nb_all;
+    if (b0 >= b1 || batch == 0) return BDSP_OK;
+    const long long in_off = -(long long)(taps / 2);
+    // interior blocks: window [bV + in_off, + L) inside [0, n) (then all V outputs are below n as well, see below)
+    long long lo = b0, hi = b1;
+    while (lo < hi && lo * V + in_off < 0) ++lo;
+    while (hi > lo && ((hi - 1) * V + in_off + L2 > (long long)points || (hi - 1) * V + V > (long long)points)) --hi;
+    if ((unsigned long long)(b1 - b0) * batch >= (1ull << 32) || batch > 0xffffffffull) {
+        set_last_error("convolve_overlap_save: too many blocks");
+        return BDSP_ERR_UNSUPPORTED;
+    }
+    ConvV2Args a{};
+    a.x = reinterpret_cast<const cpx<float>*>(in);
+    a.y = reinterpret_cast<cpx<float>*>(out);
+    a.hs = reinterpret_cast<const cpx<float>*>(hs);
+    a.wtab = wtab;
+    a.n = (unsigned)points;
+    a.taps = (unsigned)taps;
+    a.b_first = (unsigned)b0; a.b_end = (unsigned)b1;
+    a.nb_lo = (unsigned)lo; a.nb_hi = (unsigned)hi;
+    a.batch = (unsigned)batch;
+    a.hs_is_taps = hs_is_taps ? 1 : 0;
+    // grid: three workgroups per CU, a multiple of 24 so that the three dispatch groups are multiples of 8
+    const unsigned long long interior = (unsigned long long)(hi - lo) * batch;
+    const unsigned long long wrap = (unsigned long long)((lo - b0) + (b1 - hi)) * batch;
+    unsigned grid = (unsigned)num_cus() * 3;
+    grid -= grid % 24;
+    if (grid < 24) grid = 24;
+    if (interior + wrap < grid) { // a small problem: no more workgroups than blocks (each one transforms the taps first)
+        grid = (unsigned)((interior + wrap + 23) / 24 * 24);
+        if (grid < 24) grid = 24;
+    }
+    const unsigned gs = grid / 3;
+    // shares in whole rounds of gs blocks: ~43 % / ~37 % / rest (measured optimum 9 / 8 / 4.3 rounds of 21.3)
+    const unsigned long long rounds = (interior + gs - 1) / gs;
+    unsigned long long ra = (rounds * 43 + 50) / 100, rb = (rounds * 37 + 50) / 100;
+    if (rounds && ra == 0) ra = 1;
+    unsigned long long na = ra * gs, nbb = rb * gs;
+    if (na > interior) na = interior;
+    if (na + nbb > interior) nbb = interior - na;
+    a.na = (unsigned)na;
+    a.nbb = (unsigned)nbb;
+    const size_t lds = (size_t)(WgFft<float, L2, 256>::LDS_ELEMS + 16 * 17) * sizeof(cpx<float>);
+    switch (r0) {
+#define BDSP_R0(N) case N: return launch_v2<N>(a, grid, lds, s);
+        BDSP_R0(1) BDSP_R0(2) BDSP_R0(3) BDSP_R0(4) BDSP_R0(5) BDSP_R0(6)
+        BDSP_R0(7) BDSP_R0(8) BDSP_R0(9) BDSP_R0(10) BDSP_R0(11) BDSP_R0(12)
+#undef BDSP_R0
+    default: break;
+    }
+    set_last_error("convolve_overlap_save: taps out of range for the block kernel");
+    return BDSP_ERR_UNSUPPORTED;
+}
+
+} // namespace bdsp

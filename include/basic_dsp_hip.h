@@ -721,11 +721,15 @@ int32_t bdsp_hip_mat_multiply_frequency_response64(MatBuf64 *m, int32_t frequenc
 
 /* ==========================================================================================
  * B3 -- kernels on caller-owned DEVICE memory.  `stream` is a hipStream_t passed as void*
- * (NULL = the library's own stream).  Calls are asynchronous on that stream unless noted.
+ * (NULL = the library's own non-blocking stream; BDSP_HIP_STREAM_DEFAULT = HIP's null stream, the
+ * stream a framework's "default stream" handle 0 stands for -- forward such a handle as
+ * BDSP_HIP_STREAM_DEFAULT, never as 0).  Calls are asynchronous on that stream unless noted.
  * `elem` = 0 for f32, 1 for f64.  Scratch: ops that are not in place ping-pong between `data`
  * and `scratch` (same size); they return in *result_in_scratch whether the result ended in
  * `scratch` (1) or `data` (0), mirroring the reference's Buffer::trade (support_std.rs:78-82).
  * ======================================================================================== */
+
+#define BDSP_HIP_STREAM_DEFAULT ((void *)1) /* HIP's null stream (same value as hipStreamLegacy) */
 
 /* Unnormalised complex FFT of `batch` contiguous vectors of `points` complex each.
  * flags: BDSP_FFT_* bits. */

@@ -623,6 +623,90 @@ int SFX(orc_overlap_discard)(REAL *x, size_t len, const REAL *h, size_t hlen, si
 }
 
 /* ------------------------------------------------------------------------------------------
+ * Multi-threaded CPU baseline (bench.py's cpu_baseline leg only): the tail-free overlap-save above with its
+ * independent blocks spread over `threads` OpenMP threads, and a radix-2 transform whose butterflies of one
+ * stage are spread likewise.  The reference runs both on one thread unless the vector's MultiCoreSettings say
+ * otherwise (threading.rs:210-231: `parallel()` = half the logical cores for Large operations); this is what
+ * "all host cores" can do with the same algorithm.  Same arithmetic as the single-threaded functions.
+ * ---------------------------------------------------------------------------------------- */
+void SFX(orc_fft_pow2_mt)(REAL *data, size_t points, int inverse, int threads)
+{
+    SFX(cpx) *x = (SFX(cpx) *)data;
+    size_t n = points;
+    if (n < 2 || (n & (n - 1)) != 0) return;
+    if (threads < 1) threads = 1;
+    for (size_t i = 1, j = 0; i < n; ++i) {
+        size_t bit = n >> 1;
+        for (; j & bit; bit >>= 1) j ^= bit;
+        j ^= bit;
+        if (i < j) { SFX(cpx) t = x[i]; x[i] = x[j]; x[j] = t; }
+    }
+    SFX(cpx) *w = (SFX(cpx) *)malloc(sizeof(SFX(cpx)) * (n / 2));
+#pragma omp parallel for num_threads(threads) schedule(static)
+    for (long long k = 0; k < (long long)(n / 2); ++k) {
+        double a = (inverse ? 2.0 : -2.0) * M_PI * (double)k / (double)n;
+        w[k].re = (REAL)cos(a);
+        w[k].im = (REAL)sin(a);
+    }
+    for (size_t len = 2; len <= n; len <<= 1) {
+        size_t half = len >> 1, stride = n / len;
+#pragma omp parallel for num_threads(threads) schedule(static)
+        for (long long j = 0; j < (long long)(n / 2); ++j) {
+            size_t i = ((size_t)j / half) * len, k = (size_t)j % half;
+            SFX(cpx) u = x[i + k];
+            SFX(cpx) v = SFX(cmul)(x[i + k + half], w[k * stride]);
+            x[i + k].re = u.re + v.re;
+            x[i + k].im = u.im + v.im;
+            x[i + k + half].re = u.re - v.re;
+            x[i + k + half].im = u.im - v.im;
+        }
+    }
+    free(w);
+}
+
+int SFX(orc_overlap_save_mt)(REAL *x, size_t len, const REAL *h, size_t hlen, size_t fft_len_arg, int threads)
+{
+    size_t x_len = len / 2, imp_len = hlen / 2;
+    if (imp_len == 0 || x_len == 0) return 7;
+    if (threads < 1) threads = 1;
+    size_t overlap = imp_len - 1;
+    size_t min_fft_len = SFX(orc_next_power_of_two)(4 * overlap);
+    size_t fft_len = fft_len_arg > min_fft_len ? fft_len_arg : min_fft_len;
+    if (fft_len < 2) fft_len = 2;
+    size_t step = fft_len - overlap;
+    SFX(cpx) *sig = (SFX(cpx) *)x;
+    SFX(cpx) *H = (SFX(cpx) *)calloc(fft_len, sizeof(SFX(cpx)));
+    memcpy(H, h, imp_len * sizeof(SFX(cpx)));
+    SFX(orc_fft)((REAL *)H, fft_len, 0);
+    REAL scaling = (REAL)fft_len;
+    SFX(cpx) *src = (SFX(cpx) *)malloc(x_len * sizeof(SFX(cpx)));
+    memcpy(src, sig, x_len * sizeof(SFX(cpx)));
+    long long back = (long long)(imp_len / 2);
+    long long nblocks = (long long)((x_len + step - 1) / step);
+#pragma omp parallel num_threads(threads)
+    {
+        SFX(cpx) *blk = (SFX(cpx) *)malloc(fft_len * sizeof(SFX(cpx)));
+#pragma omp for schedule(dynamic, 4)
+        for (long long b = 0; b < nblocks; ++b) {
+            size_t o = (size_t)b * step;
+            for (size_t n = 0; n < fft_len; ++n)
+                blk[n] = src[SFX(wrap)((long long)o - back + (long long)n, x_len)];
+            SFX(orc_fft)((REAL *)blk, fft_len, 0);
+            for (size_t n = 0; n < fft_len; ++n) {
+                SFX(cpx) p = SFX(cmul)(blk[n], H[n]);
+                blk[n].re = p.re / scaling;
+                blk[n].im = p.im / scaling;
+            }
+            SFX(orc_fft)((REAL *)blk, fft_len, 1);
+            for (size_t m = 0; m < step && o + m < x_len; ++m) sig[o + m] = blk[m + overlap];
+        }
+        free(blk);
+    }
+    free(src); free(H);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------
  * a9: convolve_signal dispatcher (time_freq/convolution.rs:464-543).  Every branch computes the
  * same a9 sum; what differs is the schedule (and therefore rounding).  has_gpu = 0 here (this is
  * the CPU path).  `out` receives the result (len scalars).

@@ -210,6 +210,23 @@ def overlap_discard(x, h, fft_len=0, fair=False):
     return code, y
 
 
+def overlap_save_mt(x, h, fft_len=0, threads=1):
+    """Tail-free overlap-save with the blocks spread over `threads` OpenMP threads (bench.py's CPU baseline)."""
+    y = np.array(x, copy=True); h = np.ascontiguousarray(h, dtype=y.dtype)
+    fn = _fn("orc_overlap_save_mt", y.dtype)
+    fn.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int]
+    fn.restype = C.c_int
+    code = fn(_p(y), y.size, _p(h), h.size, fft_len, int(threads))
+    return code, y
+
+
+def fft_pow2_mt(x, inverse=False, threads=1):
+    """Power-of-two transform with each stage's butterflies spread over `threads` OpenMP threads."""
+    y = np.array(x, copy=True); fn = _fn("orc_fft_pow2_mt", y.dtype)
+    fn.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int]; fn.restype = None
+    fn(_p(y), y.size // 2, int(inverse), int(threads)); return y
+
+
 def convolve_signal(x, h, is_complex):
     x = np.ascontiguousarray(x); h = np.ascontiguousarray(h, dtype=x.dtype)
     out = np.zeros_like(x); path = C.c_int(0); fn = _fn("orc_convolve_signal", x.dtype)

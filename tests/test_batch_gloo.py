@@ -71,6 +71,47 @@ def test_scatter_process_gather_gloo(tmp_path, world, nvec):
     assert float(open(result).read()) == 0.0
 
 
+def _worker_chunked(rank, world, port, nvec, points, m, chunk, result_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from basic_dsp_amd.batch import scatter_process_gather_chunked, shard_bounds
+    import oracle_lib as orc
+    batch = taps = None
+    if rank == 0:
+        batch = torch.from_numpy(np.stack([orc.fill_uniform(2 * points, 201511212 + v, -10, 10, np.float64)
+                                           for v in range(nvec)]))
+        taps = torch.from_numpy(orc.fill_uniform(2 * m, 201601172, -1, 1, np.float64))
+    seen = []
+
+    def process(shard, t, p):
+        seen.append(shard.shape[0])
+        return _oracle_process(shard, t, p)
+
+    out = scatter_process_gather_chunked(batch, taps, points, process, chunk_vectors=chunk, device=torch.device("cpu"))
+    f, l = shard_bounds(nvec, world, rank)
+    # every vector of the shard went through the compute step exactly once, in chunks of at most `chunk`
+    assert sum(seen) == l - f and all(0 < c <= chunk for c in seen)
+    assert len(seen) == -(-(l - f) // chunk)
+    if rank == 0:
+        ref = _oracle_process(batch, taps, points)
+        err = float((out - ref).abs().max())
+        with open(result_path, "w") as fh:
+            fh.write("%g" % err)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,nvec,chunk", [(2, 8, 2), (2, 8, 3), (3, 7, 1), (2, 1, 4), (3, 20, 4)])
+def test_scatter_process_gather_chunked_gloo(tmp_path, world, nvec, chunk):
+    """The pipelined scatter / compute / gather (chunk k+1 in flight while chunk k is transformed, results two
+    rounds behind): bit-identical to transforming the whole batch on rank 0."""
+    port = _free_port()
+    result = str(tmp_path / "err.txt")
+    mp.spawn(_worker_chunked, args=(world, port, nvec, 300, 9, chunk, result), nprocs=world, join=True)
+    assert float(open(result).read()) == 0.0
+
+
 def test_shard_bounds_contiguous_cover():
     from basic_dsp_amd.batch import shard_bounds
     for nvec in (1, 7, 64, 512, 513):

@@ -164,9 +164,18 @@ def test_zero_pad_interleave_mirror():
 
 
 # ------------------------------------------------------------------ windows
+def _ulp_of_10(dtype):
+    return float(np.spacing(np.asarray(10.0, dtype=dtype)))
+
+
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 @pytest.mark.parametrize("wid", [0, 1, 2, 3, 4])
 def test_windows(wid, dtype):
+    # window_functions.rs:26-132 applied by time.rs:32-66; inputs are in [-10, 10).  Triangular, Hamming and Hann
+    # are held to 4 ulp of 10 (same formula in T; libm and device cos differ by an ulp or two of the value).  The
+    # four-term Blackman-Harris sum cancels to 6e-5 at its ends, where an ulp of the cosines is 1e-3 of the window
+    # value: 30 ulp of 10 there.
+    ulps = 30 if wid == 2 else 4
     for cplx, points in ((True, 1000), (False, 1001), (True, 65537)):
         e = 2 if cplx else 1
         x = orc.fill_uniform(points * e, 17, -10, 10, dtype)
@@ -174,9 +183,18 @@ def test_windows(wid, dtype):
         v = DspVec(x, is_complex=cplx)
         assert v.apply_window(wid) == 0
         ref = orc.apply_window(x, cplx, oid, alpha)
-        # same formula in T, libm vs device cos differ by a few ulp of the angle
-        np.testing.assert_allclose(v.data(), ref, rtol=0, atol=(3e-6 if dtype == np.float32 else 1e-13) * 10)
-        assert v.unapply_window(wid) == 0 or True
+        np.testing.assert_allclose(v.data(), ref, rtol=0, atol=ulps * _ulp_of_10(dtype))
+        # unapply_window divides by the same window (time.rs:50-66): against the oracle's division of the
+        # oracle's product, and back to the input wherever the window is not tiny
+        assert v.unapply_window(wid) == 0
+        back = orc.apply_window(ref, cplx, oid, alpha, unapply=True)
+        w = orc.apply_window(np.ones_like(x), cplx, oid, alpha).astype(np.float64)
+        ok = np.abs(w) > 1e-2
+        assert ok.sum() > 0.7 * ok.size  # (Blackman-Harris is below 1e-2 over its outer 10 % on either side)
+        got = v.data().astype(np.float64)
+        np.testing.assert_allclose(got[ok], back.astype(np.float64)[ok], rtol=0,
+                                   atol=4 * ulps * _ulp_of_10(dtype) / 1e-2)
+        assert rel_l2(got[ok], x.astype(np.float64)[ok]) < (3e-6 if dtype == np.float32 else 1e-14)
 
 
 # ------------------------------------------------------------------ FFT
@@ -261,7 +279,7 @@ def test_fft_ifft_with_fused_shift_window_scale(n, dtype):
     assert rel_l2(v.data(), ref) < 2 * tol_for(dtype)
     v = DspVec(x, is_complex=True)
     assert v.windowed_fft(V.WINDOW_HAMMING) == 0 and v.windowed_ifft(V.WINDOW_HAMMING) == 0
-    assert rel_l2(v.data(), xd) < 2e-5 if dtype == np.float32 else 1e-10
+    assert rel_l2(v.data(), xd) < (2e-5 if dtype == np.float32 else 1e-10)
 
 
 def test_fft_type_state_errors():
@@ -426,7 +444,7 @@ def test_b3_device_pointer_api():
     x = orc.fill_uniform(2 * n, 77, -10, 10, np.float32)
     d = torch.from_numpy(x).cuda()
     s = torch.empty_like(d)
-    sp = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    sp = bd._lib.torch_stream_arg()
     flag = C.c_int(0)
     assert lib.bdsp_hip_dev_fft(0, d.data_ptr(), s.data_ptr(), n, 1, bd._lib.FFT_SHIFT_OUT | bd._lib.FFT_MAGNITUDE,
                                 1.0, -1, 0.0, C.byref(flag), sp) == 0
@@ -511,6 +529,57 @@ def test_symmetric_fft_family(dtype):
     assert DspVec(np.zeros(10, dtype), is_complex=True).plain_sifft() == 6  # must be frequency domain
     bad = DspVec(np.array([1.0, 0.5, 2.0, 0.0], dtype), is_complex=True, domain=V.FREQ)
     assert bad.plain_sifft() == 8                                            # first bin must be real
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("n", [9, 1001, 4097, 65537])
+def test_shifted_and_windowed_symmetric_transforms_against_oracle(n, dtype):
+    # sfft / windowed_sfft (time_to_freq.rs:232-298): zero-interleave -> [window] -> fft (= plain_fft + fft_shift)
+    # -> keep the first n/2+1 bins of the SHIFTED spectrum (unmirror!, :178-186).
+    # sifft / windowed_sifft (freq_to_time.rs:226-247): scale(1/points) and ifft_shift of the HALF spectrum ->
+    # plain_sifft (mirror -> inverse transform -> real part) -> [unapply_window].  The oracle side is composed
+    # from its pinned fft / swap_halves / apply_window / mirror restatements.
+    tol = 1e-6 if dtype == np.float32 else 1e-12
+    x = orc.fill_uniform(n, 201511213 + n, -10, 10, dtype)
+    xd = x.astype(np.float64)
+    p = n // 2 + 1
+    cplx = orc.zero_interleave(xd, False, 2)
+
+    v = DspVec(x)
+    assert v.sfft() == 0 and v.is_complex() and v.domain() == V.FREQ and v.points() == p
+    ref = orc.swap_halves(orc.fft(cplx), True, True)[:2 * p]
+    assert rel_l2(v.data(), ref) < 2 * tol
+
+    for wid, oid, alpha in ((V.WINDOW_HAMMING, 1, 0.54), (V.WINDOW_HANN, 1, 0.5), (V.WINDOW_TRIANGULAR, 0, 0.0),
+                            (V.WINDOW_BLACKMAN_HARRIS, 2, 0.0)):
+        v = DspVec(x)
+        assert v.windowed_sfft(wid) == 0 and v.points() == p
+        ref = orc.swap_halves(orc.fft(orc.apply_window(cplx, True, oid, alpha)), True, True)[:2 * p]
+        assert rel_l2(v.data(), ref) < 2 * tol, wid
+
+    # a half spectrum whose first bin AFTER ifft_shift is real (index p/2 before it)
+    h = orc.fill_uniform(2 * p, 77 + n, -10, 10, dtype)
+    h[2 * (p // 2) + 1] = 0
+    hd = h.astype(np.float64)
+
+    def oracle_sifft(hd):
+        y = orc.complex_scale(hd, 1.0 / p, 0.0)
+        y = orc.swap_halves(y, True, False)
+        return orc.fft(orc.mirror(y), inverse=True)[0::2]
+
+    v = DspVec(h, is_complex=True, domain=V.FREQ)
+    assert v.sifft() == 0 and not v.is_complex() and v.domain() == V.TIME and len(v) == n
+    assert rel_l2(v.data(), oracle_sifft(hd)) < 2 * tol
+
+    v = DspVec(h, is_complex=True, domain=V.FREQ)
+    assert v.windowed_sifft(V.WINDOW_HAMMING) == 0 and len(v) == n
+    ref = orc.apply_window(oracle_sifft(hd), False, 1, 0.54, unapply=True)
+    assert rel_l2(v.data(), ref) < 4 * tol
+
+    # an imaginary first bin after the shift is rejected as in plain_sifft (freq_to_time.rs:203-211)
+    bad = h.copy()
+    bad[2 * (p // 2) + 1] = 1.0
+    assert DspVec(bad, is_complex=True, domain=V.FREQ).sifft() == 8
 
 
 # ------------------------------------------------------------------ correlate, convolve(function), real interpolation
@@ -629,6 +698,11 @@ def test_smaller_vector_ops_custom_windows_misc(dtype):
     a, b = DspVec(r), DspVec(r)
     assert a.windowed_custom_sfft(ham) == 0 and b.windowed_sfft(V.WINDOW_HAMMING) == 0
     assert rel_l2(a.data(), b.data()) < (2e-6 if dtype == np.float32 else 1e-12)
+    # ... and both equal the oracle's zero-interleave -> window -> fft -> fft_shift -> first n/2+1 bins
+    rc = orc.zero_interleave(r.astype(np.float64), False, 2)
+    ref = orc.swap_halves(orc.fft(orc.apply_window(rc, True, 1, 0.54)), True, True)[:2 * (1001 // 2 + 1)]
+    assert rel_l2(a.data(), ref) < (2e-6 if dtype == np.float32 else 1e-12)
+    assert rel_l2(b.data(), ref) < (2e-6 if dtype == np.float32 else 1e-12)
     # callback frequency response equals the built-in raised cosine
     xs = orc.fill_uniform(2 * 1000, 3, -1, 1, dtype)
     rc = lambda t: float(orc.conv_freq(1, 0.35, t, np.float64))  # noqa: E731

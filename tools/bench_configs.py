@@ -9,7 +9,7 @@ import basic_dsp_amd as bd
 from basic_dsp_amd._lib import FFT_SHIFT_OUT, FFT_MAGNITUDE
 lib = bd.lib
 dev = torch.device("cuda", 0)
-sp = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+sp = bd._lib.torch_stream_arg()
 flag = C.c_int(0)
 PEAK = 8000.0
 

@@ -8,7 +8,7 @@ dev = torch.device("cuda", 0)
 x = torch.rand(2 * n, device=dev) * 20 - 10
 y = torch.empty(2 * n, device=dev)
 z = torch.empty(n, device=dev)
-sp = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+sp = bd._lib.torch_stream_arg()
 flag = C.c_int(0)
 for _ in range(10):
     bd._lib.check(lib.bdsp_hip_dev_fft(0, x.data_ptr(), y.data_ptr(), n, 1, bd._lib.FFT_MAGNITUDE, 1.0, -1, 0.0, C.byref(flag), sp))

@@ -10,7 +10,7 @@ x = torch.rand(2 * n, device=dev) * 20 - 10
 y = torch.empty(2 * n, device=dev)
 taps = (torch.rand(2 * m, device=dev) * 2 - 1) / m
 spec = torch.empty(2 * 4096, device=dev)
-sp = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+sp = bd._lib.torch_stream_arg()
 lib.bdsp_hip_dev_conv_prepare(0, taps.data_ptr(), m, spec.data_ptr(), sp)
 for _ in range(3):
     lib.bdsp_hip_dev_convolve_prepared(0, x.data_ptr(), y.data_ptr(), n, 1, spec.data_ptr(), m, sp)

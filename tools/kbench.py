@@ -12,15 +12,16 @@ ap.add_argument("--batch", type=int, default=1)
 ap.add_argument("--iters", type=int, default=20)
 ap.add_argument("--elem", type=int, default=0)
 ap.add_argument("--what", default="conv,fft")
+ap.add_argument("--zero", action="store_true", help="all-zero input (shows how much of a difference is the clock the data draws)")
 a = ap.parse_args()
 n, m, b = a.points, a.taps, a.batch
 dt = torch.float32 if a.elem == 0 else torch.float64
 dev = torch.device("cuda", 0)
-xs = [torch.rand(2 * n * b, device=dev, dtype=dt) * 20 - 10 for _ in range(3)]
+xs = [(torch.zeros(2 * n * b, device=dev, dtype=dt) if a.zero else torch.rand(2 * n * b, device=dev, dtype=dt) * 20 - 10) for _ in range(3)]
 taps = (torch.rand(2 * m, device=dev, dtype=dt) * 2 - 1) / m
 y = torch.empty(2 * n * b, device=dev, dtype=dt)
 spec = torch.empty(2 * lib.bdsp_hip_conv_spectrum_points(), device=dev, dtype=dt)
-sp = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+sp = bd._lib.torch_stream_arg()
 flag = C.c_int(0)
 def timeit(fn):
     # untimed pre-warm: the clock needs tens of milliseconds of load to settle (see bench.py)
@@ -60,6 +61,9 @@ if "convfft" in a.what:
 if "fft" in a.what.split(","):
     us = timeit(lambda i: bd._lib.check(lib.bdsp_hip_dev_fft(a.elem, xs[i % 3].data_ptr(), y.data_ptr(), n, b, 0, 1.0, -1, 0.0, C.byref(flag), sp)))
     print("fft   n=%d b=%d: %.1f us  %.1f Gsamples/s  %.0f GB/s algorithmic" % (n, b, us, n * b / us / 1e3, 2 * esz * n * b / us / 1e3))
+if "tapsconv" in a.what.split(","):
+    us = timeit(lambda i: bd._lib.check(lib.bdsp_hip_dev_convolve(a.elem, xs[i % 3].data_ptr(), y.data_ptr(), n, b, taps.data_ptr(), m, sp)))
+    print("conv (taps transformed in the kernel) n=%d b=%d m=%d: %.1f us" % (n, b, m, us))
 if "prep" in a.what.split(","):
     us = timeit(lambda i: bd._lib.check(lib.bdsp_hip_dev_conv_prepare(a.elem, taps.data_ptr(), m, spec.data_ptr(), sp)))
     print("prep  m=%d: %.1f us" % (m, us))

@@ -1,0 +1,921 @@
+// conv_lab -- a standalone bench + checker for variants of the fused overlap-save block kernel (complex f32,
+// 16M points, 1024 taps by default).  Every variant is checked against a double-precision direct convolution at
+// a few hundred output positions (both wrap-around ends, block seams, random interior) and timed with HIP
+// events on random data after a clock warm-up, rotating three input buffers.
+//
+//   make -C tools/lab && tools/lab/conv_lab [points] [taps]
+//
+// Variants (see the kernels below):
+//   base     the shipped kernel's structure: Stockham 16x16x16, 8 barriers per block, split stage-3 twiddles,
+//            stage-2 twiddles in an LDS table, predicated stores
+//   base+as  the same with ALIGNED stores: the taps are delayed by round_up(M-1,16)-(M-1) samples so that the valid
+//            outputs of a block start at a multiple of 16 points; whole rows are stored without a predicate
+//   dif      decimation-in-frequency forward / decimation-in-time inverse: no autosort, the spectrum stays in
+//            digit-reversed order (H is stored to match), the exchange between the second and third stage only
+//            moves data between lanes of ONE wavefront (no barrier), all twiddles in registers; 4 barriers per block,
+//            2 workgroups per CU
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cmath>
+#include <complex>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <random>
+#include <string>
+#include <type_traits>
+#include <vector>
+#include "fft_core.h"
+using namespace bdsp;
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(e_)); exit(1); } } while (0)
+
+constexpr int L = 4096;
+using C = cpx<float>;
+
+struct Args {
+    const C* x; C* y; const C* hs; const C* wtab;
+    unsigned n; int ov;  // z[ov] is the first valid output of a block (>= taps-1; the taps are delayed to match)
+    unsigned V;          // block step: block b yields outputs [bV, bV+V) from z[ov .. ov+V)
+    long long in_off;    // block b reads x[(b*V + in_off + i) mod n]
+    unsigned blocks;
+    unsigned* q;             // dynamic block queues: 8 counters 128 bytes apart + a done counter, zero between launches
+    unsigned long long* clk; // [4]: s_memtime and s_memrealtime at the start and end of workgroup 0
+};
+
+// ------------------------------------------------------------------------------------------- shared pieces
+__device__ __forceinline__ void load_block(const Args& a, unsigned b, unsigned V, unsigned ut, C (&d)[16])
+{
+    long long base = (long long)b * V + a.in_off;
+    if (base >= 0 && base + L <= (long long)a.n) {
+        const C* xb = a.x + base;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) d[r] = xb[ut + 256u * r];
+    } else {
+        long long sb = base % (long long)a.n;
+        if (sb < 0) sb += a.n;
+        const unsigned idx = (unsigned)sb + ut;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            unsigned i = idx + 256u * r;
+            if (i >= a.n) i -= a.n;
+            d[r] = a.x[i];
+        }
+    }
+}
+
+template <bool ALIGNED>
+__device__ __forceinline__ void store_block(const Args& a, unsigned b, unsigned V, unsigned ut, const C (&v)[16])
+{
+    const unsigned ov = (unsigned)a.ov;
+    const long long obase = (long long)b * V - ov; // output index of z[0]
+    if (ALIGNED && (ov & 255u) == 0 && (long long)b * V + V <= (long long)a.n) {
+        // whole rows, no predicate: rows r0 .. 15 are the valid ones (uniform)
+        C* yb = a.y + obase;
+        const unsigned r0 = ov >> 8;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            if ((unsigned)r >= r0) yb[ut + 256u * r] = v[r];
+        return;
+    }
+    long long room = (long long)a.n - obase;
+    unsigned lim = room <= 0 ? 0u : (room > L ? (unsigned)L : (unsigned)room);
+    if (lim > ov + V) lim = ov + V;
+    C* yb = a.y + obase;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        unsigned np = ut + 256u * r;
+        if (np >= ov && np < lim) yb[np] = v[r];
+    }
+}
+
+__device__ __forceinline__ unsigned xcd_contiguous(unsigned bid, unsigned g)
+{
+    return (g & 7) == 0 ? (bid & 7) * (g >> 3) + (bid >> 3) : bid;
+}
+
+// ------------------------------------------------------------------------------------------- base
+template <bool ALIGNED>
+__global__ __launch_bounds__(256, 3) void k_base(Args a)
+{
+    using F = WgFft<float, L, 256>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    C* lds = reinterpret_cast<C*>(smem_raw);
+    const int t = threadIdx.x;
+    const unsigned ut = t;
+#ifdef LAB_PROBE
+    unsigned long long clk_t0 = 0, clk_r0 = 0;
+    if (threadIdx.x == 0 && a.clk) { clk_t0 = __builtin_amdgcn_s_memtime(); clk_r0 = __builtin_amdgcn_s_memrealtime(); }
+#endif
+    const unsigned V = a.V;
+    const float hscale = 1.0f / L;
+    auto tw = [&](int mm) { return a.wtab[mm]; };
+    C tw3a[3], tw3b[3], hreg[16];
+    C* tw2l = lds + F::LDS_ELEMS;
+    F::template load_twiddles16_split<256>(tw3a, tw3b, t, tw);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        C hv = a.hs[ut + 256u * r];
+        hreg[r] = C{hv.x * hscale, hv.y * hscale};
+    }
+    if (t < 240) {
+        int k = t / 15, r = t % 15 + 1;
+        tw2l[k * 17 + r - 1] = a.wtab[r * k * 16];
+    }
+    __syncthreads();
+    const C* tw2p = tw2l + (t & 15) * 17;
+    const unsigned G = gridDim.x, wl = xcd_contiguous(blockIdx.x, G);
+    for (unsigned b = wl; b < a.blocks; b += G) {
+        C v[16];
+        load_block(a, b, V, ut, v);
+        F::template compute<16, 1, -1>(v, t, tw);
+        __syncthreads();
+        F::scatter_a(v, t, lds);
+        __syncthreads();
+        F::gather_a(v, t, lds);
+        F::template compute_pre<16, 16, -1>(v, tw2p);
+        __syncthreads();
+        F::scatter_b(v, t, lds);
+        __syncthreads();
+        F::gather_b(v, t, lds);
+        F::template compute_pre16_split<256, -1>(v, tw3a, tw3b);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = cmul(v[r], hreg[r]);
+        F::template compute<16, 1, 1>(v, t, tw);
+        __syncthreads();
+        F::scatter_a(v, t, lds);
+        __syncthreads();
+        F::gather_a(v, t, lds);
+        F::template compute_pre<16, 16, 1>(v, tw2p);
+        __syncthreads();
+        F::scatter_b(v, t, lds);
+        __syncthreads();
+        F::gather_b(v, t, lds);
+        F::template compute_pre16_split<256, 1>(v, tw3a, tw3b);
+        store_block<ALIGNED>(a, b, V, ut, v);
+    }
+#ifdef LAB_PROBE
+    if (threadIdx.x == 0 && a.clk) {
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        unsigned long long* q = a.clk + 4 * blockIdx.x;
+        q[0] = clk_r0;
+        q[1] = __builtin_amdgcn_s_memrealtime();
+        q[2] = __builtin_amdgcn_s_memtime() - clk_t0;
+        q[3] = xcc & 7;
+    }
+#endif
+}
+
+// ------------------------------------------------------------------------------------------- dif
+// Index bits of the block-local time index i = 256 i2 + 16 i1 + i0 and of the frequency k = k0 + 16 k1 + 256 k2.
+//   load      thread t = 16 i1 + i0, register i2
+//   DFT16 over i2 -> k0;  x w4096^((16 i1 + i0) k0)              (15 per-thread twiddles, registers)
+//   CROSS exchange: register <-> thread bits 4..7:  thread 16 k0 + i0, register i1         (barriers)
+//   DFT16 over i1 -> k1;  x w256^(i0 k1)                          (15 per-thread twiddles, registers)
+//   WAVE-PRIVATE exchange: register <-> lane bits 0..3: thread 16 k0 + k1, register i0     (no barrier)
+//   DFT16 over i0 -> k2:  thread 16 k0 + k1 holds X[k0 + 16 k1 + 256 r] in register r
+// and the inverse runs the same steps backwards with conjugated twiddles.
+// LDS layouts (elements of 8 bytes; all conflict-free for ds_write_b64 16-lane groups / ds_read_b64 32-lane groups):
+//   cross:   A(i1, i0, k0) = i0 + 16 k0 + 272 i1            (one pad row of 16 per 256)
+//   private: P(g, a, r)    = 272 g + 17 r + a  per wave, g = lane >> 4, a = lane & 15, region of 1088 elements
+constexpr int CROSS_ELEMS = 16 * 272, PRIV_ELEMS = 4 * 272;
+
+template <int DIR>
+__device__ __forceinline__ void tw_apply(C (&v)[16], const C (&tw)[15])
+{
+#pragma unroll
+    for (int r = 1; r < 16; ++r) v[r] = twmul<DIR>(v[r], tw[r - 1]);
+}
+
+template <bool ALIGNED, int WPC>
+__global__ __launch_bounds__(256, WPC) void k_dif(Args a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    C* cross = reinterpret_cast<C*>(smem_raw);
+    const int t = threadIdx.x;
+    const unsigned ut = t;
+    const int lane = t & 63, wave = t >> 6;
+    C* priv = cross + CROSS_ELEMS + wave * PRIV_ELEMS;
+    const unsigned V = a.V;
+    const float hscale = 1.0f / L;
+    // twiddles: tw1[k0-1] = w4096^(t k0), tw2[k1-1] = w256^((t & 15) k1)
+    C tw1[15], tw2[15], hreg[16];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) {
+        tw1[r - 1] = a.wtab[(t * r) & (L - 1)];
+        tw2[r - 1] = a.wtab[(16 * (t & 15) * r) & (L - 1)];
+    }
+    {
+        // after the forward transform thread t'' = 16 k0 + k1 holds X[k0 + 16 k1 + 256 r]
+        const unsigned k0 = ut >> 4, k1 = ut & 15;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            C hv = a.hs[k0 + 16u * k1 + 256u * r];
+            hreg[r] = C{hv.x * hscale, hv.y * hscale};
+        }
+    }
+    // exchange addressing, base(thread) + constant(register)
+    C* const cw = cross + (t & 15) + 272 * (t >> 4);       // writer (i1 = t>>4, i0 = t&15), + 16 r   (r = k0)
+    const C* const cr = cross + (t & 15) + 16 * (t >> 4);  // reader (k0 = t>>4, i0 = t&15), + 272 r  (r = i1)
+    C* const pw = priv + 272 * (lane >> 4) + (lane & 15);        // + 17 r
+    const C* const pr = priv + 272 * (lane >> 4) + 17 * (lane & 15); // + r
+    const unsigned G = gridDim.x, wl = xcd_contiguous(blockIdx.x, G);
+    for (unsigned b = wl; b < a.blocks; b += G) {
+        C v[16];
+        load_block(a, b, V, ut, v);
+        // ---------------- forward, decimation in frequency
+        dft16<-1>(v);
+        tw_apply<-1>(v, tw1);
+        __syncthreads(); // the previous block's inverse cross gather is done
+#pragma unroll
+        for (int r = 0; r < 16; ++r) cw[16 * r] = v[r];
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = cr[272 * r];
+        dft16<-1>(v);
+        tw_apply<-1>(v, tw2);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) pw[17 * r] = v[r];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = pr[r];
+        dft16<-1>(v);
+        // ---------------- spectrum product
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = cmul(v[r], hreg[r]);
+        // ---------------- inverse, decimation in time
+        dft16<1>(v);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) pw[17 * r] = v[r];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = pr[r];
+        tw_apply<1>(v, tw2);
+        dft16<1>(v);
+        __syncthreads(); // everybody has finished the forward cross gather
+        // inverse cross: writer is thread (k0 = t>>4, i0), register i1 -> same cell A(i1, i0, k0)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) const_cast<C*>(cr)[272 * r] = v[r];
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = cw[16 * r];
+        tw_apply<1>(v, tw1);
+        dft16<1>(v);
+        store_block<ALIGNED>(a, b, V, ut, v);
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------- ub
+// The structure of tools/ubench/mem_interference.hip's "shipped shape" (NOT a correct convolution: every stage
+// multiplies by 15 register twiddles, loads are clamped instead of wrapped, rows 4..15 are stored unconditionally).
+// MODE bit 0: real wrap-around load_block; bit 1: real predicated store_block; bit 2: stage-2 twiddles from the LDS
+// table; bit 3: split stage-3 twiddles; bit 4: no twiddles in the first stage
+template <int MODE>
+__global__ __launch_bounds__(256, 3) void k_ub(Args a)
+{
+    using F = WgFft<float, L, 256>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    C* lds = reinterpret_cast<C*>(smem_raw);
+    const int t = threadIdx.x;
+    const unsigned ut = t;
+    const unsigned V = a.V;
+    const float hscale = 1.0f / L;
+    auto tww = [&](int mm) { return a.wtab[mm]; };
+    C tw[15], hreg[16], tw3a[3], tw3b[3];
+#pragma unroll
+    for (int r = 0; r < 15; ++r) tw[r] = a.wtab[(t * (r + 1)) & (L - 1)];
+    F::template load_twiddles16_split<256>(tw3a, tw3b, t, tww);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        C hv = a.hs[ut + 256u * r];
+        hreg[r] = C{hv.x * hscale, hv.y * hscale};
+    }
+    C* tw2l = lds + F::LDS_ELEMS;
+    if (t < 240) {
+        int k = t / 15, r = t % 15 + 1;
+        tw2l[k * 17 + r - 1] = a.wtab[r * k * 16];
+    }
+    __syncthreads();
+    const C* tw2p = tw2l + (t & 15) * 17;
+    const unsigned G = gridDim.x, wl = xcd_contiguous(blockIdx.x, G);
+    for (unsigned b = wl; b < a.blocks; b += G) {
+        C v[16];
+        if (MODE & 1) load_block(a, b, V, ut, v);
+        else {
+            long long base = (long long)b * V + a.in_off;
+            if (base < 0) base = 0;
+            if (base + L > (long long)a.n) base = (long long)a.n - L;
+            const C* xb = a.x + base;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = xb[ut + 256u * r];
+        }
+#pragma unroll
+        for (int dir = 0; dir < 2; ++dir) {
+            auto s1 = [&](auto D) { if (MODE & 16) F::template compute<16, 1, decltype(D)::value>(v, t, tww); else F::template compute_pre<16, 256, decltype(D)::value>(v, tw); };
+            auto s2 = [&](auto D) { if (MODE & 4) F::template compute_pre<16, 16, decltype(D)::value>(v, tw2p); else F::template compute_pre<16, 256, decltype(D)::value>(v, tw); };
+            auto s3 = [&](auto D) { if (MODE & 8) F::template compute_pre16_split<256, decltype(D)::value>(v, tw3a, tw3b); else F::template compute_pre<16, 256, decltype(D)::value>(v, tw); };
+            auto run = [&](auto D) {
+                s1(D);
+                __syncthreads();
+                F::scatter_a(v, t, lds);
+                __syncthreads();
+                F::gather_a(v, t, lds);
+                s2(D);
+                __syncthreads();
+                F::scatter_b(v, t, lds);
+                __syncthreads();
+                F::gather_b(v, t, lds);
+                s3(D);
+            };
+            if (dir == 0) {
+                run(std::integral_constant<int, -1>{});
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] = cmul(v[r], hreg[r]);
+            } else run(std::integral_constant<int, 1>{});
+        }
+        if (MODE & 2) store_block<false>(a, b, V, ut, v);
+        else {
+            long long ob = (long long)b * V - a.ov;
+            if (ob + L > (long long)a.n) ob = (long long)a.n - L;
+            if (ob < 0) ob = 0;
+            C* yb = a.y + ob;
+#pragma unroll
+            for (int r = 4; r < 16; ++r) yb[ut + 256u * r] = v[r];
+        }
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------- v2
+// One block loop without merge points: interior blocks only (plain contiguous loads, rows R0..15 stored whole, no
+// predicate; the taps are delayed so that z[256 R0] is a block's first valid output); the few blocks whose window
+// wraps around the end of the vector are taken FIRST, by the first workgroups, through the general load/store code.
+//   CORE 0: Stockham 16x16x16 (8 barriers), CORE 1: DIF/DIT with the wave-private exchange (4 barriers)
+//   TWR bit 0: stage-2 twiddles in registers (else LDS table), bit 1: all 15 stage-3 twiddles in registers (else split)
+//   DBUF: two register sets take turns, so the next block's loads never wait for this block's stores to retire
+template <int CORE, int R0, int TWR, int DBUF, int WPC>
+__global__ __launch_bounds__(256, WPC) void k_v2(Args a, unsigned nb_lo, unsigned nb_hi)
+{
+    using F = WgFft<float, L, 256>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    C* lds = reinterpret_cast<C*>(smem_raw);
+    const int t = threadIdx.x;
+    const unsigned ut = t;
+    const int lane = t & 63, wave = t >> 6;
+#ifdef LAB_PROBE
+    unsigned long long clk_t0 = 0, clk_r0 = 0;
+    if (threadIdx.x == 0 && a.clk) { clk_t0 = __builtin_amdgcn_s_memtime(); clk_r0 = __builtin_amdgcn_s_memrealtime(); }
+#endif
+    const unsigned V = a.V;
+    const float hscale = 1.0f / L;
+    auto tww = [&](int mm) { return a.wtab[mm]; };
+    C hreg[16];
+    // Stockham twiddles
+    C tw2r[(CORE == 0 && (TWR & 1)) ? 15 : 1], tw3r[(CORE == 0 && (TWR & 2)) ? 15 : 1], tw3a[3], tw3b[3];
+    C* tw2l = lds + F::LDS_ELEMS;
+    const C* tw2p = tw2l + (t & 15) * 17;
+    // DIF twiddles
+    C tw1[CORE == 1 ? 15 : 1], tw2[CORE == 1 ? 15 : 1];
+    C* const cross = lds;
+    C* const priv = cross + CROSS_ELEMS + wave * PRIV_ELEMS;
+    C* const cw = cross + (t & 15) + 272 * (t >> 4);
+    C* const cr = cross + (t & 15) + 16 * (t >> 4);
+    C* const pw = priv + 272 * (lane >> 4) + (lane & 15);
+    const C* const pr = priv + 272 * (lane >> 4) + 17 * (lane & 15);
+    if constexpr (CORE == 0) {
+        if constexpr (TWR & 1) {
+#pragma unroll
+            for (int r = 1; r < 16; ++r) tw2r[r - 1] = a.wtab[16 * r * (t & 15)];
+        } else {
+            if (t < 240) {
+                int k = t / 15, r = t % 15 + 1;
+                tw2l[k * 17 + r - 1] = a.wtab[r * k * 16];
+            }
+            __syncthreads();
+        }
+        if constexpr (TWR & 2) {
+#pragma unroll
+            for (int r = 1; r < 16; ++r) tw3r[r - 1] = a.wtab[(r * t) & (L - 1)];
+        } else F::template load_twiddles16_split<256>(tw3a, tw3b, t, tww);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            C hv = a.hs[ut + 256u * r];
+            hreg[r] = C{hv.x * hscale, hv.y * hscale};
+        }
+    } else {
+#pragma unroll
+        for (int r = 1; r < 16; ++r) {
+            tw1[r - 1] = a.wtab[(t * r) & (L - 1)];
+            tw2[r - 1] = a.wtab[(16 * (t & 15) * r) & (L - 1)];
+        }
+        const unsigned k0 = ut >> 4, k1 = ut & 15;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            C hv = a.hs[k0 + 16u * k1 + 256u * r];
+            hreg[r] = C{hv.x * hscale, hv.y * hscale};
+        }
+    }
+    auto forward = [&](C (&v)[16]) {
+        if constexpr (CORE == 0) {
+            F::template compute<16, 1, -1>(v, t, tww);
+            __syncthreads();
+            F::scatter_a(v, t, lds);
+            __syncthreads();
+            F::gather_a(v, t, lds);
+            if constexpr (TWR & 1) F::template compute_pre<16, 16, -1>(v, tw2r); else F::template compute_pre<16, 16, -1>(v, tw2p);
+            __syncthreads();
+            F::scatter_b(v, t, lds);
+            __syncthreads();
+            F::gather_b(v, t, lds);
+            if constexpr (TWR & 2) F::template compute_pre<16, 256, -1>(v, tw3r); else F::template compute_pre16_split<256, -1>(v, tw3a, tw3b);
+        } else {
+            dft16<-1>(v);
+            tw_apply<-1>(v, tw1);
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < 16; ++r) cw[16 * r] = v[r];
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = cr[272 * r];
+            dft16<-1>(v);
+            tw_apply<-1>(v, tw2);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) pw[17 * r] = v[r];
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = pr[r];
+            dft16<-1>(v);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = cmul(v[r], hreg[r]);
+    };
+    auto inverse = [&](C (&v)[16]) {
+        if constexpr (CORE == 0) {
+            F::template compute<16, 1, 1>(v, t, tww);
+            __syncthreads();
+            F::scatter_a(v, t, lds);
+            __syncthreads();
+            F::gather_a(v, t, lds);
+            if constexpr (TWR & 1) F::template compute_pre<16, 16, 1>(v, tw2r); else F::template compute_pre<16, 16, 1>(v, tw2p);
+            __syncthreads();
+            F::scatter_b(v, t, lds);
+            __syncthreads();
+            F::gather_b(v, t, lds);
+            if constexpr (TWR & 2) F::template compute_pre<16, 256, 1>(v, tw3r); else F::template compute_pre16_split<256, 1>(v, tw3a, tw3b);
+        } else {
+            dft16<1>(v);
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int r = 0; r < 16; ++r) pw[17 * r] = v[r];
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = pr[r];
+            tw_apply<1>(v, tw2);
+            dft16<1>(v);
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < 16; ++r) cr[272 * r] = v[r];
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = cw[16 * r];
+            tw_apply<1>(v, tw1);
+            dft16<1>(v);
+        }
+    };
+    auto transform = [&](C (&v)[16]) { forward(v); inverse(v); };
+    const unsigned G = gridDim.x, wl = xcd_contiguous(blockIdx.x, G);
+    // the blocks that wrap around: [0, nb_lo) and [nb_hi, blocks), one per leading workgroup, general code
+    {
+        const unsigned nwrap = nb_lo + (a.blocks - nb_hi);
+        for (unsigned w = blockIdx.x; w < nwrap; w += G) {
+            const unsigned b = w < nb_lo ? w : nb_hi + (w - nb_lo);
+            C v[16];
+            load_block(a, b, V, ut, v);
+            transform(v);
+            store_block<false>(a, b, V, ut, v);
+        }
+    }
+    auto load_fast = [&](unsigned b, C (&v)[16]) {
+        const C* xb = a.x + ((long long)b * V + a.in_off);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = xb[ut + 256u * r];
+    };
+    auto store_fast = [&](unsigned b, const C (&v)[16]) {
+        if constexpr (R0 > 0) {
+            C* yb = a.y + ((long long)b * V - 256 * R0);
+#pragma unroll
+            for (int r = R0; r < 16; ++r) yb[ut + 256u * r] = v[r];
+        } else {
+            const int r0 = a.ov >> 8; // uniform
+            C* yb = a.y + ((long long)b * V - a.ov);
+#pragma unroll
+            for (int r = 1; r < 16; ++r)
+                if (r >= r0) yb[ut + 256u * r] = v[r];
+        }
+    };
+    if constexpr (DBUF == 2 || DBUF == 3) {
+        // Dynamic distribution: the interior blocks [nb_lo, nb_hi) are split into eight contiguous queues (one per XCD,
+        // so that neighbouring blocks -- which share M-1 input samples -- are in flight on the same L2); a workgroup
+        // takes its first block statically and every later one with an atomic ticket from its XCD's queue (then from
+        // the other queues once its own is empty).  The ticket for the NEXT block is requested while this one is
+        // being transformed and handed to the other waves through LDS.  Why: with a static grid-stride walk the
+        // three workgroups of a CU finish 20 us apart (the oldest wave wins every issue arbitration), and the CU
+        // idles through the tail.  The last workgroup to leave resets the counters for the next launch.
+        __shared__ unsigned s_next[2];
+        const unsigned nq = DBUF == 2 ? 8u : 1u;
+        const unsigned total = nb_hi - nb_lo, per = (total + nq - 1) / nq;
+        unsigned myq = (DBUF == 2) ? (blockIdx.x & 7u) : 0u;
+        const unsigned first_local = DBUF == 2 ? (blockIdx.x >> 3) : blockIdx.x, prefill = DBUF == 2 ? (G >> 3) : G;
+        auto q_lo = [&](unsigned q) { return nb_lo + q * per; };
+        auto q_cnt = [&](unsigned q) { unsigned lo = q * per; return lo >= total ? 0u : (total - lo < per ? total - lo : per); };
+        unsigned tried = 0; // thread 0: queues found empty so far (own queue first, then the neighbours)
+        auto fetch = [&]() -> unsigned {
+            while (tried < nq) {
+                const unsigned q = (myq + tried) % nq;
+                const unsigned v = atomicAdd(&a.q[q * 32], 1u) + (tried == 0 ? prefill : (DBUF == 2 ? (G >> 3) : G));
+                if (v < q_cnt(q)) return q_lo(q) + v;
+                ++tried;
+            }
+            return 0xffffffffu;
+        };
+        unsigned b = first_local < q_cnt(myq) ? q_lo(myq) + first_local : 0xffffffffu;
+        if (b == 0xffffffffu) { // (only when a queue is shorter than the resident workgroups of its XCD)
+            if (t == 0) s_next[1] = fetch();
+            __syncthreads();
+            b = s_next[1];
+            __syncthreads();
+        }
+        unsigned it = 0;
+        if constexpr (DBUF == 2) {
+            // the ticket is requested by an UNTRACKED atomic (inline asm: the compiler must not wait for it at the
+            // top of the block, where it would expose the whole round trip); it is awaited at the end of the block
+            while (b != 0xffffffffu) {
+                C v[16];
+                load_fast(b, v);
+                unsigned ticket = 0;
+                if (t == 0 && tried == 0) {
+                    unsigned* qp = &a.q[myq * 32];
+                    const unsigned one = 1;
+                    asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(ticket) : "v"(qp), "v"(one) : "memory");
+                }
+                transform(v);
+                store_fast(b, v);
+                if (t == 0) {
+                    unsigned nb = 0xffffffffu;
+                    if (tried == 0) {
+                        asm volatile("s_waitcnt vmcnt(0)" : "+v"(ticket)::"memory");
+                        const unsigned vv = ticket + prefill;
+                        if (vv < q_cnt(myq)) nb = q_lo(myq) + vv; else { tried = 1; nb = fetch(); }
+                    } else nb = fetch();
+                    s_next[it & 1] = nb;
+                }
+                __syncthreads();
+                b = s_next[it & 1];
+                ++it;
+            }
+        } else {
+        while (b != 0xffffffffu) {
+            C v[16];
+            load_fast(b, v);
+            if (t == 0) s_next[it & 1] = fetch();
+            transform(v);
+            store_fast(b, v);
+            b = s_next[it & 1]; // written before the transform's barriers, read after them
+            ++it;
+        }
+        }
+        if (t == 0) {
+            const unsigned old = atomicAdd(&a.q[8 * 32], 1u);
+            if (old == G - 1) {
+                for (unsigned q = 0; q < 8; ++q) a.q[q * 32] = 0;
+                a.q[8 * 32] = 0;
+            }
+        }
+    } else if constexpr (DBUF >= 2000) {
+        // skew in whole ROUNDS: group g (of WPC groups of G/WPC workgroups, in dispatch order) takes RA, RB rounds
+        // of G/WPC blocks each; the last group takes what is left.  DBUF = 2000 + 100*RA + RB (RB = 0 with two groups)
+        constexpr int RA = (DBUF - 2000) / 100, RB = (DBUF - 2000) % 100;
+        const unsigned total = nb_hi - nb_lo, gs = G / WPC;
+        unsigned na = RA * gs, nbb = WPC == 3 ? RB * gs : 0;
+        if (na > total) na = total;
+        if (na + nbb > total) nbb = total - na;
+        const unsigned grp = blockIdx.x / gs;
+        const unsigned lo = grp == 0 ? nb_lo : ((grp == 1 && WPC == 3) ? nb_lo + na : nb_lo + na + nbb);
+        const unsigned hi = grp == 0 ? nb_lo + na : ((grp == 1 && WPC == 3) ? nb_lo + na + nbb : nb_hi);
+        const unsigned w2 = xcd_contiguous(blockIdx.x - grp * gs, gs);
+        if (grp < (unsigned)WPC)
+            for (unsigned b = lo + w2; b < hi; b += gs) {
+                C v[16];
+                load_fast(b, v);
+                transform(v);
+                store_fast(b, v);
+            }
+    } else if constexpr (DBUF >= 1000) {
+        // three-way static skew for 3 workgroups per CU: DBUF = 1000 + 100*a + b: shares a/100.. of group 0 and group 1
+        constexpr int SA = (DBUF - 1000) / 100, SB = (DBUF - 1000) % 100;
+        const unsigned total = nb_hi - nb_lo, third = G / 3;
+        const unsigned na = (unsigned)((unsigned long long)total * SA / 100), nbb = (unsigned)((unsigned long long)total * SB / 100);
+        const unsigned grp = blockIdx.x / third;
+        const unsigned lo = grp == 0 ? nb_lo : (grp == 1 ? nb_lo + na : nb_lo + na + nbb);
+        const unsigned hi = grp == 0 ? nb_lo + na : (grp == 1 ? nb_lo + na + nbb : nb_hi);
+        const unsigned w2 = xcd_contiguous(blockIdx.x - grp * third, third);
+        if (grp < 3)
+            for (unsigned b = lo + w2; b < hi; b += third) {
+                C v[16];
+                load_fast(b, v);
+                transform(v);
+                store_fast(b, v);
+            }
+    } else if constexpr (DBUF >= 50) {
+        // static SKEW: the workgroups dispatched first (blockIdx < G/2: the older of the two on their CU, which win the
+        // issue arbitration and run ~1.5x faster) take a larger share of the blocks
+        const unsigned total = nb_hi - nb_lo, half = G >> 1;
+        const unsigned na = (unsigned)((unsigned long long)total * DBUF / 100);
+        const bool first = blockIdx.x < half;
+        const unsigned lo = first ? nb_lo : nb_lo + na, hi = first ? nb_lo + na : nb_hi;
+        const unsigned w2 = xcd_contiguous(first ? blockIdx.x : blockIdx.x - half, half);
+        for (unsigned b = lo + w2; b < hi; b += half) {
+            C v[16];
+            load_fast(b, v);
+            transform(v);
+            store_fast(b, v);
+        }
+    } else if constexpr (!DBUF) {
+        for (unsigned b = nb_lo + wl; b < nb_hi; b += G) {
+            C v[16];
+            load_fast(b, v);
+            transform(v);
+            store_fast(b, v);
+        }
+    } else {
+        // two register sets: while one block is transformed the next one's loads are in flight; a set is reloaded
+        // half a block after its stores were issued, when they have retired
+        unsigned b = nb_lo + wl;
+        C va[16], vb[16];
+        if (b < nb_hi) load_fast(b, va);
+        for (; b < nb_hi; b += 2 * G) {
+            const bool has_b = b + G < nb_hi;
+            if (has_b) load_fast(b + G, vb);
+            transform(va);
+            store_fast(b, va);
+            if (has_b) {
+                forward(vb);
+                if (b + 2 * G < nb_hi) load_fast(b + 2 * G, va);
+                inverse(vb);
+                store_fast(b + G, vb);
+            }
+        }
+    }
+#ifdef LAB_PROBE
+    if (threadIdx.x == 0 && a.clk) {
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        unsigned long long* q = a.clk + 4 * blockIdx.x;
+        q[0] = clk_r0;
+        q[1] = __builtin_amdgcn_s_memrealtime();
+        q[2] = __builtin_amdgcn_s_memtime() - clk_t0;
+        q[3] = xcc & 7;
+    }
+#endif
+}
+
+// ------------------------------------------------------------------------------------------- host
+static std::vector<std::complex<double>> fft_host(std::vector<std::complex<double>> v)
+{
+    const size_t n = v.size();
+    for (size_t i = 1, j = 0; i < n; ++i) {
+        size_t bit = n >> 1;
+        for (; j & bit; bit >>= 1) j ^= bit;
+        j ^= bit;
+        if (i < j) std::swap(v[i], v[j]);
+    }
+    for (size_t len = 2; len <= n; len <<= 1) {
+        const double ang = -2 * M_PI / (double)len;
+        for (size_t i = 0; i < n; i += len)
+            for (size_t k = 0; k < len / 2; ++k) {
+                std::complex<double> w(std::cos(ang * k), std::sin(ang * k));
+                auto u = v[i + k], x = v[i + k + len / 2] * w;
+                v[i + k] = u + x;
+                v[i + k + len / 2] = u - x;
+            }
+    }
+    return v;
+}
+
+int main(int argc, char** argv)
+{
+    const unsigned n = argc > 1 ? (unsigned)atol(argv[1]) : (1u << 24);
+    const int m = argc > 2 ? atoi(argv[2]) : 1024;
+    const char* only = argc > 3 ? argv[3] : "";
+    int cus = 0;
+    CK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0));
+    std::mt19937_64 rng(20260102);
+    std::uniform_real_distribution<float> ux(-10.f, 10.f), uh(-1.f, 1.f);
+    std::vector<C> hx(n), htaps(m);
+    for (auto& c : hx) c = C{ux(rng), ux(rng)};
+    for (auto& c : htaps) c = C{uh(rng) / m, uh(rng) / m};
+    C* dx[3];
+    for (auto& p : dx) { CK(hipMalloc(&p, sizeof(C) * n)); }
+    CK(hipMemcpy(dx[0], hx.data(), sizeof(C) * n, hipMemcpyHostToDevice));
+    {
+        std::vector<C> other(n);
+        for (int k = 1; k < 3; ++k) {
+            for (auto& c : other) c = C{ux(rng), ux(rng)};
+            CK(hipMemcpy(dx[k], other.data(), sizeof(C) * n, hipMemcpyHostToDevice));
+        }
+    }
+    C* dy;
+    CK(hipMalloc(&dy, sizeof(C) * n));
+    // twiddle table
+    std::vector<C> hw(L);
+    for (int k = 0; k < L; ++k) {
+        long double ang = -2.0L * 3.14159265358979323846264338327950288L * k / L;
+        hw[k] = C{(float)cosl(ang), (float)sinl(ang)};
+    }
+    C* dw;
+    CK(hipMalloc(&dw, sizeof(C) * L));
+    CK(hipMemcpy(dw, hw.data(), sizeof(C) * L, hipMemcpyHostToDevice));
+    // filter spectra: plain (ov = m-1) and delayed (ov = round_up(m-1, 16))
+    auto spectrum = [&](int delay) {
+        std::vector<std::complex<double>> z(L);
+        for (int k = 0; k < m; ++k) z[k + delay] = std::complex<double>(htaps[k][0], htaps[k][1]);
+        auto s = fft_host(z);
+        std::vector<C> f(L);
+        for (int k = 0; k < L; ++k) f[k] = C{(float)s[k].real(), (float)s[k].imag()};
+        C* d;
+        CK(hipMalloc(&d, sizeof(C) * L));
+        CK(hipMemcpy(d, f.data(), sizeof(C) * L, hipMemcpyHostToDevice));
+        return d;
+    };
+    const int ov_plain = m - 1, ov_al = (m - 1 + 15) & ~15;
+    C* hs_plain = spectrum(0);
+    C* hs_al = spectrum(ov_al - ov_plain);
+    C* hs_r0 = spectrum(((m - 1 + 255) & ~255) - ov_plain);
+
+    // reference outputs at selected positions: y[i] = sum_k x[(i + ceil(m/2) - 1 - k) mod n] h[k]
+    std::vector<unsigned> pos;
+    for (unsigned i = 0; i < 40; ++i) { pos.push_back(i); pos.push_back(n - 1 - i); }
+    for (unsigned b = 1; b < 6; ++b) for (int d = -3; d <= 3; ++d) pos.push_back(b * 3072u + d);
+    for (unsigned b = 1; b < 6; ++b) for (int d = -3; d <= 3; ++d) pos.push_back(b * 3073u + d);
+    for (int k = 0; k < 200; ++k) pos.push_back((unsigned)(rng() % n));
+    std::vector<std::complex<double>> ref(pos.size());
+    const long long c = m - m / 2;
+    for (size_t p = 0; p < pos.size(); ++p) {
+        std::complex<double> acc = 0;
+        for (int k = 0; k < m; ++k) {
+            long long j = ((long long)pos[p] + c - 1 - k) % (long long)n;
+            if (j < 0) j += n;
+            acc += std::complex<double>(hx[j][0], hx[j][1]) * std::complex<double>(htaps[k][0], htaps[k][1]);
+        }
+        ref[p] = acc;
+    }
+    double refnorm = 0;
+    for (auto& r : ref) refnorm += std::norm(r);
+
+    struct Variant { const char* name; const void* fn; bool aligned; int per_cu; size_t lds; int r0 = 0; };
+    const size_t lds_base = (size_t)(WgFft<float, L, 256>::LDS_ELEMS + 16 * 17) * sizeof(C);
+    const size_t lds_dif = (size_t)(CROSS_ELEMS + 4 * PRIV_ELEMS) * sizeof(C);
+    std::vector<Variant> vars = {
+        {"base", (const void*)k_base<false>, false, 3, lds_base},
+        {"base+as", (const void*)k_base<true>, true, 3, lds_base},
+        {"ub0", (const void*)k_ub<0>, false, 3, lds_base},
+        {"ub1", (const void*)k_ub<1>, false, 3, lds_base},
+        {"ub2", (const void*)k_ub<2>, false, 3, lds_base},
+        {"ub3", (const void*)k_ub<3>, false, 3, lds_base},
+        {"ub4", (const void*)k_ub<4>, false, 3, lds_base},
+        {"ub8", (const void*)k_ub<8>, false, 3, lds_base},
+        {"ub16", (const void*)k_ub<16>, false, 3, lds_base},
+        {"ub31", (const void*)k_ub<31>, false, 3, lds_base},
+        {"dif", (const void*)k_dif<false, 2>, false, 2, lds_dif},
+        {"dif+as", (const void*)k_dif<true, 2>, true, 2, lds_dif},
+        {"v2 st tw0 3", (const void*)k_v2<0, 4, 0, 0, 3>, true, 3, lds_base, 4},
+        {"v2 st tw1 3", (const void*)k_v2<0, 4, 1, 0, 3>, true, 3, lds_base, 4},
+        {"v2 st tw3 2", (const void*)k_v2<0, 4, 3, 0, 2>, true, 2, lds_base, 4},
+        {"v2 st tw3 2 db", (const void*)k_v2<0, 4, 3, 1, 2>, true, 2, lds_base, 4},
+        {"v2 st tw0 2 db", (const void*)k_v2<0, 4, 0, 1, 2>, true, 2, lds_base, 4},
+        {"v2 st tw0 4", (const void*)k_v2<0, 4, 0, 0, 4>, true, 4, lds_base, 4},
+        {"v2 st tw0 4 dyn", (const void*)k_v2<0, 4, 0, 2, 4>, true, 4, lds_base, 4},
+        {"v2 st tw0 3 dyn", (const void*)k_v2<0, 4, 0, 2, 3>, true, 3, lds_base, 4},
+        {"v2 st tw0 3 dyn1", (const void*)k_v2<0, 4, 0, 3, 3>, true, 3, lds_base, 4},
+        {"v2 st tw3 2 dyn", (const void*)k_v2<0, 4, 3, 2, 2>, true, 2, lds_base, 4},
+        {"v2 dif 2 dyn", (const void*)k_v2<1, 4, 0, 2, 2>, true, 2, lds_dif, 4},
+        {"v2 st tw3 2 skew52", (const void*)k_v2<0, 4, 3, 52, 2>, true, 2, lds_base, 4},
+        {"v2 st tw3 2 skew54", (const void*)k_v2<0, 4, 3, 54, 2>, true, 2, lds_base, 4},
+        {"v2 st tw3 2 skew55", (const void*)k_v2<0, 4, 3, 55, 2>, true, 2, lds_base, 4},
+        {"v2 st tw3 2 skew56", (const void*)k_v2<0, 4, 3, 56, 2>, true, 2, lds_base, 4},
+        {"v2 st tw3 2 skew58", (const void*)k_v2<0, 4, 3, 58, 2>, true, 2, lds_base, 4},
+        {"v2 st tw1 3 skew 40/33", (const void*)k_v2<0, 4, 1, 1000 + 4033, 3>, true, 3, lds_base, 4},
+        {"v2 st tw1 3 skew 38/33", (const void*)k_v2<0, 4, 1, 1000 + 3833, 3>, true, 3, lds_base, 4},
+        {"v2 st tw1 3 skew 42/33", (const void*)k_v2<0, 4, 1, 1000 + 4233, 3>, true, 3, lds_base, 4},
+        {"v2 st tw0 3 skew 40/33", (const void*)k_v2<0, 4, 0, 1000 + 4033, 3>, true, 3, lds_base, 4},
+        {"v2 st tw1 3 rounds 9/7", (const void*)k_v2<0, 4, 1, 2000 + 907, 3>, true, 3, lds_base, 4},
+        {"v2 st tw1 3 rounds 9/8", (const void*)k_v2<0, 4, 1, 2000 + 908, 3>, true, 3, lds_base, 4},
+        {"v2 st tw1 3 rounds 10/7", (const void*)k_v2<0, 4, 1, 2000 + 1007, 3>, true, 3, lds_base, 4},
+        {"v2 st tw1 3 rounds 8/7", (const void*)k_v2<0, 4, 1, 2000 + 807, 3>, true, 3, lds_base, 4},
+        {"v2 st tw1 3 rounds 10/6", (const void*)k_v2<0, 4, 1, 2000 + 1006, 3>, true, 3, lds_base, 4},
+        {"v2 st tw1 3 rounds 10/8", (const void*)k_v2<0, 4, 1, 2000 + 1008, 3>, true, 3, lds_base, 4},
+        {"v2 st tw1 3 rounds 9/9", (const void*)k_v2<0, 4, 1, 2000 + 909, 3>, true, 3, lds_base, 4},
+        {"v2 st tw1 3 rounds 10/9", (const void*)k_v2<0, 4, 1, 2000 + 1009, 3>, true, 3, lds_base, 4},
+        {"v2 st tw1 3 rounds 11/8", (const void*)k_v2<0, 4, 1, 2000 + 1108, 3>, true, 3, lds_base, 4},
+        {"v2 st tw0 3 rounds 9/8", (const void*)k_v2<0, 4, 0, 2000 + 908, 3>, true, 3, lds_base, 4},
+        {"v2 st tw0 3 rounds 9/7", (const void*)k_v2<0, 4, 0, 2000 + 907, 3>, true, 3, lds_base, 4},
+        {"v2 st tw3 2 rounds 12", (const void*)k_v2<0, 4, 3, 2000 + 1200, 2>, true, 2, lds_base, 4},
+        {"v2 st tw3 2 rounds 13", (const void*)k_v2<0, 4, 3, 2000 + 1300, 2>, true, 2, lds_base, 4},
+        {"v2 st tw3 2 skew55 rt", (const void*)k_v2<0, 0, 3, 55, 2>, true, 2, lds_base, 4},
+        {"v2 dif 2 skew55", (const void*)k_v2<1, 4, 0, 55, 2>, true, 2, lds_dif, 4},
+        {"v2 dif 2", (const void*)k_v2<1, 4, 0, 0, 2>, true, 2, lds_dif, 4},
+        {"v2 dif 2 db", (const void*)k_v2<1, 4, 0, 1, 2>, true, 2, lds_dif, 4},
+    };
+    // clock warm-up
+    {
+        Args a{dx[0], dy, hs_plain, dw, n, ov_plain, 3072u, -(long long)(m / 2), (n + 3071u) / 3072u, nullptr, nullptr};
+        CK(hipFuncSetAttribute(vars[0].fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_base));
+        for (int i = 0; i < 2500; ++i) hipLaunchKernelGGL(k_base<false>, dim3(cus * 3), dim3(256), lds_base, 0, a);
+        CK(hipDeviceSynchronize());
+    }
+    unsigned* dq;
+    CK(hipMalloc(&dq, 4 * 32 * 9));
+    CK(hipMemset(dq, 0, 4 * 32 * 9));
+    unsigned long long* dclk;
+    CK(hipMalloc(&dclk, 32 * 4096));
+    std::vector<C> hy(n);
+    for (auto& v : vars) {
+        if (*only && std::string(v.name) != only) continue;
+        const int ov = v.r0 ? 256 * v.r0 : (v.aligned ? ov_al : ov_plain);
+        unsigned V = (unsigned)(L - ov);
+        if (V >= 16) V &= ~15u; // every block starts on a 128-byte line of the input
+        Args a{dx[0], dy, v.r0 ? hs_r0 : (v.aligned ? hs_al : hs_plain), dw, n, ov, V, -(long long)(m / 2), (n + V - 1) / V, dq, nullptr};
+        unsigned nb_lo = 0, nb_hi = a.blocks;
+        while (nb_lo < a.blocks && (long long)nb_lo * V + a.in_off < 0) ++nb_lo;
+        while (nb_hi > nb_lo && (long long)(nb_hi - 1) * V + a.in_off + L > (long long)n) --nb_hi;
+        CK(hipFuncSetAttribute(v.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)v.lds));
+        int occ = 0;
+        CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, v.fn, 256, v.lds));
+        const unsigned grid = std::min<unsigned>((unsigned)cus * v.per_cu, a.blocks);
+        void* params[] = {&a, &nb_lo, &nb_hi};
+        CK(hipMemset(dy, 0xff, sizeof(C) * n));
+        CK(hipLaunchKernel(v.fn, dim3(grid), dim3(256), params, v.lds, 0));
+        CK(hipDeviceSynchronize());
+        CK(hipMemcpy(hy.data(), dy, sizeof(C) * n, hipMemcpyDeviceToHost));
+        double err = 0;
+        for (size_t p = 0; p < pos.size(); ++p) err += std::norm(std::complex<double>(hy[pos[p]][0], hy[pos[p]][1]) - ref[p]);
+        size_t nans = 0;
+        for (auto& cc : hy) if (!(cc[0] == cc[0]) || !(cc[1] == cc[1])) ++nans;
+        // timing
+        for (int i = 0; i < 300; ++i) { a.x = dx[i % 3]; CK(hipLaunchKernel(v.fn, dim3(grid), dim3(256), params, v.lds, 0)); }
+        hipEvent_t e0, e1;
+        CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+        CK(hipDeviceSynchronize());
+        const int reps = 400;
+        CK(hipEventRecord(e0, 0));
+        for (int i = 0; i < reps; ++i) { a.x = dx[i % 3]; CK(hipLaunchKernel(v.fn, dim3(grid), dim3(256), params, v.lds, 0)); }
+        CK(hipEventRecord(e1, 0));
+        CK(hipDeviceSynchronize());
+        float ms;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        const double us = ms * 1e3 / reps;
+        std::vector<unsigned long long> hclk(4 * grid, 0);
+        CK(hipMemset(dclk, 0, 32 * 4096));
+        a.clk = dclk;
+        for (int i = 0; i < 7; ++i) { a.x = dx[i % 3]; CK(hipLaunchKernel(v.fn, dim3(grid), dim3(256), params, v.lds, 0)); }
+        CK(hipDeviceSynchronize());
+        a.clk = nullptr;
+        CK(hipMemcpy(hclk.data(), dclk, 32 * grid, hipMemcpyDeviceToHost));
+        double mhz = 0, dmin = 1e9, dmax = 0, dsum = 0, span = 0;
+        if (hclk[1]) {
+            unsigned long long t0 = ~0ull, t1 = 0;
+            double xs[8] = {0}, xe[8] = {0}; int xn[8] = {0};
+            for (unsigned g = 0; g < grid; ++g) {
+                t0 = std::min(t0, hclk[4 * g]); t1 = std::max(t1, hclk[4 * g + 1]);
+            }
+            for (unsigned g = 0; g < grid; ++g) {
+                double d = (hclk[4 * g + 1] - hclk[4 * g]) / 100.0;
+                dmin = std::min(dmin, d); dmax = std::max(dmax, d); dsum += d;
+                mhz += 100.0 * hclk[4 * g + 2] / (double)(hclk[4 * g + 1] - hclk[4 * g]);
+                int x = (int)hclk[4 * g + 3];
+                xs[x] += (hclk[4 * g] - t0) / 100.0; xe[x] += (hclk[4 * g + 1] - t0) / 100.0; xn[x]++;
+            }
+            mhz /= grid; span = (t1 - t0) / 100.0;
+            if (getenv("LAB_DUMP")) {
+                std::string fn = std::string(getenv("LAB_DUMP")) + "/wg_" + std::to_string((int)(&v - &vars[0])) + ".txt";
+                if (FILE* f = fopen(fn.c_str(), "w")) {
+                    fprintf(f, "# %s: wg start_us end_us xcc\n", v.name);
+                    for (unsigned g = 0; g < grid; ++g)
+                        fprintf(f, "%u %.2f %.2f %d\n", g, (hclk[4 * g] - t0) / 100.0, (hclk[4 * g + 1] - t0) / 100.0, (int)hclk[4 * g + 3]);
+                    fclose(f);
+                }
+            }
+            printf("    per-XCD mean start/end us:");
+            for (int x = 0; x < 8; ++x) printf(" [%d: n=%d %.1f/%.1f]", x, xn[x], xn[x] ? xs[x] / xn[x] : 0, xn[x] ? xe[x] / xn[x] : 0);
+            printf("\n");
+        }
+        printf("%-10s wg/CU %d (occ %d) V=%u blocks=%u: %6.2f us  %.3f of 8 TB/s  rel-L2 err %.2e  unwritten/NaN %zu | %.0f MHz, WG life min/mean/max %.1f/%.1f/%.1f us, first start -> last end %.1f us\n", v.name,
+               v.per_cu, occ, V, a.blocks, us, 16.0 * n / (us * 1e-6) / 8e12, std::sqrt(err / refnorm), nans, mhz, dmin, dsum / grid, dmax, span);
+    }
+    return 0;
+}

@@ -5,7 +5,7 @@ import torch
 import basic_dsp_amd as bd
 lib = bd.lib
 dev = torch.device("cuda", 0)
-sp = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+sp = bd._lib.torch_stream_arg()
 for mb in (8, 16, 32, 64, 128, 256, 512, 1024, 2048):
     n = mb * (1 << 20) // 4
     x = torch.rand(n, device=dev)
