@@ -130,19 +130,22 @@ def scatter_process_gather_chunked(batch, taps, points, process_fn, chunk_vector
     the transform that has just been queued.  Rank 0 transforms its own shard chunk by chunk between rounds.
     Returns the gathered [V, 2*points] tensor on rank 0, None elsewhere.
     """
-    world = dist.get_world_size(group)
-    rank = dist.get_rank(group)
+    single = not dist.is_initialized()  # one process, one GPU: the same pipeline without any communication
+    world = 1 if single else dist.get_world_size(group)
+    rank = 0 if single else dist.get_rank(group)
     meta = [None]
     if rank == 0:
         meta = [(batch.shape[0], str(batch.dtype).split(".")[-1], int(taps.numel()))]
-    dist.broadcast_object_list(meta, src=0, group=group)
+    if not single:
+        dist.broadcast_object_list(meta, src=0, group=group)
     nvec, dtype_name, ntaps = meta[0]
     dtype = getattr(torch, dtype_name)
     if device is None:
         device = batch.device if rank == 0 else torch.device("cpu")
     if rank != 0:
         taps = torch.empty(ntaps, dtype=dtype, device=device)
-    dist.broadcast(taps, src=0, group=group)
+    if not single:
+        dist.broadcast(taps, src=0, group=group)
     cuda = torch.device(device).type == "cuda"
     side = torch.cuda.Stream(device=device) if cuda else None
 

@@ -6,6 +6,7 @@
 #include <cstddef>
 #include <cstdint>
 #include <string>
+#include <vector>
 
 #include "../../include/basic_dsp_hip.h"
 #include "fft_core.h"
@@ -45,6 +46,10 @@ inline hipStream_t pick_stream(void* s)
 }
 int ws_alloc(void** p, size_t bytes, hipStream_t stream);
 void ws_free(void* p, hipStream_t stream);
+// HIP-graph capture on `stream`: blocks freed between begin and end are not recycled; end hands them to the caller
+// (the graph handle), which gives them back with ws_free when the graph is destroyed
+int ws_capture_begin(hipStream_t stream);
+void ws_capture_end(hipStream_t stream, std::vector<void*>* pinned);
 int num_cus();
 
 struct WsBlock { // RAII workspace

@@ -76,10 +76,21 @@ struct BsPlan {
     bool inverse = false;
     int esz = 0, dev = 0;
     unsigned long long stamp = 0;
+    int pins = 0; // HIP graphs that recorded this plan's addresses: never evicted while > 0
 };
 static std::mutex g_bs_mu;
 static std::vector<BsPlan> g_bs_plans;
 static unsigned long long g_bs_clock = 0;
+// capture bookkeeping (bdsp_hip_capture_begin/_end): plans looked up while a capture is open are pinned to the graph
+static int g_capture_open = 0;
+static std::vector<void*> g_capture_plans; // chirp pointers identify plans
+static unsigned long long g_capture_moves = 0; // g_buffer_moves when the capture was opened
+struct GraphHandle {
+    hipGraphExec_t exec = nullptr;
+    hipStream_t stream = nullptr;
+    std::vector<void*> pinned_blocks; // workspace blocks the captured calls released
+    std::vector<void*> pinned_plans;  // Bluestein plans (by chirp pointer) the captured calls used
+};
 constexpr size_t BS_CACHE_BYTES = size_t(1) << 30;
 
 template <typename T>
@@ -90,6 +101,7 @@ int bs_plan(size_t n, size_t m, bool inverse, hipStream_t s, const T** chirp, co
     for (auto& p : g_bs_plans)
         if (p.n == n && p.inverse == inverse && p.esz == (int)sizeof(T) && p.dev == dev) {
             p.stamp = ++g_bs_clock;
+            if (g_capture_open) { ++p.pins; g_capture_plans.push_back(p.chirp); }
             *chirp = (const T*)p.chirp;
             *bspec = (const T*)p.bspec;
             return BDSP_OK;
@@ -101,9 +113,10 @@ int bs_plan(size_t n, size_t m, bool inverse, hipStream_t s, const T** chirp, co
     size_t used = 0;
     for (auto& q : g_bs_plans) used += q.bytes;
     while (!g_bs_plans.empty() && used + p.bytes > BS_CACHE_BYTES) {
-        size_t lru = 0;
-        for (size_t i = 1; i < g_bs_plans.size(); ++i)
-            if (g_bs_plans[i].stamp < g_bs_plans[lru].stamp) lru = i;
+        size_t lru = g_bs_plans.size();
+        for (size_t i = 0; i < g_bs_plans.size(); ++i)
+            if (g_bs_plans[i].pins == 0 && (lru == g_bs_plans.size() || g_bs_plans[i].stamp < g_bs_plans[lru].stamp)) lru = i;
+        if (lru == g_bs_plans.size()) break; // everything left is pinned by a graph
         BDSP_HIP_TRY(hipDeviceSynchronize());
         (void)hipFree(g_bs_plans[lru].chirp);
         (void)hipFree(g_bs_plans[lru].bspec);
@@ -124,6 +137,7 @@ int bs_plan(size_t n, size_t m, bool inverse, hipStream_t s, const T** chirp, co
     if (c == BDSP_OK && hipStreamSynchronize(s) != hipSuccess) c = BDSP_ERR_HIP;
     if (c != BDSP_OK) { (void)hipFree(p.chirp); (void)hipFree(p.bspec); return c; }
     p.stamp = ++g_bs_clock;
+    if (g_capture_open) { ++p.pins; g_capture_plans.push_back(p.chirp); }
     g_bs_plans.push_back(p);
     *chirp = (const T*)p.chirp;
     *bspec = (const T*)p.bspec;
@@ -541,6 +555,12 @@ size_t b1_overlap_discard(T* x_time, size_t x_len, T* tmp, size_t tmp_len, const
 // ----------------------------------------------------------------------------------------------
 // B2: HBM-resident vector behind the facade handle
 // ----------------------------------------------------------------------------------------------
+// Every buffer trade (and every reallocation) of a handle XORs a token into this word; two trades of the same
+// vector cancel.  A captured HIP graph records device addresses, so a capture may only contain sequences that
+// leave every vector's (live, trade) pair as they found it: bdsp_hip_capture_end compares the word.
+static std::atomic<unsigned long long> g_buffer_moves{0};
+static std::atomic<unsigned long long> g_realloc_ticket{1};
+
 template <typename T>
 struct DevVec {
     T* data = nullptr; // live buffer
@@ -555,7 +575,7 @@ struct DevVec {
     size_t points() const { return complex_ ? valid_len / 2 : valid_len; }
     bool erroneous() const { return valid_len == 0 && std::isnan((double)delta); }
     void poison() { valid_len = 0; delta = std::numeric_limits<T>::quiet_NaN(); } // mod.rs:226-229
-    void trade() { T* t = data; data = buf; buf = t; }
+    void trade() { T* t = data; data = buf; buf = t; g_buffer_moves ^= (unsigned long long)(uintptr_t)this * 0x9E3779B97F4A7C15ull; }
 
     int reserve(size_t scalars)
     {
@@ -573,6 +593,7 @@ struct DevVec {
         data = (T*)nd;
         buf = (T*)nb;
         cap = ncap;
+        g_buffer_moves ^= g_realloc_ticket.fetch_add(1) * 0xD1B54A32D192ED03ull; // never cancels: no capture across a reallocation
         return BDSP_OK;
     }
     ~DevVec()
@@ -2448,27 +2469,83 @@ void bdsp_hip_event_destroy(void* event) { if (event) (void)hipEventDestroy((hip
 int bdsp_hip_capture_begin(void* stream)
 {
     BDSP_TRY(check_device());
-    BDSP_HIP_TRY(hipStreamBeginCapture(pick_stream(stream), hipStreamCaptureModeRelaxed));
+    hipStream_t st = pick_stream(stream);
+    {
+        std::lock_guard<std::mutex> lk(g_bs_mu);
+        if (g_capture_open) { set_last_error("capture_begin: a capture is already open"); return BDSP_ERR_UNSUPPORTED; }
+        BDSP_TRY(ws_capture_begin(st));
+        g_capture_open = 1;
+        g_capture_plans.clear();
+        g_capture_moves = g_buffer_moves.load();
+    }
+    hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed);
+    if (e != hipSuccess) {
+        std::lock_guard<std::mutex> lk(g_bs_mu);
+        g_capture_open = 0;
+        ws_capture_end(st, nullptr);
+        set_last_error(hipGetErrorString(e));
+        return BDSP_ERR_HIP;
+    }
     return BDSP_OK;
 }
 int bdsp_hip_capture_end(void* stream, void** graph_exec)
 {
     if (!graph_exec) return BDSP_ERR_ARG_LENGTH;
     *graph_exec = nullptr;
+    hipStream_t st = pick_stream(stream);
     hipGraph_t g = nullptr;
-    BDSP_HIP_TRY(hipStreamEndCapture(pick_stream(stream), &g));
-    hipGraphExec_t e = nullptr;
-    hipError_t rc = hipGraphInstantiate(&e, g, nullptr, nullptr, 0);
+    hipError_t ec = hipStreamEndCapture(st, &g);
+    GraphHandle* h = new GraphHandle;
+    h->stream = st;
+    bool moved;
+    {
+        std::lock_guard<std::mutex> lk(g_bs_mu);
+        ws_capture_end(st, &h->pinned_blocks);
+        h->pinned_plans.swap(g_capture_plans);
+        moved = g_buffer_moves.load() != g_capture_moves;
+        g_capture_open = 0;
+    }
+    auto fail = [&](const char* msg, int code) {
+        if (g) (void)hipGraphDestroy(g);
+        bdsp_hip_graph_destroy(h);
+        set_last_error(msg);
+        return code;
+    };
+    if (ec != hipSuccess) return fail(hipGetErrorString(ec), BDSP_ERR_HIP);
+    // a graph replays ADDRESSES: the captured sequence must leave every vector's (live, trade) buffer pair where it
+    // found it -- an even number of trades per vector (fft followed by ifft is fine, a lone fft of 2^21 points is not)
+    // and no reallocation
+    if (moved)
+        return fail("capture_end: the captured calls traded or reallocated a vector's buffers an odd number of times; "
+                    "a replay would run on stale addresses", BDSP_ERR_UNSUPPORTED);
+    hipError_t rc = hipGraphInstantiate(&h->exec, g, nullptr, nullptr, 0);
     (void)hipGraphDestroy(g);
-    if (rc != hipSuccess) { set_last_error("hipGraphInstantiate failed"); return BDSP_ERR_HIP; }
-    *graph_exec = e;
+    g = nullptr;
+    if (rc != hipSuccess) return fail("hipGraphInstantiate failed", BDSP_ERR_HIP);
+    *graph_exec = h;
     return BDSP_OK;
 }
 int bdsp_hip_graph_launch(void* graph_exec, void* stream)
 {
-    BDSP_HIP_TRY(hipGraphLaunch((hipGraphExec_t)graph_exec, pick_stream(stream)));
+    if (!graph_exec) return BDSP_ERR_ARG_LENGTH;
+    BDSP_HIP_TRY(hipGraphLaunch(static_cast<GraphHandle*>(graph_exec)->exec, pick_stream(stream)));
     return BDSP_OK;
 }
-void bdsp_hip_graph_destroy(void* graph_exec) { if (graph_exec) (void)hipGraphExecDestroy((hipGraphExec_t)graph_exec); }
+// Destroys the executable graph and releases what it pinned: the workspace blocks the captured calls used (they go
+// back to the stream's cache) and its Bluestein plans (evictable again).  The caller makes sure no replay is in flight.
+void bdsp_hip_graph_destroy(void* graph_exec)
+{
+    if (!graph_exec) return;
+    GraphHandle* h = static_cast<GraphHandle*>(graph_exec);
+    if (h->exec) (void)hipGraphExecDestroy(h->exec);
+    for (void* p : h->pinned_blocks) ws_free(p, h->stream);
+    {
+        std::lock_guard<std::mutex> lk(g_bs_mu);
+        for (void* c : h->pinned_plans)
+            for (auto& p : g_bs_plans)
+                if (p.chirp == c && p.pins > 0) { --p.pins; break; }
+    }
+    delete h;
+}
 
 } // extern "C"

@@ -32,6 +32,10 @@ struct DeviceCtx {
     // free workspace blocks per stream, keyed by capacity
     std::map<hipStream_t, std::multimap<size_t, void*>> free_blocks;
     std::map<void*, size_t> block_size;
+    // streams whose work is being captured into a HIP graph: blocks released meanwhile are PINNED to the graph
+    // (a replay writes to the addresses it recorded, so they must not be handed to anybody else before the
+    // graph is destroyed)
+    std::map<hipStream_t, std::vector<void*>> capturing;
     std::map<std::pair<int, int>, void*> twiddles; // (n, sizeof(T)) -> device table
     size_t cached_bytes = 0; // sum of the free blocks' capacities
     size_t cache_limit = 0;  // a quarter of the device memory: beyond it blocks go back to the driver
@@ -155,6 +159,8 @@ void ws_free(void* p, hipStream_t stream)
     if (ctx_locked(&c) != BDSP_OK) return;
     auto it = c->block_size.find(p);
     if (it == c->block_size.end()) return;
+    auto cap = c->capturing.find(stream);
+    if (cap != c->capturing.end()) { cap->second.push_back(p); return; }
     if (c->cache_limit && c->cached_bytes + it->second > c->cache_limit) {
         // the cache is full: hand the block back (hipFree waits for the device, so work that still uses
         // the block has finished) instead of letting the cache grow without bound
@@ -164,6 +170,27 @@ void ws_free(void* p, hipStream_t stream)
     }
     c->cached_bytes += it->second;
     c->free_blocks[stream].emplace(it->second, p);
+}
+
+int ws_capture_begin(hipStream_t stream)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    DeviceCtx* c;
+    BDSP_TRY(ctx_locked(&c));
+    if (c->capturing.count(stream)) { g_last_error = "a capture is already open on this stream"; return BDSP_ERR_UNSUPPORTED; }
+    c->capturing[stream];
+    return BDSP_OK;
+}
+
+void ws_capture_end(hipStream_t stream, std::vector<void*>* pinned)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    DeviceCtx* c;
+    if (ctx_locked(&c) != BDSP_OK) return;
+    auto it = c->capturing.find(stream);
+    if (it == c->capturing.end()) return;
+    if (pinned) pinned->swap(it->second);
+    c->capturing.erase(it);
 }
 
 template <typename T>

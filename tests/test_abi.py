@@ -85,3 +85,15 @@ def test_header_is_plain_c_and_a_c_client_links():
     with tempfile.TemporaryDirectory() as d:
         subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Werror", "-D_GNU_SOURCE", "-I", os.path.join(ROOT, "include"),
                                src, "-L", libdir, "-lbasic_dsp_hip", "-lm", "-o", os.path.join(d, "demo")])
+
+
+def test_library_exports_nothing_but_the_declared_c_abi():
+    """No C++ internals leak out of the shared object: the dynamic symbol table holds the header's functions only
+    (the link uses the version script tools/gen_exports.py writes from the header)."""
+    import subprocess
+    import basic_dsp_amd._lib as L
+    out = subprocess.run(["nm", "-D", "--defined-only", L.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = {line.split()[-1].split("@")[0] for line in out.splitlines() if line.strip()}
+    extra = sorted(exported - set(declared_functions()))
+    assert not [n for n in extra if n.startswith("_Z")], extra[:5]
+    assert not extra, extra[:10]

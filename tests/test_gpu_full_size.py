@@ -128,21 +128,32 @@ def test_c4_f64_windowed_fft_and_interpolatef_4m():
     assert rel_l2(v.data(), ref) < 1e-13
 
 
-def test_c5_batch_of_1m_vectors_equals_single_vector_path():
+def test_c5_shard_of_64_1m_vectors_against_the_oracle():
+    """BASELINE config C5, one GPU's shard: 64 vectors of 1 048 576 complex f32 points through the batched
+    convolve_signal(1024 taps) -> plain_fft (basic_dsp_amd.batch.process_shard_gpu: two launches for the whole
+    shard).  One vector in eight is checked against the oracle's f64 overlap-save + transform of the same f32
+    input, three more against the single-vector path of the library, and the chunked pipeline
+    (scatter_process_gather_chunked, world size 1) must reproduce the shard bit for bit."""
     import torch
-    from basic_dsp_amd.batch import process_shard_gpu
-    nvec, n, m = 8, 1 << 20, 1024
+    from basic_dsp_amd.batch import process_shard_gpu, scatter_process_gather_chunked
+    nvec, n, m = 64, 1 << 20, 1024
     rows = np.stack([orc.fill_uniform(2 * n, SEED_C2 + r, -10, 10, np.float32) for r in range(nvec)])
     taps = (orc.fill_uniform(2 * m, SEED_C3_H, -1, 1, np.float32) / np.float32(m)).astype(np.float32)
-    out = process_shard_gpu(torch.from_numpy(rows).cuda(), torch.from_numpy(taps).cuda(), n)
-    torch.cuda.synchronize()
+    dev_rows, dev_taps = torch.from_numpy(rows).cuda(), torch.from_numpy(taps).cuda()
+    out = process_shard_gpu(dev_rows.clone(), dev_taps, n)
+    # no device-wide synchronize here: .cpu() on torch's stream must already be ordered behind the kernels (they run
+    # on the stream process_shard_gpu was given, torch's current one)
     out = out.cpu().numpy()
-    for r in (0, 3, nvec - 1):
+    for r in range(0, nvec, 8):
+        code, y = orc.overlap_discard(rows[r].astype(np.float64), taps.astype(np.float64), 0, fair=True)
+        assert code == 0
+        assert rel_l2(out[r], orc.fft(y)) < 1e-6, r
+    for r in (1, 31, nvec - 1):
         v = DspVec(rows[r], is_complex=True)
         assert v.convolve_signal(DspVec(taps, is_complex=True)) == 0 and v.plain_fft() == 0
         assert rel_l2(out[r], v.data()) < 1e-6
-    ref = orc.fft(orc.convolve_signal(rows[1].astype(np.float64), taps.astype(np.float64), True)[1])
-    assert rel_l2(out[1], ref) < 1e-6
+    piped = scatter_process_gather_chunked(dev_rows, dev_taps, n, process_shard_gpu, chunk_vectors=8)
+    assert np.array_equal(piped.cpu().numpy(), out)
 
 
 @pytest.mark.gpu

@@ -907,6 +907,18 @@ def test_hip_graph_capture_and_replay():
     lib.bdsp_hip_synchronize(None)
     t_graph = (time.perf_counter() - t0) / 100
     print("12-kernel chain: %.1f us direct, %.1f us as a graph" % (t_direct * 1e6, t_graph * 1e6))
+    # a graph replays addresses: a captured sequence that leaves a vector's (live, trade) buffers swapped is refused
+    big = DspVec(orc.fill_uniform(2 * (1 << 21), 6, -10, 10, np.float32), is_complex=True)
+    ref3 = np.fft.fft(big.datac().astype(np.complex128))
+    with pytest.raises(bd.BackendError):
+        Graph.capture(lambda: big.plain_fft(), warmup=False)   # three passes: the result ends in the trade buffer
+    # ... the capture attempt still ran nothing twice and left the library usable
+    assert big.domain() == V.FREQ
+    g5 = Graph.capture(lambda: (big.plain_ifft(), big.plain_fft()), warmup=False)  # two trades cancel
+    del g, g2, g3, g4, g5   # releases the workspace blocks and plans the graphs pinned
+    w2 = DspVec(x)
+    assert w2.scale(2.0) == 0 and np.array_equal(w2.data(), orc.real_scale(x, 2.0))
+    del ref3
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
