@@ -21,16 +21,21 @@
 //     the others filling its gaps.  So the shares follow the dispatch order instead: the first third of the grid
 //     takes ~43 % of the blocks, the second ~37 %, the last ~20 % (whole rounds of G/3 blocks: 9 / 8 / 4.3 rounds at
 //     16M points).  Only speed depends on the dispatch order.  62-63 us = 0.53-0.54 of the 8 TB/s roofline.
+//   * exchange A in a layout without write conflicts (fft_core.h LAYOUT3: the PMC's 20 % LDS conflict cycles were all
+//     on the first generation's 16-byte store pairs): 61.7 -> 61.3 us.
 //   * measured and NOT adopted: decimation-in-frequency / -time transforms with a wave-private second exchange
 //     (4 barriers per block instead of 8: 65-68 us with the skew, 2 workgroups per CU), all twiddles in registers at
-//     2 per CU (64.4-66.8), register or LDS-DMA prefetch of the next block (72-77), 4 workgroups per CU with 9
-//     spilled registers (70).
+//     2 per CU (64.4-66.8), register or LDS-DMA prefetch of the next block (72-77), 4 workgroups per CU (60.6 with a
+//     four-way skew: no better than three).  Wavefront shuffles (tools/ubench/permlane_exchange.hip): trading two
+//     register-index bits for lane bits 4 and 5 with v_permlane32_swap / v_permlane16_swap costs 28 ns per workgroup
+//     exchange and CU against 217 ns for a full four-bit exchange through LDS, but only those two lane bits are
+//     reachable that way (a select-and-shuffle exchange of two other bits measured 625 ns), so a transform built on
+//     them needs radix 16 x 4 x 16 x 4 -- 55 more packed instructions per transform than 16 x 16 x 16 on the unit
+//     that is already the busiest; not built.
 #include "bdsp_internal.h"
 #include <cstdlib>
 
 namespace bdsp {
-
-namespace {
 
 constexpr int L2 = 4096;
 using C32 = cpx<float>;
@@ -49,7 +54,7 @@ struct ConvV2Args {
     int hs_is_taps;
 };
 
-__device__ __forceinline__ unsigned xcd_contiguous(unsigned bid, unsigned g)
+static __device__ __forceinline__ unsigned xcd_contiguous(unsigned bid, unsigned g)
 {
     // workgroup w runs on XCD w % 8 (observed; only speed depends on it): give every XCD a contiguous run of the
     // blocks of a round, so that the M-1 input samples neighbouring blocks share are an L2 hit
@@ -69,7 +74,7 @@ __global__ __launch_bounds__(256, 3) void k_overlap_save_v2(ConvV2Args a)
     const float hscale = 1.0f / L;
     auto tww = [&](int mm) { return a.wtab[mm]; };
     C32 hreg[16], tw3a[3], tw3b[3];
-    C32* tw2l = lds + F::LDS_ELEMS;
+    C32* tw2l = lds + F::LDS_ELEMS3;
     const C32* tw2p = tw2l + (t & 15) * 17;
     if (t < 240) {
         int k = t / 15, r = t % 15 + 1;
@@ -81,12 +86,12 @@ __global__ __launch_bounds__(256, 3) void k_overlap_save_v2(ConvV2Args a)
     auto forward = [&](C32 (&v)[16]) {
         F::template compute<16, 1, -1>(v, t, tww);
         __syncthreads(); // the previous transform's last gather is done
-        F::scatter_a(v, t, lds);
+        F::scatter_a3(v, t, lds);
         __syncthreads();
-        F::gather_a(v, t, lds);
+        F::gather_a3(v, t, lds);
         F::template compute_pre<16, 16, -1>(v, tw2p);
         __syncthreads();
-        F::scatter_b(v, t, lds);
+        F::scatter_b3(v, t, lds);
         __syncthreads();
         F::gather_b(v, t, lds);
         F::template compute_pre16_split<256, -1>(v, tw3a, tw3b);
@@ -94,12 +99,12 @@ __global__ __launch_bounds__(256, 3) void k_overlap_save_v2(ConvV2Args a)
     auto inverse = [&](C32 (&v)[16]) {
         F::template compute<16, 1, 1>(v, t, tww);
         __syncthreads();
-        F::scatter_a(v, t, lds);
+        F::scatter_a3(v, t, lds);
         __syncthreads();
-        F::gather_a(v, t, lds);
+        F::gather_a3(v, t, lds);
         F::template compute_pre<16, 16, 1>(v, tw2p);
         __syncthreads();
-        F::scatter_b(v, t, lds);
+        F::scatter_b3(v, t, lds);
         __syncthreads();
         F::gather_b(v, t, lds);
         F::template compute_pre16_split<256, 1>(v, tw3a, tw3b);
@@ -193,7 +198,7 @@ __global__ __launch_bounds__(256, 3) void k_overlap_save_v2(ConvV2Args a)
 }
 
 template <int R0>
-int launch_v2(const ConvV2Args& a, unsigned grid, size_t lds, hipStream_t s)
+static int launch_v2(const ConvV2Args& a, unsigned grid, size_t lds, hipStream_t s)
 {
     if (a.batch > 1) {
         auto kern = k_overlap_save_v2<R0, true>;
@@ -205,8 +210,6 @@ int launch_v2(const ConvV2Args& a, unsigned grid, size_t lds, hipStream_t s)
     BDSP_LAUNCH_CHECK();
     return BDSP_OK;
 }
-
-} // namespace
 
 // block step of the second-generation kernel: V = 4096 - 256 ceil((M-1)/256)
 size_t conv_v2_block_step(size_t taps)
@@ -273,7 +276,7 @@ int conv_v2_run(const float* in, float* out, size_t points, size_t batch, const 
     if (na + nbb > interior) nbb = interior - na;
     a.na = (unsigned)na;
     a.nbb = (unsigned)nbb;
-    const size_t lds = (size_t)(WgFft<float, L2, 256>::LDS_ELEMS + 16 * 17) * sizeof(cpx<float>);
+    const size_t lds = (size_t)(WgFft<float, L2, 256>::LDS_ELEMS3 + 16 * 17) * sizeof(cpx<float>);
     switch (r0) {
 #define BDSP_R0(N) case N: return launch_v2<N>(a, grid, lds, s);
         BDSP_R0(1) BDSP_R0(2) BDSP_R0(3) BDSP_R0(4) BDSP_R0(5) BDSP_R0(6)

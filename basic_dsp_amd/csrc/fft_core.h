@@ -434,6 +434,36 @@ struct WgFft {
         }
     }
 
+    // LAYOUT3: exchange A without the two-way WRITE conflict LAYOUT2 still has (PMC: 20 % of the overlap-save
+    // kernel's LDS cycles; the analytic bank model of MI355X_MICROARCH.md puts all of them on scatter_a, whose 16-byte
+    // store pairs are served in groups of 8 lanes over 32 dword banks: bases 16 j + (j & ~1) put lanes j and j+1 on the
+    // same banks).  Row j (the 16 results of thread j) starts at 16 j + 2 (j & 7) + 16 (j >> 3): eight consecutive
+    // lanes tile the 32 banks.  A 32-lane READ group then needs its two rows 16 elements apart mod 32, which rows j and
+    // j + 8 are: the thread that reads for stage 2 therefore takes column col3(t) (thread bits 4 and 5..7 swapped),
+    // and writes exchange B from that column.  Exchange B's layout and gather_b are unchanged, so the transform's
+    // input and output register maps stay what they were.  4608 elements instead of 4368.
+    static constexpr int LDS_ELEMS3 = 4608;
+    static BDSP_HD int col3(int t) { return 16 * ((t >> 5) + 8 * ((t >> 4) & 1)) + (t & 15); }
+    static BDSP_HD void scatter_a3(const cpx<T> (&v)[E], int t, cpx<T>* lds)
+    {
+        cpx<T>* p = lds + 16 * t + 2 * (t & 7) + 16 * (t >> 3);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) p[r] = v[r];
+    }
+    static BDSP_HD void gather_a3(cpx<T> (&v)[E], int t, const cpx<T>* lds)
+    {
+        const cpx<T>* p = lds + 18 * (t >> 5) + 144 * ((t >> 4) & 1) + (t & 15);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = p[r * 288];
+    }
+    static BDSP_HD void scatter_b3(const cpx<T> (&v)[E], int t, cpx<T>* lds)
+    {
+        const int c = col3(t);
+        cpx<T>* p = lds + 272 * (c >> 4) + (c & 15);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) p[16 * r + 2 * (r >> 1)] = v[r];
+    }
+
     template <int R>
     static BDSP_HD void gather(cpx<T> (&v)[E], int t, const cpx<T>* lds)
     {

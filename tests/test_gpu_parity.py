@@ -303,7 +303,12 @@ def test_b1_fft_host_slices(dtype):
 
 # ------------------------------------------------------------------ convolution
 CONV_CASES = [(100, 6), (1000, 17), (5000, 64), (12288, 33), (4096, 1), (4097, 1024), (10000, 1025),
-              (65536, 1024), (3073 * 3, 1024), (50000, 2), (20000, 257)]
+              (65536, 1024), (3073 * 3, 1024), (50000, 2), (20000, 257),
+              # the block kernel stores whole 256-point rows from row ceil((M-1)/256) on: tap counts either side of
+              # every row boundary, the largest filter it takes (3073), vectors shorter than one block, lengths that
+              # leave 1 / V-1 outputs in the last block (V = 4096 - 256 ceil((M-1)/256))
+              (9000, 256), (9000, 258), (7000, 513), (30000, 769), (30000, 2049), (40000, 3073), (3073, 3073),
+              (3840 * 2 + 1, 200), (3840 * 3 - 1, 129), (3072 * 4, 1024), (3072 * 4 + 1, 1024), (2, 2), (1, 1)]
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
@@ -316,6 +321,36 @@ def test_convolve_signal_complex_vs_direct_oracle(n, m, dtype):
     assert v.convolve_signal(hv) == 0
     assert len(v) == 2 * n
     assert rel_l2(v.data(), ref) < tol_for(dtype), (n, m)
+
+
+@pytest.mark.parametrize("taps", [5, 300, 1024])
+def test_convolve_batch_through_device_api_matches_single_vectors(taps):
+    """bdsp_hip_dev_convolve on a batch (what the C5 shard and the matrix API use): the block space of all vectors is
+    one index range inside the kernel; every vector must equal its own single-vector convolution, wrap-around blocks
+    included, and vectors of a length that is not a multiple of the block step."""
+    import ctypes as C
+    import torch
+    lib = bd.lib
+    sp = bd._lib.torch_stream_arg()
+    for n, nvec in ((10000, 7), (3072 * 5 + 17, 3), (100, 5)):
+        if taps > n:
+            continue
+        rows = np.stack([orc.fill_uniform(2 * n, 31 + r + n, -10, 10, np.float32) for r in range(nvec)])
+        h = (orc.fill_uniform(2 * taps, 77 + taps, -1, 1, np.float32) / np.float32(taps)).astype(np.float32)
+        dx, dh = torch.from_numpy(rows).cuda(), torch.from_numpy(h).cuda()
+        dy = torch.empty_like(dx)
+        assert lib.bdsp_hip_dev_convolve(0, dx.data_ptr(), dy.data_ptr(), n, nvec, dh.data_ptr(), taps, sp) == 0
+        got = dy.cpu().numpy()
+        for r in range(nvec):
+            ref = orc.convolve_direct(rows[r].astype(np.float64), h.astype(np.float64), True)
+            assert rel_l2(got[r], ref) < 1e-6, (n, nvec, r)
+        # the prepared-spectrum entry point takes the same path with the delay applied as a linear phase
+        spec = torch.empty(2 * lib.bdsp_hip_conv_spectrum_points(), device="cuda", dtype=torch.float32)
+        assert lib.bdsp_hip_dev_conv_prepare(0, dh.data_ptr(), taps, spec.data_ptr(), sp) == 0
+        dy.zero_()
+        assert lib.bdsp_hip_dev_convolve_prepared(0, dx.data_ptr(), dy.data_ptr(), n, nvec, spec.data_ptr(), taps, sp) == 0
+        got2 = dy.cpu().numpy()
+        assert rel_l2(got2, got) < 1e-6
 
 
 def test_convolve_signal_kats_on_gpu():

@@ -13,11 +13,14 @@ sp = bd._lib.torch_stream_arg()
 flag = C.c_int(0)
 PEAK = 8000.0
 
+QUICK = "--quick" in sys.argv  # a few launches per config only: for the rocprofv3 --pmc passes (tools/profile_r02.sh)
+
 def timeit(fn, iters=20):
     # untimed pre-warm: the clock needs tens of milliseconds of load to settle (see bench.py)
     import time as _t
+    if QUICK: iters = 2
     t0 = _t.perf_counter(); k = 0
-    while _t.perf_counter() - t0 < 0.15:
+    while _t.perf_counter() - t0 < (0.0 if QUICK else 0.15):
         for _ in range(10): fn(k); k += 1
         torch.cuda.synchronize()
     e0, e1 = lib.bdsp_hip_event_create(), lib.bdsp_hip_event_create()

@@ -376,8 +376,8 @@ __global__ __launch_bounds__(256, WPC) void k_v2(Args a, unsigned nb_lo, unsigne
     auto tww = [&](int mm) { return a.wtab[mm]; };
     C hreg[16];
     // Stockham twiddles
-    C tw2r[(CORE == 0 && (TWR & 1)) ? 15 : 1], tw3r[(CORE == 0 && (TWR & 2)) ? 15 : 1], tw3a[3], tw3b[3];
-    C* tw2l = lds + F::LDS_ELEMS;
+    C tw2r[(CORE != 1 && (TWR & 1)) ? 15 : 1], tw3r[(CORE != 1 && (TWR & 2)) ? 15 : 1], tw3a[3], tw3b[3];
+    C* tw2l = lds + (CORE == 2 ? F::LDS_ELEMS3 : F::LDS_ELEMS);
     const C* tw2p = tw2l + (t & 15) * 17;
     // DIF twiddles
     C tw1[CORE == 1 ? 15 : 1], tw2[CORE == 1 ? 15 : 1];
@@ -387,7 +387,7 @@ __global__ __launch_bounds__(256, WPC) void k_v2(Args a, unsigned nb_lo, unsigne
     C* const cr = cross + (t & 15) + 16 * (t >> 4);
     C* const pw = priv + 272 * (lane >> 4) + (lane & 15);
     const C* const pr = priv + 272 * (lane >> 4) + 17 * (lane & 15);
-    if constexpr (CORE == 0) {
+    if constexpr (CORE == 0 || CORE == 2) {
         if constexpr (TWR & 1) {
 #pragma unroll
             for (int r = 1; r < 16; ++r) tw2r[r - 1] = a.wtab[16 * r * (t & 15)];
@@ -421,7 +421,19 @@ __global__ __launch_bounds__(256, WPC) void k_v2(Args a, unsigned nb_lo, unsigne
         }
     }
     auto forward = [&](C (&v)[16]) {
-        if constexpr (CORE == 0) {
+        if constexpr (CORE == 2) {
+            F::template compute<16, 1, -1>(v, t, tww);
+            __syncthreads();
+            F::scatter_a3(v, t, lds);
+            __syncthreads();
+            F::gather_a3(v, t, lds);
+            F::template compute_pre<16, 16, -1>(v, tw2p);
+            __syncthreads();
+            F::scatter_b3(v, t, lds);
+            __syncthreads();
+            F::gather_b(v, t, lds);
+            F::template compute_pre16_split<256, -1>(v, tw3a, tw3b);
+        } else if constexpr (CORE == 0) {
             F::template compute<16, 1, -1>(v, t, tww);
             __syncthreads();
             F::scatter_a(v, t, lds);
@@ -455,7 +467,19 @@ __global__ __launch_bounds__(256, WPC) void k_v2(Args a, unsigned nb_lo, unsigne
         for (int r = 0; r < 16; ++r) v[r] = cmul(v[r], hreg[r]);
     };
     auto inverse = [&](C (&v)[16]) {
-        if constexpr (CORE == 0) {
+        if constexpr (CORE == 2) {
+            F::template compute<16, 1, 1>(v, t, tww);
+            __syncthreads();
+            F::scatter_a3(v, t, lds);
+            __syncthreads();
+            F::gather_a3(v, t, lds);
+            F::template compute_pre<16, 16, 1>(v, tw2p);
+            __syncthreads();
+            F::scatter_b3(v, t, lds);
+            __syncthreads();
+            F::gather_b(v, t, lds);
+            F::template compute_pre16_split<256, 1>(v, tw3a, tw3b);
+        } else if constexpr (CORE == 0) {
             F::template compute<16, 1, 1>(v, t, tww);
             __syncthreads();
             F::scatter_a(v, t, lds);
@@ -594,6 +618,26 @@ __global__ __launch_bounds__(256, WPC) void k_v2(Args a, unsigned nb_lo, unsigne
             if (old == G - 1) {
                 for (unsigned q = 0; q < 8; ++q) a.q[q * 32] = 0;
                 a.q[8 * 32] = 0;
+            }
+        }
+    } else if constexpr (DBUF >= 1000000) {
+        // four dispatch groups (4 workgroups per CU): DBUF = 1000000 + 10000*RA + 100*RB + RC rounds, the last group the rest
+        constexpr int RA = (DBUF - 1000000) / 10000, RB = (DBUF - 1000000) / 100 % 100, RC = (DBUF - 1000000) % 100;
+        const unsigned total = nb_hi - nb_lo, gs = G / 4;
+        unsigned n0 = RA * gs, n1 = RB * gs, n2 = RC * gs;
+        if (n0 > total) n0 = total;
+        if (n0 + n1 > total) n1 = total - n0;
+        if (n0 + n1 + n2 > total) n2 = total - n0 - n1;
+        const unsigned grp = blockIdx.x / gs;
+        const unsigned starts[5] = {0, n0, n0 + n1, n0 + n1 + n2, total};
+        if (grp < 4) {
+            const unsigned lo = nb_lo + starts[grp], hi = nb_lo + starts[grp + 1];
+            const unsigned w2 = xcd_contiguous(blockIdx.x - grp * gs, gs);
+            for (unsigned b = lo + w2; b < hi; b += gs) {
+                C v[16];
+                load_fast(b, v);
+                transform(v);
+                store_fast(b, v);
             }
         }
     } else if constexpr (DBUF >= 2000) {
@@ -779,6 +823,7 @@ int main(int argc, char** argv)
 
     struct Variant { const char* name; const void* fn; bool aligned; int per_cu; size_t lds; int r0 = 0; };
     const size_t lds_base = (size_t)(WgFft<float, L, 256>::LDS_ELEMS + 16 * 17) * sizeof(C);
+    const size_t lds_l3 = (size_t)(WgFft<float, L, 256>::LDS_ELEMS3 + 16 * 17) * sizeof(C);
     const size_t lds_dif = (size_t)(CROSS_ELEMS + 4 * PRIV_ELEMS) * sizeof(C);
     std::vector<Variant> vars = {
         {"base", (const void*)k_base<false>, false, 3, lds_base},
@@ -823,6 +868,13 @@ int main(int argc, char** argv)
         {"v2 st tw1 3 rounds 10/9", (const void*)k_v2<0, 4, 1, 2000 + 1009, 3>, true, 3, lds_base, 4},
         {"v2 st tw1 3 rounds 11/8", (const void*)k_v2<0, 4, 1, 2000 + 1108, 3>, true, 3, lds_base, 4},
         {"v2 st tw0 3 rounds 9/8", (const void*)k_v2<0, 4, 0, 2000 + 908, 3>, true, 3, lds_base, 4},
+        {"v2 st tw0 4 rounds 8/7/4", (const void*)k_v2<0, 4, 0, 1000000 + 80704, 4>, true, 4, lds_base, 4},
+        {"v2 st tw0 4 rounds 7/6/5", (const void*)k_v2<0, 4, 0, 1000000 + 70605, 4>, true, 4, lds_base, 4},
+        {"v2 st tw0 4 rounds 8/6/4", (const void*)k_v2<0, 4, 0, 1000000 + 80604, 4>, true, 4, lds_base, 4},
+        {"v2 st tw0 4 rounds 9/7/4", (const void*)k_v2<0, 4, 0, 1000000 + 90704, 4>, true, 4, lds_base, 4},
+        {"v2 st tw0 4 rounds 6/6/5", (const void*)k_v2<0, 4, 0, 1000000 + 60605, 4>, true, 4, lds_base, 4},
+        {"v2 L3 tw0 3 rounds 9/8", (const void*)k_v2<2, 4, 0, 2000 + 908, 3>, true, 3, lds_l3, 4},
+        {"v2 L3 tw0 3 even", (const void*)k_v2<2, 4, 0, 0, 3>, true, 3, lds_l3, 4},
         {"v2 st tw0 3 rounds 9/7", (const void*)k_v2<0, 4, 0, 2000 + 907, 3>, true, 3, lds_base, 4},
         {"v2 st tw3 2 rounds 12", (const void*)k_v2<0, 4, 3, 2000 + 1200, 2>, true, 2, lds_base, 4},
         {"v2 st tw3 2 rounds 13", (const void*)k_v2<0, 4, 3, 2000 + 1300, 2>, true, 2, lds_base, 4},
