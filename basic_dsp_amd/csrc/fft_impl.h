@@ -93,6 +93,25 @@ __host__ __device__ constexpr int col_stride(int n, int w = 0)
     return base + (w >= 16 ? 1 : 16 / w);
 }
 
+// Inner-stage twiddles of a pass kernel from an LDS copy of the RP-entry table instead of global memory?  Yes whenever
+// the copy does not cost a resident workgroup.  *Measured* on 64 x 2^20 points (two passes of 1024-point columns):
+// 479 us with the 27 dependent global loads per thread and tile between an LDS gather and its butterflies, 405 us with
+// the loads removed altogether (a timing experiment); keeping the twiddles in registers across a persistent tile
+// loop instead made hipcc allocate 200+ VGPRs (532 us) or, with the budget capped at 128, spill (890 us).
+__host__ __device__ constexpr int pass_wgs_per_cu(size_t lds_bytes, int threads)
+{
+    size_t k = (size_t)(160 * 1024) / (lds_bytes + 64);
+    if (k > (size_t)(2048 / threads)) k = (size_t)(2048 / threads);
+    if (k > 8) k = 8;
+    return (int)k;
+}
+template <typename T, int RP, int W>
+constexpr bool pass_lds_twiddles()
+{
+    constexpr size_t base = (size_t)W * col_stride(RP, W) * sizeof(cpx<T>), tab = (size_t)RP * sizeof(cpx<T>);
+    return RP >= 256 && pass_wgs_per_cu(base, W * (RP / 16)) == pass_wgs_per_cu(base + tab, W * (RP / 16));
+}
+
 // ------------------------------------------------------------------------------ n <= 8
 template <typename T, int N, int DIR>
 __global__ __launch_bounds__(256) void k_fft_tiny(FftIo<T> io, size_t batch)
@@ -414,7 +433,12 @@ __global__ __launch_bounds__(W * (RP / 16)) void k_fft_pass(FftIo<T> io, const c
     if ((tiles_per_vec & 7) == 0) tile = (tile & 7) * (tiles_per_vec >> 3) + (tile >> 3);
     const size_t j0 = tile * W;
     const size_t stride_in = n / RP;
-    auto tw = [&](int m) { return wtab[m]; };
+    constexpr bool LTW = pass_lds_twiddles<T, RP, W>();
+    cpx<T>* ltw = lds + (size_t)W * CS; // [RP] copy of the twiddle table (visible after the first barrier below)
+    if constexpr (LTW) {
+        for (int i = tid; i < RP; i += W * NT) ltw[i] = wtab[i];
+    }
+    auto tw = [&](int m) { return LTW ? ltw[m] : wtab[m]; };
 
     // ---- load (lanes along columns: W contiguous points per row)
     const int c = tid % W, ti = tid / W;
@@ -666,6 +690,7 @@ static int launch_pass(const FftIo<T>& io, const cpx<T>* src, cpx<T>* dst, size_
     BDSP_TRY(twiddle_table<T>(RP, &wtab));
     constexpr int THREADS = W * (RP / 16);
     size_t lds = (size_t)W * col_stride(RP, W) * sizeof(cpx<T>);
+    if (pass_lds_twiddles<T, RP, W>()) lds += (size_t)RP * sizeof(cpx<T>);
     size_t tiles = (n / RP) / W;
     dim3 grid((unsigned)(tiles * batch));
     const bool rowmap = nsg == 1; // the first pass
