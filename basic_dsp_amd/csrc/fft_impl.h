@@ -411,7 +411,11 @@ __device__ __forceinline__ cpx<double> unit_root<double>(size_t e, size_t n)
 // columns are contiguous).
 // GEN: fused options on the vector's input (first pass = the ROWMAP instantiation) or output (last
 // pass = a !ROWMAP instantiation), staged through LDS by a rolled loop like k_fft_wg<GEN>.
-template <typename T, int RP, int W, int DIR, bool ROWMAP, bool GEN>
+// SIMPLE: plain complex input without scale / window / shift / real input on the first pass and a plain complex output
+// on a later one -- the instantiation the headline transforms take.  The run-time option checks around the loads and
+// stores are then compiled out: the branches themselves are free, but hipcc's code around their merge points is not
+// (the same lesson as in conv_v2.hip).
+template <typename T, int RP, int W, int DIR, bool ROWMAP, bool GEN, bool SIMPLE = false>
 __global__ __launch_bounds__(W * (RP / 16)) void k_fft_pass(FftIo<T> io, const cpx<T>* __restrict__ src,
                                                    cpx<T>* __restrict__ dst,
                                                    const cpx<T>* __restrict__ wtab, size_t n,
@@ -456,8 +460,8 @@ __global__ __launch_bounds__(W * (RP / 16)) void k_fft_pass(FftIo<T> io, const c
     } else {
         const cpx<T>* in = src + vec * n + j;
         // first pass (ROWMAP): ifft_shift = the row index's top bit flipped = register r ^ 8's address
-        const int rx = (ROWMAP && (io.flags & BDSP_FFT_SHIFT_IN)) ? 8 : 0;
-        if (ROWMAP && (io.flags & FFT_IN_REAL)) {
+        const int rx = (!SIMPLE && ROWMAP && (io.flags & BDSP_FFT_SHIFT_IN)) ? 8 : 0;
+        if (!SIMPLE && ROWMAP && (io.flags & FFT_IN_REAL)) {
             // real input: `points` scalars per vector, imaginary parts are zero (time_to_freq.rs:147-150)
             const T* inr = reinterpret_cast<const T*>(io.in) + vec * io.in_stride + j;
 #pragma unroll
@@ -466,11 +470,11 @@ __global__ __launch_bounds__(W * (RP / 16)) void k_fft_pass(FftIo<T> io, const c
 #pragma unroll
             for (int r = 0; r < 16; ++r) v[r] = in[(size_t)(ti + (r ^ rx) * NT) * stride_in];
         }
-        if (ROWMAP && io.in_scale != (T)1) {
+        if (!SIMPLE && ROWMAP && io.in_scale != (T)1) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) v[r] = cpx<T>{v[r].x * io.in_scale, v[r].y * io.in_scale};
         }
-        if (ROWMAP && io.window_id == 1 && !(io.flags & FFT_WINDOW_OUT_DIV)) {
+        if (!SIMPLE && ROWMAP && io.window_id == 1 && !(io.flags & FFT_WINDOW_OUT_DIV)) {
             // generalised Hamming (Hamming, Hann) on the input, in registers: w = alpha - beta cos(2 pi i/(n-1)),
             // symmetric evaluation like the reference (vector_types/mod.rs:567-594)
             const T beta = (T)1 - io.window_alpha, two_over = (T)2 / ((T)n - (T)1);
@@ -484,7 +488,7 @@ __global__ __launch_bounds__(W * (RP / 16)) void k_fft_pass(FftIo<T> io, const c
             }
         }
     }
-    if (nsg > 1) {
+    if (!ROWMAP) { // (nsg > 1 exactly on the later passes)
         // inter-pass twiddle w_n^{row*q}, q = k * n/(nsg*RP); row = ti + r*NT
         const size_t k = j % nsg;
         const size_t q = k * (n / (nsg * RP));
@@ -544,8 +548,8 @@ __global__ __launch_bounds__(W * (RP / 16)) void k_fft_pass(FftIo<T> io, const c
     } else {
         cpx<T>* out = dst + vec * n + base;
         // last pass: fft_shift = the row index's top bit flipped; the last inner stage's digit r is that top digit
-        const int sx = (last && !ROWMAP && (io.flags & BDSP_FFT_SHIFT_OUT)) ? RL / 2 : 0;
-        if (last && !ROWMAP && (io.flags & (BDSP_FFT_MAGNITUDE | FFT_OUT_REAL))) {
+        const int sx = (!SIMPLE && last && !ROWMAP && (io.flags & BDSP_FFT_SHIFT_OUT)) ? RL / 2 : 0;
+        if (!SIMPLE && last && !ROWMAP && (io.flags & (BDSP_FFT_MAGNITUDE | FFT_OUT_REAL))) {
             // magnitude / real part straight from the registers: `points` reals per vector
             T* outr = reinterpret_cast<T*>(io.out) + vec * io.out_stride + base;
             const bool mag = (io.flags & BDSP_FFT_MAGNITUDE) != 0;
@@ -697,16 +701,19 @@ static int launch_pass(const FftIo<T>& io, const cpx<T>* src, cpx<T>* dst, size_
     const bool gen = (first && io_in_generic(io)) || (last && io_out_generic(io));
     if (first && !gen) src = reinterpret_cast<const cpx<T>*>(io.in);
     if (last && !gen) dst = reinterpret_cast<cpx<T>*>(io.out);
-#define BDSP_PASS(DIRV, RM, GENV)                                                                  \
+    // plain first / last pass?  (then no option is looked at inside the kernel)
+    const bool simple = !gen && (rowmap ? ((io.flags & (FFT_IN_REAL | BDSP_FFT_SHIFT_IN)) == 0 && io.in_scale == (T)1 && io.window_id < 0)
+                                        : (!last || (io.flags & (BDSP_FFT_SHIFT_OUT | BDSP_FFT_MAGNITUDE | FFT_OUT_REAL)) == 0));
+#define BDSP_PASS(DIRV, RM, GENV, SV)                                                              \
     do {                                                                                           \
-        BDSP_TRY(set_lds(k_fft_pass<T, RP, W, DIRV, RM, GENV>, lds));                              \
-        hipLaunchKernelGGL((k_fft_pass<T, RP, W, DIRV, RM, GENV>), grid, dim3(THREADS), lds, s,    \
+        BDSP_TRY(set_lds(k_fft_pass<T, RP, W, DIRV, RM, GENV, SV>, lds));                          \
+        hipLaunchKernelGGL((k_fft_pass<T, RP, W, DIRV, RM, GENV, SV>), grid, dim3(THREADS), lds, s, \
                            io, src, dst, wtab, n, nsg, tiles, (int)last);                          \
     } while (0)
 #define BDSP_PASS_D(DIRV)                                                                          \
     do {                                                                                           \
-        if (rowmap) { if (gen) BDSP_PASS(DIRV, true, true); else BDSP_PASS(DIRV, true, false); }   \
-        else { if (gen) BDSP_PASS(DIRV, false, true); else BDSP_PASS(DIRV, false, false); }        \
+        if (rowmap) { if (gen) BDSP_PASS(DIRV, true, true, false); else if (simple) BDSP_PASS(DIRV, true, false, true); else BDSP_PASS(DIRV, true, false, false); }   \
+        else { if (gen) BDSP_PASS(DIRV, false, true, false); else if (simple) BDSP_PASS(DIRV, false, false, true); else BDSP_PASS(DIRV, false, false, false); }        \
     } while (0)
     if (inverse) BDSP_PASS_D(1); else BDSP_PASS_D(-1);
 #undef BDSP_PASS_D
