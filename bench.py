@@ -106,6 +106,22 @@ def launch_ranks(args):
 
 
 # ------------------------------------------------------------------------------------------ CPU baseline
+def usable_cores():
+    """Host cores this process may actually run on: the affinity mask, cut down by a cgroup CPU quota if there is one
+    (os.cpu_count() reports the machine, not the container)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        n = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = max(1, min(n, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(points, taps, sample_points):
     """The oracle on the host cores, on a bounded prefix of the workload (~10-20 s in all):
       reference_schedule_1core  overlap_discard exactly as the reference schedules it (scalar head, O(N*M/2) scalar
@@ -119,7 +135,7 @@ def cpu_baseline(points, taps, sample_points):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as orc
     n = min(points, sample_points)
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     x = orc.fill_uniform(2 * n, 201601171, -10, 10, np.float32)
     h = orc.fill_uniform(2 * taps, 201601172, -1, 1, np.float32) / np.float32(taps)
     l = orc.next_power_of_two(taps)
@@ -141,6 +157,7 @@ def cpu_baseline(points, taps, sample_points):
     return {
         "value": fair_all, "unit": "Msamples/s", "cores": cores, "kind": "port",
         "sample": "%d-point prefix of the workload (convolve_signal with %d taps -> FFT), f32" % (n, taps),
+        "machine_logical_cores": os.cpu_count(),
         "reference_schedule_1core_Msamples_s": ref1,
         "fair_1core_Msamples_s": fair1,
         "fair_allcores_Msamples_s": fair_all,

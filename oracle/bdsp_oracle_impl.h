@@ -648,7 +648,28 @@ void SFX(orc_fft_pow2_mt)(REAL *data, size_t points, int inverse, int threads)
         w[k].re = (REAL)cos(a);
         w[k].im = (REAL)sin(a);
     }
-    for (size_t len = 2; len <= n; len <<= 1) {
+    /* stages that stay inside one of `parts` contiguous chunks: every thread runs all of them on its own chunks
+     * (cache-resident); the last log2(parts) stages span chunks and are spread butterfly by butterfly */
+    size_t parts = 1;
+    while (parts * 2 <= (size_t)threads && parts * 2 <= n / 2) parts *= 2;
+    size_t chunk = n / parts;
+#pragma omp parallel for num_threads(threads) schedule(static)
+    for (long long c = 0; c < (long long)parts; ++c) {
+        SFX(cpx) *xc = x + (size_t)c * chunk;
+        for (size_t len = 2; len <= chunk; len <<= 1) {
+            size_t half = len >> 1, stride = n / len;
+            for (size_t i = 0; i < chunk; i += len)
+                for (size_t k = 0; k < half; ++k) {
+                    SFX(cpx) u = xc[i + k];
+                    SFX(cpx) v = SFX(cmul)(xc[i + k + half], w[k * stride]);
+                    xc[i + k].re = u.re + v.re;
+                    xc[i + k].im = u.im + v.im;
+                    xc[i + k + half].re = u.re - v.re;
+                    xc[i + k + half].im = u.im - v.im;
+                }
+        }
+    }
+    for (size_t len = 2 * chunk; len <= n; len <<= 1) {
         size_t half = len >> 1, stride = n / len;
 #pragma omp parallel for num_threads(threads) schedule(static)
         for (long long j = 0; j < (long long)(n / 2); ++j) {
