@@ -28,7 +28,8 @@ size_t conv_fft_len(size_t) { return CONV_L; }
 // Grid: x = persistent workgroups walking the blocks of one vector with a grid stride,
 //       y = vector of the batch.  All per-vector indices are 32-bit (points < 2^31).
 //
-// What bounds this kernel (MI355X measurements: tools/conv_timeline.py, tools/ubench/*.hip):
+// What bounds this kernel (MI355X measurements: an in-kernel timeline, tools/ubench/*.hip; the complex f32 case now runs
+// conv_v2.hip, which documents what round 2 measured):
 //   * per block and CU the butterflies need 1.39 us of VALU (620 v_pk_* instructions per wave at
 //     ~4.4 clk each, saturated by ~2 waves per SIMD), the four LDS exchanges 1.16 us (64 KB each at
 //     ~110 B/clk per CU, saturated by ONE workgroup), the block's share of HBM 2.0 us -- and the three
