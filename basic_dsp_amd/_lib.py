@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libbasic_dsp_hip.so")
+LIB_PATH = os.environ.get("BDSP_HIP_LIBRARY") or os.path.join(_HERE, "lib", "libbasic_dsp_hip.so")  # (override: A/B runs of two builds)
 
 
 class BackendError(RuntimeError):

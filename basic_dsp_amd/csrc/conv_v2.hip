@@ -35,6 +35,11 @@
 #include "bdsp_internal.h"
 #include <cstdlib>
 
+// 1: stage-2 twiddles in a 2 KB LDS table (130 VGPRs), 0: in registers (164 VGPRs)
+#ifndef BDSP_CONV_TW2_LDS
+#define BDSP_CONV_TW2_LDS 1
+#endif
+
 namespace bdsp {
 
 constexpr int L2 = 4096;
@@ -73,7 +78,10 @@ __global__ __launch_bounds__(256, 3) void k_overlap_save_v2(ConvV2Args a)
     const unsigned ut = t;
     const float hscale = 1.0f / L;
     auto tww = [&](int mm) { return a.wtab[mm]; };
+    // stage-2 twiddles w256^((t & 15) r) in registers (the LDS table of the first generation cost 30 LDS reads per block
+    // inside the dependency chain: 62.1 -> 60.9 us in the lab), stage-3 twiddles as six values (w^r = w^(4a) w^b)
     C32 hreg[16], tw3a[3], tw3b[3];
+#if BDSP_CONV_TW2_LDS
     C32* tw2l = lds + F::LDS_ELEMS3;
     const C32* tw2p = tw2l + (t & 15) * 17;
     if (t < 240) {
@@ -82,6 +90,12 @@ __global__ __launch_bounds__(256, 3) void k_overlap_save_v2(ConvV2Args a)
     }
     F::template load_twiddles16_split<256>(tw3a, tw3b, t, tww);
     __syncthreads();
+#else
+    C32 tw2p[15];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) tw2p[r - 1] = a.wtab[16 * r * (t & 15)];
+    F::template load_twiddles16_split<256>(tw3a, tw3b, t, tww);
+#endif
 
     auto forward = [&](C32 (&v)[16]) {
         F::template compute<16, 1, -1>(v, t, tww);

@@ -248,6 +248,17 @@ def run_rank(args):
     # Untimed clock pre-warm: the GPU idles at a few hundred MHz and needs tens of milliseconds of load to reach its
     # sustained clock (*measured*: the same step runs 233 us right after start-up and 216 us once the clock has
     # settled).  Then the W warm-up steps of the contract.
+    # ... but first the COLD figure a caller's first milliseconds see: three steps to load the code objects and fill the
+    # workspace cache, a short idle, then twenty timed steps from the idle clock
+    for i in range(3):
+        step(i)
+    torch.cuda.synchronize()
+    time.sleep(0.05)
+    t_cold = time.perf_counter()
+    for i in range(20):
+        step(i)
+    torch.cuda.synchronize()
+    cold_ms = (time.perf_counter() - t_cold) / 20 * 1e3
     t_pre = time.perf_counter()
     pre = 0
     while time.perf_counter() - t_pre < args.prewarm:
@@ -334,6 +345,7 @@ def run_rank(args):
                 "workload": workload,
                 "points": n, "taps": m, "vectors_per_gpu": nvec, "input_buffers_rotated": len(xs),
                 "untimed_clock_prewarm_s": args.prewarm, "untimed_prewarm_steps": pre,
+                "cold_ms_per_step_first_20_steps_after_idle": cold_ms,
                 "steps_with_kernel_events": len(events),
                 "parallelism": "independent vectors per GPU, no data-path collective",
             },

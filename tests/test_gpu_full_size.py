@@ -5,6 +5,8 @@ The oracle cannot produce a full 16M-point x 1024-tap convolution in seconds, so
 16M-point convolution, single DFT bins) with (b) size-independent properties: round trips, Parseval,
 linearity, shift identities.  Tolerances are north_star's: 1e-6 rel-L2 for f32, 1e-12 for f64.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -195,3 +197,30 @@ def test_f64_and_real_convolution_4m_whole_output():
         for first in (0, n // 3, n - 4096):
             ref = orc.convolve_direct(xr.astype(np.float64), hr.astype(np.float64), False, first, 4096)
             assert rel_l2(yr[first:first + 4096], ref) < tol, (dtype, first)
+
+
+@pytest.mark.gpu
+def test_bench_py_runs_both_modes_and_prints_the_contract_fields():
+    """bench.py end to end on this GPU (few steps): the headline mode and --mode c5, one JSON line each with the
+    contract's fields, `roofline` and (headline) `cpu_baseline`; `--gpus 1` is accepted as the driver passes it."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "16", "--warmup", "2",
+                        "--prewarm", "0.02", "--cpu-sample-points", str(1 << 18)], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = json.loads(p.stdout.strip().splitlines()[-1])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "ranks_seen"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["ranks_seen"] == 1 and d["steps"] == 16 and d["value"] > 1000
+    assert d["roofline"]["bound"] == "hbm" and 0.05 < d["roofline"]["frac"] < 1.0
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["fair_allcores_Msamples_s"] > 0
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--mode", "c5", "--steps", "4", "--warmup", "1",
+                        "--prewarm", "0.02", "--vectors-per-gpu", "16", "--no-cpu-baseline"], env=env, capture_output=True,
+                       text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = json.loads(p.stdout.strip().splitlines()[-1])
+    assert d["config"]["vectors_per_gpu"] == 16 and d["c5_end_to_end"]["vectors"] == 16 and d["c5_end_to_end"]["ms"] > 0

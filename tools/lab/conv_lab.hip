@@ -388,7 +388,7 @@ __global__ __launch_bounds__(256, WPC) void k_v2(Args a, unsigned nb_lo, unsigne
     C* const pw = priv + 272 * (lane >> 4) + (lane & 15);
     const C* const pr = priv + 272 * (lane >> 4) + 17 * (lane & 15);
     if constexpr (CORE == 0 || CORE == 2) {
-        if constexpr (TWR & 1) {
+        if constexpr ((TWR & 1) != 0) {
 #pragma unroll
             for (int r = 1; r < 16; ++r) tw2r[r - 1] = a.wtab[16 * r * (t & 15)];
         } else {
@@ -422,16 +422,22 @@ __global__ __launch_bounds__(256, WPC) void k_v2(Args a, unsigned nb_lo, unsigne
     }
     auto forward = [&](C (&v)[16]) {
         if constexpr (CORE == 2) {
+            constexpr int PX = (TWR & 4) ? 2 : ((TWR & 8) ? 0 : -1), PC = (TWR & 4) ? 0 : ((TWR & 8) ? 2 : -1);
+            if constexpr (PC >= 0) __builtin_amdgcn_s_setprio(PC);
             F::template compute<16, 1, -1>(v, t, tww);
+            if constexpr (PX >= 0) __builtin_amdgcn_s_setprio(PX);
             __syncthreads();
             F::scatter_a3(v, t, lds);
             __syncthreads();
             F::gather_a3(v, t, lds);
+            if constexpr (PC >= 0) __builtin_amdgcn_s_setprio(PC);
             F::template compute_pre<16, 16, -1>(v, tw2p);
+            if constexpr (PX >= 0) __builtin_amdgcn_s_setprio(PX);
             __syncthreads();
             F::scatter_b3(v, t, lds);
             __syncthreads();
             F::gather_b(v, t, lds);
+            if constexpr (PC >= 0) __builtin_amdgcn_s_setprio(PC);
             F::template compute_pre16_split<256, -1>(v, tw3a, tw3b);
         } else if constexpr (CORE == 0) {
             F::template compute<16, 1, -1>(v, t, tww);
@@ -468,16 +474,22 @@ __global__ __launch_bounds__(256, WPC) void k_v2(Args a, unsigned nb_lo, unsigne
     };
     auto inverse = [&](C (&v)[16]) {
         if constexpr (CORE == 2) {
+            constexpr int PX = (TWR & 4) ? 2 : ((TWR & 8) ? 0 : -1), PC = (TWR & 4) ? 0 : ((TWR & 8) ? 2 : -1);
+            if constexpr (PC >= 0) __builtin_amdgcn_s_setprio(PC);
             F::template compute<16, 1, 1>(v, t, tww);
+            if constexpr (PX >= 0) __builtin_amdgcn_s_setprio(PX);
             __syncthreads();
             F::scatter_a3(v, t, lds);
             __syncthreads();
             F::gather_a3(v, t, lds);
+            if constexpr (PC >= 0) __builtin_amdgcn_s_setprio(PC);
             F::template compute_pre<16, 16, 1>(v, tw2p);
+            if constexpr (PX >= 0) __builtin_amdgcn_s_setprio(PX);
             __syncthreads();
             F::scatter_b3(v, t, lds);
             __syncthreads();
             F::gather_b(v, t, lds);
+            if constexpr (PC >= 0) __builtin_amdgcn_s_setprio(PC);
             F::template compute_pre16_split<256, 1>(v, tw3a, tw3b);
         } else if constexpr (CORE == 0) {
             F::template compute<16, 1, 1>(v, t, tww);
@@ -874,6 +886,9 @@ int main(int argc, char** argv)
         {"v2 st tw0 4 rounds 9/7/4", (const void*)k_v2<0, 4, 0, 1000000 + 90704, 4>, true, 4, lds_base, 4},
         {"v2 st tw0 4 rounds 6/6/5", (const void*)k_v2<0, 4, 0, 1000000 + 60605, 4>, true, 4, lds_base, 4},
         {"v2 L3 tw0 3 rounds 9/8", (const void*)k_v2<2, 4, 0, 2000 + 908, 3>, true, 3, lds_l3, 4},
+        {"v2 L3 prioX 3 rounds 9/8", (const void*)k_v2<2, 4, 4, 2000 + 908, 3>, true, 3, lds_l3, 4},
+        {"v2 L3 prioC 3 rounds 9/8", (const void*)k_v2<2, 4, 8, 2000 + 908, 3>, true, 3, lds_l3, 4},
+        {"v2 L3 prioX 3 even", (const void*)k_v2<2, 4, 4, 0, 3>, true, 3, lds_l3, 4},
         {"v2 L3 tw0 3 even", (const void*)k_v2<2, 4, 0, 0, 3>, true, 3, lds_l3, 4},
         {"v2 st tw0 3 rounds 9/7", (const void*)k_v2<0, 4, 0, 2000 + 907, 3>, true, 3, lds_base, 4},
         {"v2 st tw3 2 rounds 12", (const void*)k_v2<0, 4, 3, 2000 + 1200, 2>, true, 2, lds_base, 4},
