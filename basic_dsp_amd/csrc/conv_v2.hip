@@ -80,7 +80,10 @@ __global__ __launch_bounds__(256, 3) void k_overlap_save_v2(ConvV2Args a)
     auto tww = [&](int mm) { return a.wtab[mm]; };
     // stage-2 twiddles w256^((t & 15) r) in registers (the LDS table of the first generation cost 30 LDS reads per block
     // inside the dependency chain: 62.1 -> 60.9 us in the lab), stage-3 twiddles as six values (w^r = w^(4a) w^b)
-    C32 hreg[16], tw3a[3], tw3b[3];
+    // stage-3 twiddles w4096^(t r), r = 1..15, all in registers: the six-value split of the first generation (w^r =
+    // w^(4a) w^b) cost nine extra multiplies per transform -- 62.0 -> 60.6 us in the lab, and the kernel still fits three
+    // workgroups per CU (164 VGPRs)
+    C32 hreg[16], tw3[15];
 #if BDSP_CONV_TW2_LDS
     C32* tw2l = lds + F::LDS_ELEMS3;
     const C32* tw2p = tw2l + (t & 15) * 17;
@@ -88,13 +91,13 @@ __global__ __launch_bounds__(256, 3) void k_overlap_save_v2(ConvV2Args a)
         int k = t / 15, r = t % 15 + 1;
         tw2l[k * 17 + r - 1] = a.wtab[r * k * 16];
     }
-    F::template load_twiddles16_split<256>(tw3a, tw3b, t, tww);
+    F::template load_twiddles<16, 256>(tw3, t, tww);
     __syncthreads();
 #else
     C32 tw2p[15];
 #pragma unroll
     for (int r = 1; r < 16; ++r) tw2p[r - 1] = a.wtab[16 * r * (t & 15)];
-    F::template load_twiddles16_split<256>(tw3a, tw3b, t, tww);
+    F::template load_twiddles<16, 256>(tw3, t, tww);
 #endif
 
     auto forward = [&](C32 (&v)[16]) {
@@ -108,7 +111,7 @@ __global__ __launch_bounds__(256, 3) void k_overlap_save_v2(ConvV2Args a)
         F::scatter_b3(v, t, lds);
         __syncthreads();
         F::gather_b(v, t, lds);
-        F::template compute_pre16_split<256, -1>(v, tw3a, tw3b);
+        F::template compute_pre<16, 256, -1>(v, tw3);
     };
     auto inverse = [&](C32 (&v)[16]) {
         F::template compute<16, 1, 1>(v, t, tww);
@@ -121,7 +124,7 @@ __global__ __launch_bounds__(256, 3) void k_overlap_save_v2(ConvV2Args a)
         F::scatter_b3(v, t, lds);
         __syncthreads();
         F::gather_b(v, t, lds);
-        F::template compute_pre16_split<256, 1>(v, tw3a, tw3b);
+        F::template compute_pre<16, 256, 1>(v, tw3);
     };
 
     // ---- the filter spectrum, delayed by d samples, x 1/L, in register r of thread t: H'[t + 256 r]

@@ -438,7 +438,7 @@ __global__ __launch_bounds__(256, WPC) void k_v2(Args a, unsigned nb_lo, unsigne
             __syncthreads();
             F::gather_b(v, t, lds);
             if constexpr (PC >= 0) __builtin_amdgcn_s_setprio(PC);
-            F::template compute_pre16_split<256, -1>(v, tw3a, tw3b);
+            if constexpr (TWR & 2) F::template compute_pre<16, 256, -1>(v, tw3r); else F::template compute_pre16_split<256, -1>(v, tw3a, tw3b);
         } else if constexpr (CORE == 0) {
             F::template compute<16, 1, -1>(v, t, tww);
             __syncthreads();
@@ -490,7 +490,7 @@ __global__ __launch_bounds__(256, WPC) void k_v2(Args a, unsigned nb_lo, unsigne
             __syncthreads();
             F::gather_b(v, t, lds);
             if constexpr (PC >= 0) __builtin_amdgcn_s_setprio(PC);
-            F::template compute_pre16_split<256, 1>(v, tw3a, tw3b);
+            if constexpr (TWR & 2) F::template compute_pre<16, 256, 1>(v, tw3r); else F::template compute_pre16_split<256, 1>(v, tw3a, tw3b);
         } else if constexpr (CORE == 0) {
             F::template compute<16, 1, 1>(v, t, tww);
             __syncthreads();
@@ -889,6 +889,8 @@ int main(int argc, char** argv)
         {"v2 L3 prioX 3 rounds 9/8", (const void*)k_v2<2, 4, 4, 2000 + 908, 3>, true, 3, lds_l3, 4},
         {"v2 L3 prioC 3 rounds 9/8", (const void*)k_v2<2, 4, 8, 2000 + 908, 3>, true, 3, lds_l3, 4},
         {"v2 L3 prioX 3 even", (const void*)k_v2<2, 4, 4, 0, 3>, true, 3, lds_l3, 4},
+        {"v2 L3 tw3full 3 rounds 9/8", (const void*)k_v2<2, 4, 2, 2000 + 908, 3>, true, 3, lds_l3, 4},
+        {"v2 L3 tw3full 3 rounds 10/8", (const void*)k_v2<2, 4, 2, 2000 + 1008, 3>, true, 3, lds_l3, 4},
         {"v2 L3 tw0 3 even", (const void*)k_v2<2, 4, 0, 0, 3>, true, 3, lds_l3, 4},
         {"v2 st tw0 3 rounds 9/7", (const void*)k_v2<0, 4, 0, 2000 + 907, 3>, true, 3, lds_base, 4},
         {"v2 st tw3 2 rounds 12", (const void*)k_v2<0, 4, 3, 2000 + 1200, 2>, true, 2, lds_base, 4},
