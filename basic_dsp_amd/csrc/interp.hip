@@ -152,6 +152,24 @@ __global__ __launch_bounds__(256) void k_interp_inner(const T* __restrict__ x, T
 #pragma unroll
         for (int s = 0; s < FACTOR; ++s) { ar[k][s] = 0; ai[k][s] = 0; }
     // position q = q0 + QB*t + k; local index of x[n] in lx: n - xbase = QB*t + k + j, j = 0 .. 2L+1
+    if constexpr (QB == 1) {
+        // one position per thread: step j needs just x[t + j] -- one LDS read per step, no sliding window to shuffle
+        // (the generic loop below spent 8 of its 24 vector instructions per two steps on register moves and two
+        // branches on its conditional last read).  2L + 2 steps: always an even count.
+#pragma unroll 2
+        for (int j = 0; j <= 2 * conv_len + 1; ++j) {
+            const T xr = lx[(t + j) * E];
+            const T xi = CPLX ? lx[(t + j) * E + 1] : (T)0;
+            T w[FACTOR];
+#pragma unroll
+            for (int s = 0; s < FACTOR; ++s) w[s] = lt[j * FACTOR + s];
+#pragma unroll
+            for (int s = 0; s < FACTOR; ++s) {
+                ar[0][s] = dev_fma<T>(xr, w[s], ar[0][s]);
+                if (CPLX) ai[0][s] = dev_fma<T>(xi, w[s], ai[0][s]);
+            }
+        }
+    } else {
     T wr[QB], wi[QB]; // sliding window x[QB*t + k + j], k = 0..QB-1
 #pragma unroll
     for (int k = 0; k < QB; ++k) {
@@ -180,6 +198,7 @@ __global__ __launch_bounds__(256) void k_interp_inner(const T* __restrict__ x, T
             wr[QB - 1] = lx[nx];
             wi[QB - 1] = CPLX ? lx[nx + 1] : (T)0;
         }
+    }
     }
 #pragma unroll
     for (int k = 0; k < QB; ++k)
@@ -337,12 +356,21 @@ int interpolatef_dev(const T* in, T* out, size_t len, bool is_complex, int fid, 
         long long q_hi = ((long long)new_points - scalar_len) / f;   // f*q + f - 1 < new_points - scalar_len
         const bool blocked = (f == 2 || f == 3 || f == 4 || f == 8) && q_hi > q_lo &&
                              (long long)new_points >= 2 * scalar_len;
+        // with the inner region left to the blocked kernel only the two edge runs remain here: size the grid for them
+        // (a 2048-workgroup launch for a few hundred outputs cost 5 us of the 88 us of config C4b)
+        size_t eblocks = blocks;
+        if (blocked) {
+            const size_t edge_outputs = new_points - (size_t)((q_hi - q_lo) * f);
+            eblocks = (edge_outputs + 255) / 256;
+            if (eblocks > blocks) eblocks = blocks;
+            if (eblocks < 1) eblocks = 1;
+        }
         if (is_complex)
-            hipLaunchKernelGGL((k_interp_table<T, true>), dim3((unsigned)blocks), dim3(256), lds, s, in, out,
+            hipLaunchKernelGGL((k_interp_table<T, true>), dim3((unsigned)eblocks), dim3(256), lds, s, in, out,
                                tb.as<T>(), (long long)points, (long long)new_points, (int)conv_len, f,
                                blocked ? q_lo * f : -1LL, blocked ? q_hi * f : -1LL);
         else
-            hipLaunchKernelGGL((k_interp_table<T, false>), dim3((unsigned)blocks), dim3(256), lds, s, in, out,
+            hipLaunchKernelGGL((k_interp_table<T, false>), dim3((unsigned)eblocks), dim3(256), lds, s, in, out,
                                tb.as<T>(), (long long)points, (long long)new_points, (int)conv_len, f,
                                blocked ? q_lo * f : -1LL, blocked ? q_hi * f : -1LL);
         if (blocked) {
