@@ -103,10 +103,11 @@ int convolve_direct(const T* in, T* out, size_t points, size_t batch, const T* t
 size_t conv_fft_len(size_t taps);
 // block step (valid outputs per 4096-point block) of the kernel conv_run_blocks<T> will use for these taps
 template <typename T> size_t conv_block_step(size_t points, size_t taps, bool real_data);
-// conv_v2.hip: the second-generation block kernel (complex f32)
+// conv_v2.hip: the second-generation block kernel (complex f32 and f64)
 size_t conv_v2_block_step(size_t taps);
 bool conv_v2_applies(size_t points, size_t taps);
-int conv_v2_run(const float* in, float* out, size_t points, size_t batch, const float* hs, size_t taps,
+template <typename T>
+int conv_v2_run(const T* in, T* out, size_t points, size_t batch, const T* hs, size_t taps,
                 size_t first_block, size_t nblocks, bool hs_is_taps, hipStream_t s);
 template <typename T>
 int conv_prepare_spectrum(const T* taps_dev, size_t taps, const T* h_freq_dev, T* hs, hipStream_t s);

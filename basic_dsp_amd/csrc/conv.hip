@@ -371,9 +371,7 @@ int conv_prepare_spectrum(const T* taps_dev, size_t taps, const T* h_freq_dev, T
 template <typename T>
 size_t conv_block_step(size_t points, size_t taps, bool real_data)
 {
-    if constexpr (sizeof(T) == 4) {
-        if (!real_data && conv_v2_applies(points, taps)) return conv_v2_block_step(taps);
-    }
+    if (!real_data && conv_v2_applies(points, taps)) return conv_v2_block_step(taps);
     size_t V = (size_t)CONV_L - (taps - 1);
     if (real_data) { if (V >= 32) V &= ~(size_t)31; }
     else if (V >= 16) V &= ~(size_t)15;
@@ -388,13 +386,11 @@ int conv_run_blocks(const T* in, T* out, size_t points, size_t batch, const T* h
                     hipStream_t s, bool real_data, bool hs_is_taps)
 {
     constexpr int L = CONV_L;
-    if constexpr (sizeof(T) == 4) {
-        // complex f32: the second-generation kernel (conv_v2.hip) whenever the call is a run of whole blocks
-        if (!real_data && !last_block_out && taps >= 1 && taps - 1 <= 3 * (size_t)L / 4 && conv_v2_applies(points, taps)) {
-            const long long V2 = (long long)conv_v2_block_step(taps);
-            if (out_off >= 0 && out_off % V2 == 0 && in_off + (long long)(taps / 2) == out_off)
-                return conv_v2_run(in, out, points, batch, hs, taps, (size_t)(out_off / V2), nblocks_limit, hs_is_taps, s);
-        }
+    // complex data: the second-generation kernel (conv_v2.hip) whenever the call is a run of whole blocks
+    if (!real_data && !last_block_out && taps >= 1 && taps - 1 <= 3 * (size_t)L / 4 && conv_v2_applies(points, taps)) {
+        const long long V2 = (long long)conv_v2_block_step(taps);
+        if (out_off >= 0 && out_off % V2 == 0 && in_off + (long long)(taps / 2) == out_off)
+            return conv_v2_run<T>(in, out, points, batch, hs, taps, (size_t)(out_off / V2), nblocks_limit, hs_is_taps, s);
     }
     if (taps == 0 || taps - 1 > 3 * (size_t)L / 4 || points == 0) {
         set_last_error("convolve_overlap_save: taps out of range for the block kernel");

@@ -36,6 +36,12 @@
 #include <cstdlib>
 
 // 1: stage-2 twiddles in a 2 KB LDS table (130 VGPRs), 0: in registers (164 VGPRs)
+#ifndef BDSP_CONV_NT_LOADS
+#define BDSP_CONV_NT_LOADS 0
+#endif
+#ifndef BDSP_CONV_NT_STORES
+#define BDSP_CONV_NT_STORES 0
+#endif
 #ifndef BDSP_CONV_TW2_LDS
 #define BDSP_CONV_TW2_LDS 1
 #endif
@@ -43,13 +49,13 @@
 namespace bdsp {
 
 constexpr int L2 = 4096;
-using C32 = cpx<float>;
 
+template <typename T>
 struct ConvV2Args {
-    const C32* x;
-    C32* y;
-    const C32* hs;   // taps (hs_is_taps) or the UNSCALED, undelayed L-point spectrum of the taps
-    const C32* wtab; // exp(-2 pi i m / 4096)
+    const cpx<T>* x;
+    cpx<T>* y;
+    const cpx<T>* hs;   // taps (hs_is_taps) or the UNSCALED, undelayed L-point spectrum of the taps
+    const cpx<T>* wtab; // exp(-2 pi i m / 4096)
     unsigned n;      // points per vector
     unsigned taps;
     unsigned b_first, b_end; // blocks of each vector to compute
@@ -57,6 +63,7 @@ struct ConvV2Args {
     unsigned batch;
     unsigned na, nbb;        // interior blocks (all vectors together) given to dispatch groups 0 and 1
     int hs_is_taps;
+    unsigned groups;         // dispatch groups = workgroups per CU: 3 (f32), 2 (f64)
 };
 
 static __device__ __forceinline__ unsigned xcd_contiguous(unsigned bid, unsigned g)
@@ -66,65 +73,63 @@ static __device__ __forceinline__ unsigned xcd_contiguous(unsigned bid, unsigned
     return (g & 7) == 0 ? (bid & 7) * (g >> 3) + (bid >> 3) : bid;
 }
 
-template <int R0, bool BATCHED>
-__global__ __launch_bounds__(256, 3) void k_overlap_save_v2(ConvV2Args a)
+// f64 (round 2, late): the same structure with TWO workgroups per CU (74 KB of LDS and 240 registers each), two dispatch
+// groups, the generic padded exchange layouts and the six-value split of the stage-3 twiddles (fifteen would not fit).
+template <typename T, int R0, bool BATCHED>
+__global__ __launch_bounds__(256, sizeof(T) == 4 ? 3 : 2) void k_overlap_save_v2(ConvV2Args<T> a)
 {
     constexpr int L = L2;
     constexpr unsigned V = L - 256 * R0, OV = 256 * R0;
-    using F = WgFft<float, L, 256>;
+    constexpr bool F32 = sizeof(T) == 4;
+    using C32 = cpx<T>;
+    using F = WgFft<T, L, 256>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     C32* lds = reinterpret_cast<C32*>(smem_raw);
     const int t = threadIdx.x;
     const unsigned ut = t;
-    const float hscale = 1.0f / L;
+    const T hscale = (T)1 / (T)L;
     auto tww = [&](int mm) { return a.wtab[mm]; };
     // stage-2 twiddles w256^((t & 15) r) in registers (the LDS table of the first generation cost 30 LDS reads per block
     // inside the dependency chain: 62.1 -> 60.9 us in the lab), stage-3 twiddles as six values (w^r = w^(4a) w^b)
-    // stage-3 twiddles w4096^(t r), r = 1..15, all in registers: the six-value split of the first generation (w^r =
+    // stage-3 twiddles w4096^(t r), r = 1..15, all in registers (f32): the six-value split of the first generation (w^r =
     // w^(4a) w^b) cost nine extra multiplies per transform -- 62.0 -> 60.6 us in the lab, and the kernel still fits three
-    // workgroups per CU (164 VGPRs)
-    C32 hreg[16], tw3[15];
-#if BDSP_CONV_TW2_LDS
-    C32* tw2l = lds + F::LDS_ELEMS3;
+    // workgroups per CU (166 VGPRs).  f64 keeps the split.  Stage-2 twiddles: a 2 KB LDS table (registers measured equal).
+    C32 hreg[16], tw3[F32 ? 15 : 1], tw3a[3], tw3b[3];
+    C32* tw2l = lds + (F32 ? F::LDS_ELEMS3 : F::LDS_ELEMS);
     const C32* tw2p = tw2l + (t & 15) * 17;
     if (t < 240) {
         int k = t / 15, r = t % 15 + 1;
         tw2l[k * 17 + r - 1] = a.wtab[r * k * 16];
     }
-    F::template load_twiddles<16, 256>(tw3, t, tww);
+    if constexpr (F32) F::template load_twiddles<16, 256>(tw3, t, tww);
+    else F::template load_twiddles16_split<256>(tw3a, tw3b, t, tww);
     __syncthreads();
-#else
-    C32 tw2p[15];
-#pragma unroll
-    for (int r = 1; r < 16; ++r) tw2p[r - 1] = a.wtab[16 * r * (t & 15)];
-    F::template load_twiddles<16, 256>(tw3, t, tww);
-#endif
 
     auto forward = [&](C32 (&v)[16]) {
         F::template compute<16, 1, -1>(v, t, tww);
         __syncthreads(); // the previous transform's last gather is done
-        F::scatter_a3(v, t, lds);
+        if constexpr (F32) F::scatter_a3(v, t, lds); else F::scatter_a(v, t, lds);
         __syncthreads();
-        F::gather_a3(v, t, lds);
+        if constexpr (F32) F::gather_a3(v, t, lds); else F::gather_a(v, t, lds);
         F::template compute_pre<16, 16, -1>(v, tw2p);
         __syncthreads();
-        F::scatter_b3(v, t, lds);
+        if constexpr (F32) F::scatter_b3(v, t, lds); else F::scatter_b(v, t, lds);
         __syncthreads();
         F::gather_b(v, t, lds);
-        F::template compute_pre<16, 256, -1>(v, tw3);
+        if constexpr (F32) F::template compute_pre<16, 256, -1>(v, tw3); else F::template compute_pre16_split<256, -1>(v, tw3a, tw3b);
     };
     auto inverse = [&](C32 (&v)[16]) {
         F::template compute<16, 1, 1>(v, t, tww);
         __syncthreads();
-        F::scatter_a3(v, t, lds);
+        if constexpr (F32) F::scatter_a3(v, t, lds); else F::scatter_a(v, t, lds);
         __syncthreads();
-        F::gather_a3(v, t, lds);
+        if constexpr (F32) F::gather_a3(v, t, lds); else F::gather_a(v, t, lds);
         F::template compute_pre<16, 16, 1>(v, tw2p);
         __syncthreads();
-        F::scatter_b3(v, t, lds);
+        if constexpr (F32) F::scatter_b3(v, t, lds); else F::scatter_b(v, t, lds);
         __syncthreads();
         F::gather_b(v, t, lds);
-        F::template compute_pre<16, 256, 1>(v, tw3);
+        if constexpr (F32) F::template compute_pre<16, 256, 1>(v, tw3); else F::template compute_pre16_split<256, 1>(v, tw3a, tw3b);
     };
 
     // ---- the filter spectrum, delayed by d samples, x 1/L, in register r of thread t: H'[t + 256 r]
@@ -134,7 +139,7 @@ __global__ __launch_bounds__(256, 3) void k_overlap_save_v2(ConvV2Args a)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const unsigned i = ut + 256u * r;
-            hv[r] = (i >= d && i - d < a.taps) ? a.hs[i - d] : C32{0.0f, 0.0f};
+            hv[r] = (i >= d && i - d < a.taps) ? a.hs[i - d] : C32{(T)0, (T)0};
         }
         forward(hv);
 #pragma unroll
@@ -193,12 +198,12 @@ __global__ __launch_bounds__(256, 3) void k_overlap_save_v2(ConvV2Args a)
             }
         }
     }
-    // ---- interior blocks: three dispatch groups with skewed shares (see the header)
-    const unsigned ni = a.nb_hi - a.nb_lo, total = ni * a.batch, gs = G / 3;
+    // ---- interior blocks: dispatch groups (one workgroup of each per CU) with skewed shares (see the header)
+    const unsigned ni = a.nb_hi - a.nb_lo, total = ni * a.batch, gs = G / a.groups;
     const unsigned grp = blockIdx.x / gs;
-    if (grp >= 3) return;
+    if (grp >= a.groups) return;
     const unsigned lo = grp == 0 ? 0u : (grp == 1 ? a.na : a.na + a.nbb);
-    const unsigned hi = grp == 0 ? a.na : (grp == 1 ? a.na + a.nbb : total);
+    const unsigned hi = grp == 0 ? a.na : ((grp == 1 && a.groups == 3) ? a.na + a.nbb : total);
     const unsigned w2 = xcd_contiguous(blockIdx.x - grp * gs, gs);
     for (unsigned id = lo + w2; id < hi; id += gs) {
         unsigned vec = 0, b = a.nb_lo + id;
@@ -207,21 +212,35 @@ __global__ __launch_bounds__(256, 3) void k_overlap_save_v2(ConvV2Args a)
         C32* yb = a.y + ((size_t)vec * a.n + ((long long)b * V - OV));
         C32 v[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) v[r] = xb[ut + 256u * r];
+        for (int r = 0; r < 16; ++r) {
+#if BDSP_CONV_NT_LOADS
+            v[r] = __builtin_nontemporal_load(&xb[ut + 256u * r]);
+#else
+            v[r] = xb[ut + 256u * r];
+#endif
+        }
         transform(v);
 #pragma unroll
-        for (int r = R0; r < 16; ++r) yb[ut + 256u * r] = v[r];
+        for (int r = R0; r < 16; ++r) {
+#if BDSP_CONV_NT_STORES
+            __builtin_nontemporal_store(v[r], &yb[ut + 256u * r]);
+#else
+            yb[ut + 256u * r] = v[r];
+#endif
+        }
     }
 }
 
-template <int R0>
-static int launch_v2(const ConvV2Args& a, unsigned grid, size_t lds, hipStream_t s)
+template <typename T, int R0>
+static int launch_v2(const ConvV2Args<T>& a, unsigned grid, size_t lds, hipStream_t s)
 {
     if (a.batch > 1) {
-        auto kern = k_overlap_save_v2<R0, true>;
+        auto kern = k_overlap_save_v2<T, R0, true>;
+        if (lds > 64 * 1024) BDSP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, a);
     } else {
-        auto kern = k_overlap_save_v2<R0, false>;
+        auto kern = k_overlap_save_v2<T, R0, false>;
+        if (lds > 64 * 1024) BDSP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, a);
     }
     BDSP_LAUNCH_CHECK();
@@ -242,11 +261,12 @@ bool conv_v2_applies(size_t points, size_t taps)
 }
 
 // Blocks [first_block, first_block + nblocks) (nblocks = 0: all from first_block on) of every vector of the batch.
-int conv_v2_run(const float* in, float* out, size_t points, size_t batch, const float* hs, size_t taps,
+template <typename T>
+int conv_v2_run(const T* in, T* out, size_t points, size_t batch, const T* hs, size_t taps,
                 size_t first_block, size_t nblocks, bool hs_is_taps, hipStream_t s)
 {
-    const cpx<float>* wtab;
-    BDSP_TRY(twiddle_table<float>(L2, &wtab));
+    const cpx<T>* wtab;
+    BDSP_TRY(twiddle_table<T>(L2, &wtab));
     const unsigned r0 = taps <= 1 ? 1u : (unsigned)((taps - 1 + 255) / 256);
     const long long V = L2 - 256 * (long long)r0;
     const long long nb_all = ((long long)points + V - 1) / V;
@@ -262,10 +282,12 @@ int conv_v2_run(const float* in, float* out, size_t points, size_t batch, const 
         set_last_error("convolve_overlap_save: too many blocks");
         return BDSP_ERR_UNSUPPORTED;
     }
-    ConvV2Args a{};
-    a.x = reinterpret_cast<const cpx<float>*>(in);
-    a.y = reinterpret_cast<cpx<float>*>(out);
-    a.hs = reinterpret_cast<const cpx<float>*>(hs);
+    constexpr unsigned GROUPS = sizeof(T) == 4 ? 3 : 2;
+    ConvV2Args<T> a{};
+    a.groups = GROUPS;
+    a.x = reinterpret_cast<const cpx<T>*>(in);
+    a.y = reinterpret_cast<cpx<T>*>(out);
+    a.hs = reinterpret_cast<const cpx<T>*>(hs);
     a.wtab = wtab;
     a.n = (unsigned)points;
     a.taps = (unsigned)taps;
@@ -273,29 +295,31 @@ int conv_v2_run(const float* in, float* out, size_t points, size_t batch, const 
     a.nb_lo = (unsigned)lo; a.nb_hi = (unsigned)hi;
     a.batch = (unsigned)batch;
     a.hs_is_taps = hs_is_taps ? 1 : 0;
-    // grid: three workgroups per CU, a multiple of 24 so that the three dispatch groups are multiples of 8
+    // grid: GROUPS workgroups per CU, a multiple of 8 * GROUPS so that every dispatch group is a multiple of 8
     const unsigned long long interior = (unsigned long long)(hi - lo) * batch;
     const unsigned long long wrap = (unsigned long long)((lo - b0) + (b1 - hi)) * batch;
-    unsigned grid = (unsigned)num_cus() * 3;
-    grid -= grid % 24;
-    if (grid < 24) grid = 24;
+    constexpr unsigned Q = 8 * GROUPS;
+    unsigned grid = (unsigned)num_cus() * GROUPS;
+    grid -= grid % Q;
+    if (grid < Q) grid = Q;
     if (interior + wrap < grid) { // a small problem: no more workgroups than blocks (each one transforms the taps first)
-        grid = (unsigned)((interior + wrap + 23) / 24 * 24);
-        if (grid < 24) grid = 24;
+        grid = (unsigned)((interior + wrap + Q - 1) / Q * Q);
+        if (grid < Q) grid = Q;
     }
-    const unsigned gs = grid / 3;
-    // shares in whole rounds of gs blocks: ~43 % / ~37 % / rest (measured optimum 9 / 8 / 4.3 rounds of 21.3)
+    const unsigned gs = grid / GROUPS;
+    // shares in whole rounds of gs blocks.  Three groups: ~43 % / ~37 % / rest (measured optimum 9 / 8 / 4.3 rounds of
+    // 21.3); two groups: ~55 % / rest (12 of 21.3 rounds measured best for two workgroups per CU)
     const unsigned long long rounds = (interior + gs - 1) / gs;
-    unsigned long long ra = (rounds * 43 + 50) / 100, rb = (rounds * 37 + 50) / 100;
+    unsigned long long ra = (rounds * (GROUPS == 3 ? 43 : 55) + 50) / 100, rb = GROUPS == 3 ? (rounds * 37 + 50) / 100 : 0;
     if (rounds && ra == 0) ra = 1;
     unsigned long long na = ra * gs, nbb = rb * gs;
     if (na > interior) na = interior;
     if (na + nbb > interior) nbb = interior - na;
     a.na = (unsigned)na;
     a.nbb = (unsigned)nbb;
-    const size_t lds = (size_t)(WgFft<float, L2, 256>::LDS_ELEMS3 + 16 * 17) * sizeof(cpx<float>);
+    const size_t lds = (size_t)((sizeof(T) == 4 ? WgFft<T, L2, 256>::LDS_ELEMS3 : WgFft<T, L2, 256>::LDS_ELEMS) + 16 * 17) * sizeof(cpx<T>);
     switch (r0) {
-#define BDSP_R0(N) case N: return launch_v2<N>(a, grid, lds, s);
+#define BDSP_R0(N) case N: return launch_v2<T, N>(a, grid, lds, s);
         BDSP_R0(1) BDSP_R0(2) BDSP_R0(3) BDSP_R0(4) BDSP_R0(5) BDSP_R0(6)
         BDSP_R0(7) BDSP_R0(8) BDSP_R0(9) BDSP_R0(10) BDSP_R0(11) BDSP_R0(12)
 #undef BDSP_R0
@@ -304,5 +328,8 @@ int conv_v2_run(const float* in, float* out, size_t points, size_t batch, const 
     set_last_error("convolve_overlap_save: taps out of range for the block kernel");
     return BDSP_ERR_UNSUPPORTED;
 }
+
+template int conv_v2_run<float>(const float*, float*, size_t, size_t, const float*, size_t, size_t, size_t, bool, hipStream_t);
+template int conv_v2_run<double>(const double*, double*, size_t, size_t, const double*, size_t, size_t, size_t, bool, hipStream_t);
 
 } // namespace bdsp
