@@ -479,12 +479,35 @@ __global__ __launch_bounds__(W * (RP / 16)) void k_fft_pass(FftIo<T> io, const c
             // symmetric evaluation like the reference (vector_types/mod.rs:567-594)
             const T beta = (T)1 - io.window_alpha, two_over = (T)2 / ((T)n - (T)1);
             const size_t half = n - n / 2;
+            if constexpr (sizeof(T) == 8) {
+                // f64: sixteen cospi evaluations per thread were what made this pass 5 us slower than the others at
+                // 4M points.  The sixteen rows are n/16 apart, i.e. a constant angle step: two runs of eight rotations
+                // (registers 0..7 and 8..15 hold rows rx.. and (8^rx)..) from three sincospi; 8 rotations add < 1e-15.
+                double sd, cd;
+                sincospi((double)((size_t)NT * stride_in) * two_over, &sd, &cd);
+#pragma unroll
+                for (int run = 0; run < 2; ++run) {
+                    const size_t i0 = j + (size_t)(ti + ((8 * run) ^ rx) * NT) * stride_in;
+                    double s0, c0;
+                    sincospi((double)i0 * two_over, &s0, &c0);
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const int r = 8 * run + q;
+                        const T w = io.window_alpha - beta * c0;
+                        v[r] = cpx<T>{v[r].x * w, v[r].y * w};
+                        const double cn = c0 * cd - s0 * sd;
+                        s0 = s0 * cd + c0 * sd;
+                        c0 = cn;
+                    }
+                }
+            } else {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 size_t i = j + (size_t)(ti + (r ^ rx) * NT) * stride_in;
                 i = i < half ? i : n - 1 - i;
                 const T w = io.window_alpha - beta * dev_cospi<T>((T)i * two_over);
                 v[r] = cpx<T>{v[r].x * w, v[r].y * w};
+            }
             }
         }
     }

@@ -632,6 +632,44 @@ __global__ __launch_bounds__(256, WPC) void k_v2(Args a, unsigned nb_lo, unsigne
                 a.q[8 * 32] = 0;
             }
         }
+    } else if constexpr (DBUF >= 3000000) {
+        // HYBRID: whole static rounds per dispatch group (DBUF = 3000000 + 10000*RA + 100*RB + RC) and the blocks left
+        // over handed out one by one from an atomic counter to whichever workgroup has finished its static share
+        constexpr int RA = (DBUF - 3000000) / 10000, RB = (DBUF - 3000000) / 100 % 100, RC = (DBUF - 3000000) % 100;
+        __shared__ unsigned s_tk;
+        const unsigned total = nb_hi - nb_lo, gs = G / 3;
+        unsigned n0 = RA * gs, n1 = RB * gs, n2 = RC * gs;
+        if (n0 > total) n0 = total;
+        if (n0 + n1 > total) n1 = total - n0;
+        if (n0 + n1 + n2 > total) n2 = total - n0 - n1;
+        const unsigned stat = n0 + n1 + n2;
+        const unsigned grp = blockIdx.x / gs;
+        const unsigned starts[4] = {0, n0, n0 + n1, stat};
+        if (grp < 3) {
+            const unsigned lo = nb_lo + starts[grp], hi = nb_lo + starts[grp + 1];
+            const unsigned w2 = xcd_contiguous(blockIdx.x - grp * gs, gs);
+            for (unsigned b = lo + w2; b < hi; b += gs) {
+                C v[16];
+                load_fast(b, v);
+                transform(v);
+                store_fast(b, v);
+            }
+        }
+        for (;;) {
+            if (t == 0) s_tk = atomicAdd(&a.q[0], 1u);
+            __syncthreads();
+            const unsigned b = nb_lo + stat + s_tk;
+            __syncthreads();
+            if (b >= nb_hi) break;
+            C v[16];
+            load_fast(b, v);
+            transform(v);
+            store_fast(b, v);
+        }
+        if (t == 0) {
+            const unsigned old = atomicAdd(&a.q[8 * 32], 1u);
+            if (old == G - 1) { a.q[0] = 0; a.q[8 * 32] = 0; }
+        }
     } else if constexpr (DBUF >= 1000000) {
         // four dispatch groups (4 workgroups per CU): DBUF = 1000000 + 10000*RA + 100*RB + RC rounds, the last group the rest
         constexpr int RA = (DBUF - 1000000) / 10000, RB = (DBUF - 1000000) / 100 % 100, RC = (DBUF - 1000000) % 100;
@@ -891,6 +929,11 @@ int main(int argc, char** argv)
         {"v2 L3 prioX 3 even", (const void*)k_v2<2, 4, 4, 0, 3>, true, 3, lds_l3, 4},
         {"v2 L3 tw3full 3 rounds 9/8", (const void*)k_v2<2, 4, 2, 2000 + 908, 3>, true, 3, lds_l3, 4},
         {"v2 L3 tw3full 3 rounds 10/8", (const void*)k_v2<2, 4, 2, 2000 + 1008, 3>, true, 3, lds_l3, 4},
+        {"v2 L3 tw3full hyb 9/7/4", (const void*)k_v2<2, 4, 2, 3000000 + 90704, 3>, true, 3, lds_l3, 4},
+        {"v2 L3 tw3full hyb 9/8/4", (const void*)k_v2<2, 4, 2, 3000000 + 90804, 3>, true, 3, lds_l3, 4},
+        {"v2 L3 tw3full hyb 8/7/4", (const void*)k_v2<2, 4, 2, 3000000 + 80704, 3>, true, 3, lds_l3, 4},
+        {"v2 L3 tw3full hyb 8/7/5", (const void*)k_v2<2, 4, 2, 3000000 + 80705, 3>, true, 3, lds_l3, 4},
+        {"v2 L3 tw3full hyb 9/7/3", (const void*)k_v2<2, 4, 2, 3000000 + 90703, 3>, true, 3, lds_l3, 4},
         {"v2 L3 tw0 3 even", (const void*)k_v2<2, 4, 0, 0, 3>, true, 3, lds_l3, 4},
         {"v2 st tw0 3 rounds 9/7", (const void*)k_v2<0, 4, 0, 2000 + 907, 3>, true, 3, lds_base, 4},
         {"v2 st tw3 2 rounds 12", (const void*)k_v2<0, 4, 3, 2000 + 1200, 2>, true, 2, lds_base, 4},
