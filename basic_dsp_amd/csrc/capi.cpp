@@ -60,7 +60,10 @@ int fft_two_buffers(T* a, T* b, size_t points, size_t batch, bool inverse, unsig
         io.out = a;
         return fft_pow2<T>(io, b, nullptr, batch, inverse, s);
     }
-    io.out = b; // a -> b -> a -> b
+    // a -> b -> a -> b.  (The last Stockham pass reads and writes the same index set per workgroup and could run in
+    // place, a -> b -> a -> a, halving the working set for the 256 MiB Infinity Cache: *measured* 135 us against 128 us
+    // for the 16M-point transform -- rewriting the lines just read is slower than ping-pong.)
+    io.out = b;
     *in_b = true;
     return fft_pow2<T>(io, b, a, batch, inverse, s);
 }
