@@ -322,7 +322,7 @@ int conv_real_dev(const T* in, T* out, size_t points, const T* taps, size_t ntap
 // a chunk has landed the blocks whose 4096-point windows it completes run on the compute stream; a helper thread
 // brings their outputs down on a third stream while the next chunk is still going up -- PCIe is full duplex.
 // Block 0 and the last blocks read across the wrap-around point and run when the whole vector is resident.
-// *Measured* 16M f32 points x 1024 taps: 4.88 -> 3.94 ms (the two directions share ~68 GB/s on this host;
+// *Measured* 16M f32 points x 1024 taps: 4.88 -> 3.94 -> 3.36 ms (the two directions share 68-80 GB/s on this host;
 // registering the caller's pages first changed nothing).
 //
 // The two transfer streams and the stage events are created once per calling thread and device and reused by
