@@ -108,7 +108,7 @@ size_t conv_v2_block_step(size_t taps);
 bool conv_v2_applies(size_t points, size_t taps);
 template <typename T>
 int conv_v2_run(const T* in, T* out, size_t points, size_t batch, const T* hs, size_t taps,
-                size_t first_block, size_t nblocks, bool hs_is_taps, hipStream_t s);
+                size_t first_block, size_t nblocks, bool hs_is_taps, hipStream_t s, bool real = false);
 template <typename T>
 int conv_prepare_spectrum(const T* taps_dev, size_t taps, const T* h_freq_dev, T* hs, hipStream_t s);
 template <typename T>

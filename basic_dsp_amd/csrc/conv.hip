@@ -371,7 +371,7 @@ int conv_prepare_spectrum(const T* taps_dev, size_t taps, const T* h_freq_dev, T
 template <typename T>
 size_t conv_block_step(size_t points, size_t taps, bool real_data)
 {
-    if (!real_data && conv_v2_applies(points, taps)) return conv_v2_block_step(taps);
+    if (conv_v2_applies(points, taps)) return conv_v2_block_step(taps);
     size_t V = (size_t)CONV_L - (taps - 1);
     if (real_data) { if (V >= 32) V &= ~(size_t)31; }
     else if (V >= 16) V &= ~(size_t)15;
@@ -386,6 +386,10 @@ int conv_run_blocks(const T* in, T* out, size_t points, size_t batch, const T* h
                     hipStream_t s, bool real_data, bool hs_is_taps)
 {
     constexpr int L = CONV_L;
+    // real data with real taps handed in as taps: the second-generation kernel on pairs of real blocks
+    if (real_data && hs_is_taps && !last_block_out && nblocks_limit == 0 && out_off == 0 && in_off == -(long long)(taps / 2) &&
+        taps >= 1 && taps - 1 <= 3 * (size_t)L / 4 && conv_v2_applies(points, taps))
+        return conv_v2_run<T>(in, out, points, batch, hs, taps, 0, 0, true, s, true);
     // complex data: the second-generation kernel (conv_v2.hip) whenever the call is a run of whole blocks
     if (!real_data && !last_block_out && taps >= 1 && taps - 1 <= 3 * (size_t)L / 4 && conv_v2_applies(points, taps)) {
         const long long V2 = (long long)conv_v2_block_step(taps);

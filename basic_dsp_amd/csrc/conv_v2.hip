@@ -69,7 +69,10 @@ static __device__ __forceinline__ unsigned xcd_contiguous(unsigned bid, unsigned
 
 // f64 (round 2, late): the same structure with TWO workgroups per CU (74 KB of LDS and 240 registers each), two dispatch
 // groups, the generic padded exchange layouts and the six-value split of the stage-3 twiddles (fifteen would not fit).
-template <typename T, int R0, bool BATCHED>
+// REAL: the vector holds n REAL samples and the taps are real: the real blocks 2p and 2p+1 travel through the complex
+// transform pair as real and imaginary part (convolution with a real filter is real-linear, so they come out
+// separated).  "Block" then means such a PAIR; x, y and hs are read as arrays of T.
+template <typename T, int R0, bool BATCHED, bool REAL = false>
 __global__ __launch_bounds__(256, sizeof(T) == 4 ? 3 : 2) void k_overlap_save_v2(ConvV2Args<T> a)
 {
     constexpr int L = L2;
@@ -133,7 +136,8 @@ __global__ __launch_bounds__(256, sizeof(T) == 4 ? 3 : 2) void k_overlap_save_v2
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const unsigned i = ut + 256u * r;
-            hv[r] = (i >= d && i - d < a.taps) ? a.hs[i - d] : C32{(T)0, (T)0};
+            if constexpr (REAL) hv[r] = (i >= d && i - d < a.taps) ? C32{reinterpret_cast<const T*>(a.hs)[i - d], (T)0} : C32{(T)0, (T)0};
+            else hv[r] = (i >= d && i - d < a.taps) ? a.hs[i - d] : C32{(T)0, (T)0};
         }
         forward(hv);
 #pragma unroll
@@ -162,9 +166,37 @@ __global__ __launch_bounds__(256, sizeof(T) == 4 ? 3 : 2) void k_overlap_save_v2
         for (unsigned w = blockIdx.x; w < total_w; w += G) {
             const unsigned vec = w / nw, k = w % nw;
             const unsigned b = k < a.nb_lo - a.b_first ? a.b_first + k : a.nb_hi + (k - (a.nb_lo - a.b_first));
+            C32 v[16];
+            if constexpr (REAL) {
+                const T* xr = reinterpret_cast<const T*>(a.x) + (size_t)vec * a.n;
+                T* yr = reinterpret_cast<T*>(a.y) + (size_t)vec * a.n;
+                T part[2][16];
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    long long sb = ((long long)(2 * b + half) * V + in_off) % (long long)a.n;
+                    if (sb < 0) sb += a.n;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) part[half][r] = xr[((unsigned long long)sb + ut + 256u * r) % a.n];
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] = C32{part[0][r], part[1][r]};
+                transform(v);
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    const long long obase = (long long)(2 * b + half) * V - OV;
+                    const long long room = (long long)a.n - obase;
+                    const unsigned lim = room <= 0 ? 0u : (room > L ? (unsigned)L : (unsigned)room);
+                    T* yb = yr + obase;
+#pragma unroll
+                    for (int r = R0; r < 16; ++r) {
+                        const unsigned np = ut + 256u * r;
+                        if (np < lim) yb[np] = half ? v[r].y : v[r].x;
+                    }
+                }
+                continue;
+            }
             const C32* xv = a.x + (size_t)vec * a.n;
             C32* yv = a.y + (size_t)vec * a.n;
-            C32 v[16];
             long long sb = ((long long)b * V + in_off) % (long long)a.n;
             if (sb < 0) sb += a.n;
             const unsigned idx = (unsigned)sb + ut;
@@ -202,6 +234,20 @@ __global__ __launch_bounds__(256, sizeof(T) == 4 ? 3 : 2) void k_overlap_save_v2
     for (unsigned id = lo + w2; id < hi; id += gs) {
         unsigned vec = 0, b = a.nb_lo + id;
         if (BATCHED) { vec = id / ni; b = a.nb_lo + id % ni; }
+        if constexpr (REAL) {
+            const T* x0 = reinterpret_cast<const T*>(a.x) + ((size_t)vec * a.n + ((long long)(2 * b) * V + in_off));
+            T* y0 = reinterpret_cast<T*>(a.y) + ((size_t)vec * a.n + ((long long)(2 * b) * V - OV));
+            C32 v[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = C32{x0[ut + 256u * r], x0[V + ut + 256u * r]};
+            transform(v);
+#pragma unroll
+            for (int r = R0; r < 16; ++r) {
+                y0[ut + 256u * r] = v[r].x;
+                y0[V + ut + 256u * r] = v[r].y;
+            }
+            continue;
+        }
         const C32* xb = a.x + ((size_t)vec * a.n + ((long long)b * V + in_off));
         C32* yb = a.y + ((size_t)vec * a.n + ((long long)b * V - OV));
         C32 v[16];
@@ -220,9 +266,13 @@ __global__ __launch_bounds__(256, sizeof(T) == 4 ? 3 : 2) void k_overlap_save_v2
 }
 
 template <typename T, int R0>
-static int launch_v2(const ConvV2Args<T>& a, unsigned grid, size_t lds, hipStream_t s)
+static int launch_v2(const ConvV2Args<T>& a, unsigned grid, size_t lds, hipStream_t s, bool real)
 {
-    if (a.batch > 1) {
+    if (real) {
+        auto kern = k_overlap_save_v2<T, R0, true, true>; // (the batched instantiation serves single vectors too)
+        if (lds > 64 * 1024) BDSP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, a);
+    } else if (a.batch > 1) {
         auto kern = k_overlap_save_v2<T, R0, true>;
         if (lds > 64 * 1024) BDSP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, a);
@@ -249,23 +299,26 @@ bool conv_v2_applies(size_t points, size_t taps)
 }
 
 // Blocks [first_block, first_block + nblocks) (nblocks = 0: all from first_block on) of every vector of the batch.
+// real: `points` REAL samples per vector and real taps (hs_is_taps); blocks are then PAIRS of real blocks.
 template <typename T>
 int conv_v2_run(const T* in, T* out, size_t points, size_t batch, const T* hs, size_t taps,
-                size_t first_block, size_t nblocks, bool hs_is_taps, hipStream_t s)
+                size_t first_block, size_t nblocks, bool hs_is_taps, hipStream_t s, bool real)
 {
     const cpx<T>* wtab;
     BDSP_TRY(twiddle_table<T>(L2, &wtab));
     const unsigned r0 = taps <= 1 ? 1u : (unsigned)((taps - 1 + 255) / 256);
     const long long V = L2 - 256 * (long long)r0;
-    const long long nb_all = ((long long)points + V - 1) / V;
+    const long long U = real ? 2 : 1; // real blocks per kernel block
+    const long long nb_all = (((long long)points + V - 1) / V + U - 1) / U;
     long long b0 = (long long)first_block, b1 = nblocks ? b0 + (long long)nblocks : nb_all;
     if (b1 > nb_all) b1 = nb_all;
     if (b0 >= b1 || batch == 0) return BDSP_OK;
     const long long in_off = -(long long)(taps / 2);
     // interior blocks: window [bV + in_off, + L) inside [0, n) (then all V outputs are below n as well, see below)
     long long lo = b0, hi = b1;
-    while (lo < hi && lo * V + in_off < 0) ++lo;
-    while (hi > lo && ((hi - 1) * V + in_off + L2 > (long long)points || (hi - 1) * V + V > (long long)points)) --hi;
+    // (a pair is interior when both of its real blocks are: the first one's window start and the last one's end decide)
+    while (lo < hi && lo * U * V + in_off < 0) ++lo;
+    while (hi > lo && ((hi * U - 1) * V + in_off + L2 > (long long)points || (hi * U - 1) * V + V > (long long)points)) --hi;
     if ((unsigned long long)(b1 - b0) * batch >= (1ull << 32) || batch > 0xffffffffull) {
         set_last_error("convolve_overlap_save: too many blocks");
         return BDSP_ERR_UNSUPPORTED;
@@ -307,7 +360,7 @@ int conv_v2_run(const T* in, T* out, size_t points, size_t batch, const T* hs, s
     a.nbb = (unsigned)nbb;
     const size_t lds = (size_t)((sizeof(T) == 4 ? WgFft<T, L2, 256>::LDS_ELEMS3 : WgFft<T, L2, 256>::LDS_ELEMS) + 16 * 17) * sizeof(cpx<T>);
     switch (r0) {
-#define BDSP_R0(N) case N: return launch_v2<T, N>(a, grid, lds, s);
+#define BDSP_R0(N) case N: return launch_v2<T, N>(a, grid, lds, s, real);
         BDSP_R0(1) BDSP_R0(2) BDSP_R0(3) BDSP_R0(4) BDSP_R0(5) BDSP_R0(6)
         BDSP_R0(7) BDSP_R0(8) BDSP_R0(9) BDSP_R0(10) BDSP_R0(11) BDSP_R0(12)
 #undef BDSP_R0
@@ -317,7 +370,7 @@ int conv_v2_run(const T* in, T* out, size_t points, size_t batch, const T* hs, s
     return BDSP_ERR_UNSUPPORTED;
 }
 
-template int conv_v2_run<float>(const float*, float*, size_t, size_t, const float*, size_t, size_t, size_t, bool, hipStream_t);
-template int conv_v2_run<double>(const double*, double*, size_t, size_t, const double*, size_t, size_t, size_t, bool, hipStream_t);
+template int conv_v2_run<float>(const float*, float*, size_t, size_t, const float*, size_t, size_t, size_t, bool, hipStream_t, bool);
+template int conv_v2_run<double>(const double*, double*, size_t, size_t, const double*, size_t, size_t, size_t, bool, hipStream_t, bool);
 
 } // namespace bdsp

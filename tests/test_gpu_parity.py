@@ -389,6 +389,25 @@ def test_convolve_signal_real_and_errors():
     assert DspVec(h).convolve_signal(DspVec(x)) == 7                      # points < imp points
 
 
+REAL_CONV_CASES = [(100, 6), (5000, 31), (4097, 1024), (3840 + 1, 200), (3840 * 2, 200), (3840 * 2 + 1, 129),
+                   (3840 * 3 - 1, 129), (3072 * 5, 1024), (3072 * 5 + 7, 1025), (30000, 769), (40000, 3073), (9000, 258),
+                   (3073, 3073), (2, 2), (1, 1)]
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("n,m", REAL_CONV_CASES)
+def test_convolve_signal_real_vs_direct_oracle(n, m, dtype):
+    """Real vectors with real taps: two real blocks share one complex transform pair in the block kernel.  Odd and
+    even numbers of real blocks (the last pair half empty), lengths one sample past / short of a block boundary,
+    tap counts either side of a 256-row boundary, vectors shorter than a block."""
+    x = orc.fill_uniform(n, 201601181 + n, -10, 10, dtype)
+    h = orc.fill_uniform(m, 201601182 + m, -1, 1, dtype) / dtype(m)
+    ref = orc.convolve_direct(x.astype(np.float64), h.astype(np.float64), False)
+    v, hv = DspVec(x), DspVec(h)
+    assert v.convolve_signal(hv) == 0 and not v.is_complex() and len(v) == n
+    assert rel_l2(v.data(), ref) < tol_for(dtype), (n, m)
+
+
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 def test_b1_gpu_convolve_vector(dtype):
     # ocl/mod.rs:549-564 compares inside the returned range; ours covers the whole vector
