@@ -72,6 +72,20 @@ report("C3 in f64: complex f64 16M (*) 1024 taps", us, n, 32, "samples")
 del xd, yd
 us = timeit(lambda i: lib.bdsp_hip_dev_fft(0, xs[i % 3].data_ptr(), y.data_ptr(), n, 1, 0, 1.0, -1, 0.0, C.byref(flag), sp))
 report("FFT complex f32 16M: plain_fft (3 passes)", us, n, 16, "points")
+# real signal, real taps through the facade (B2): two real blocks per complex transform pair
+import numpy as np
+from basic_dsp_amd import DspVec
+rv = [DspVec(np.random.rand(n).astype(np.float32) * 20 - 10) for _ in range(3)]
+rh = DspVec((np.random.rand(m).astype(np.float32) * 2 - 1) / m)
+def real_conv(i): rv[i % 3].convolve_signal(rh)
+import time as _tm
+for i in range(30): real_conv(i)
+lib.bdsp_hip_synchronize(None)
+_t0 = _tm.perf_counter()
+for i in range(200): real_conv(i)
+lib.bdsp_hip_synchronize(None)
+report("C3 on REAL data: real f32 16M (*) 1024 real taps, through the facade (incl. host call)", (_tm.perf_counter() - _t0) / 200 * 1e6, n, 8, "samples")
+del rv
 del xs, y
 
 n = 1 << 22
