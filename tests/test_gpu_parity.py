@@ -474,6 +474,27 @@ def test_interpolatef_both_paths(cplx, dtype):
     np.testing.assert_allclose(v.data(), ref, atol=1e-5)
 
 
+@pytest.mark.parametrize("cplx", [True, False])
+def test_interpolatef_f64_integer_factors_ragged_lengths(cplx):
+    # f64, integer factors with and without a blocked inner kernel (2, 4, 8 / 16), ragged lengths (the last workgroup's
+    # tile ends inside the vector, an odd first inner output), conv_len from 1 to 46, a delay, both functions -- each
+    # against the oracle's "simd" path at the f64 tolerance
+    e = 2 if cplx else 1
+    cases = [(1, 0.35, 2, 0.0, 12, 3000), (1, 0.35, 4, 0.0, 12, 3001), (0, 0.0, 8, 0.0, 12, 1777), (0, 0.0, 16, 0.0, 5, 1500),
+             (1, 0.2, 4, 0.25, 1, 2047), (0, 0.0, 2, -0.5, 40, 4099), (1, 0.5, 4, 0.0, 44, 2500), (0, 0.0, 16, 0.0, 45, 3000),
+             (1, 0.35, 8, 0.0, 46, 9001), (0, 0.0, 4, 0.0, 12, 70001)]
+    for fid, rolloff, factor, delay, conv_len, points in cases:
+        x = orc.fill_uniform(e * points, 201602221 + points, -10, 10, np.float64)
+        v = DspVec(x, is_complex=cplx, delta=1.0)
+        assert v.interpolatef(fid, float(factor), delay, conv_len, rolloff) == 0
+        ref, path = orc.interpolatef(x, cplx, fid, rolloff, np.float64(factor), delay, conv_len)
+        assert path == 1  # the reference would take its "simd" path (interpolation.rs:411-445)
+        assert len(v) == ref.size
+        got = v.data()
+        assert rel_l2(got, ref) < 1e-13, (fid, factor, delay, conv_len, points, rel_l2(got, ref))
+        assert np.max(np.abs(got - ref)) < 1e-11, (factor, conv_len, points)
+
+
 # ------------------------------------------------------------------ batch (config C5, one GPU)
 def test_batch_shard_on_gpu_matches_oracle():
     import torch
