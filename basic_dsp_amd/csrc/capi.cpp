@@ -58,6 +58,23 @@ int fft_two_buffers(T* a, T* b, size_t points, size_t batch, bool inverse, unsig
     io.in = a;
     if (!three) { // a -> b -> a
         io.out = a;
+        // A large batch goes through in chunks whose data plus the (shared) scratch fill the 256 MB Infinity Cache:
+        // the intermediate of a chunk is then re-read from the cache instead of HBM.  *Measured* (tools/chunk_probe.py,
+        // 64 x 1M-point f32 -> magnitude): 402 us in one piece, 372 us in chunks of 16 (128 MB + 128 MB), 424 at 32,
+        // 451 at 8 (launches too small) -- so only batches of at least two such chunks are split.  A chunk's output
+        // never reaches an unprocessed chunk's input (real input, whose output is larger than the input, is excluded).
+        static const bool no_chunks = getenv("BDSP_FFT_NO_CHUNKS") != nullptr;
+        const size_t vec_bytes = sizeof(T) * 2 * points, k0 = (size_t(128) << 20) / vec_bytes;
+        if (!no_chunks && !(flags & FFT_IN_REAL) && k0 >= 1 && batch >= 2 * k0) {
+            const size_t nchunks = batch / k0, k = (batch + nchunks - 1) / nchunks;
+            const size_t out_elems = (flags & (BDSP_FFT_MAGNITUDE | FFT_OUT_REAL)) ? points : 2 * points; // scalars per vector
+            for (size_t c0 = 0; c0 < batch; c0 += k) {
+                io.in = a + c0 * 2 * points;
+                io.out = a + c0 * out_elems;
+                BDSP_TRY(fft_pow2<T>(io, b, nullptr, batch - c0 < k ? batch - c0 : k, inverse, s));
+            }
+            return BDSP_OK;
+        }
         return fft_pow2<T>(io, b, nullptr, batch, inverse, s);
     }
     // a -> b -> a -> b.  (The last Stockham pass reads and writes the same index set per workgroup and could run in

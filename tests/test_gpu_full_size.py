@@ -158,6 +158,34 @@ def test_c5_shard_of_64_1m_vectors_against_the_oracle():
     assert np.array_equal(piped.cpu().numpy(), out)
 
 
+def test_c2_batch_of_40_fft_magnitude_in_cache_sized_chunks():
+    """40 x 1 048 576-point complex f32 plain_fft -> magnitude in ONE device call (config C2 batched): 320 MB of data, which
+    the library walks in two chunks of 20 vectors that share the scratch buffer (fft_two_buffers, capi.cpp).  The
+    magnitudes come back compact (1M reals per vector at the head of the data buffer): every vector must equal the
+    single-vector fused call bit for bit, vector 0 and the last one also the oracle's f64 transform."""
+    import ctypes as C
+    import torch
+    from basic_dsp_amd import _lib
+    from basic_dsp_amd._lib import FFT_MAGNITUDE
+    lib, sp = _lib.lib, _lib.torch_stream_arg()
+    nvec, n = 40, 1 << 20
+    rows = np.stack([orc.fill_uniform(2 * n, SEED_C2 + 7 * r, -10, 10, np.float32) for r in range(nvec)])
+    data = torch.from_numpy(rows).cuda().reshape(-1)
+    scratch = torch.empty_like(data)
+    flag = C.c_int(-1)
+    assert lib.bdsp_hip_dev_fft(0, data.data_ptr(), scratch.data_ptr(), n, nvec, FFT_MAGNITUDE, 1.0, -1, 0.0, C.byref(flag), sp) == 0
+    assert flag.value == 0  # result in the data buffer
+    got = data[: nvec * n].reshape(nvec, n).cpu().numpy()
+    one, one_scratch = torch.empty(2 * n, device="cuda"), torch.empty(2 * n, device="cuda")
+    for r in range(nvec):
+        one.copy_(torch.from_numpy(rows[r]))
+        assert lib.bdsp_hip_dev_fft(0, one.data_ptr(), one_scratch.data_ptr(), n, 1, FFT_MAGNITUDE, 1.0, -1, 0.0, C.byref(flag), sp) == 0
+        single = (one_scratch if flag.value else one)[:n].cpu().numpy()
+        assert np.array_equal(got[r], single), r
+    for r in (0, nvec - 1):
+        assert rel_l2(got[r], orc.magnitude(orc.fft(rows[r].astype(np.float64)))) < 1e-6, r
+
+
 @pytest.mark.gpu
 def test_mixed_radix_three_million_points():
     """3 000 000 = 2^6 3 5^6 points: the four-step mixed-radix form with 2-wide tiles (factors 1500 x 2000), against
