@@ -88,6 +88,7 @@ constexpr unsigned FFT_OUT_REAL = 1u << 10;      // write only the real parts
 template <typename T>
 int fft_pow2(const FftIo<T>& io, T* scratch_a, T* scratch_b, size_t batch, bool inverse,
              hipStream_t s);
+template <typename T> int fft_pow2_passes(size_t n); // 1 (n <= 4096), 2 or 3 trips through memory
 template <typename T>
 int fft_any(const FftIo<T>& io, size_t batch, bool inverse, hipStream_t s);
 bool is_pow2(size_t n);

@@ -54,10 +54,19 @@ int fft_two_buffers(T* a, T* b, size_t points, size_t batch, bool inverse, unsig
         else io.out = a;
         return fft_pow2<T>(io, nullptr, nullptr, batch, inverse, s);
     }
-    const bool three = points > (size_t(1) << 20);
+    const bool three = fft_pow2_passes<T>(points) == 3;
     io.in = a;
     if (!three) { // a -> b -> a
         io.out = a;
+        // a -> b -> b for ONE 2^21-point f32 transform: the last pass reads and writes the same index set per workgroup,
+        // so it may run in place, and at this size (16 MB per buffer) that measured 31.9 -> 27.0 us (tools/plan_probe.py);
+        // every other two-pass size measured equal or slower in place (2^20 f64: 20.8 -> 25.3 us), as did 2^24 (above)
+        static const bool force_inplace = getenv("BDSP_FFT_LAST_INPLACE") != nullptr;
+        if (!reshaping && (force_inplace || (sizeof(T) == 4 && points == (size_t(1) << 21) && batch == 1))) {
+            io.out = b;
+            *in_b = true;
+            return fft_pow2<T>(io, b, nullptr, batch, inverse, s);
+        }
         // A large batch goes through in chunks whose data plus the (shared) scratch fill the 256 MB Infinity Cache:
         // the intermediate of a chunk is then re-read from the cache instead of HBM.  *Measured* (tools/chunk_probe.py,
         // 64 x 1M-point f32 -> magnitude): 402 us in one piece, 372 us in chunks of 16 (128 MB + 128 MB), 424 at 32,
@@ -274,7 +283,7 @@ int conv_long_dev(const T* in, T* out, size_t points, const T* taps, size_t ntap
         io.n = L; io.in = xe.p; io.in_stride = V; io.out_stride = L; io.flags = 0;
         io.in_scale = (T)1; io.window_id = -1; io.window_alpha = (T)0;
         bool r1 = false;
-        if (L <= (size_t(1) << 20)) { io.out = z1.p; BDSP_TRY(fft_pow2<T>(io, z2.as<T>(), nullptr, nb, false, s)); }
+        if (fft_pow2_passes<T>(L) < 3) { io.out = z1.p; BDSP_TRY(fft_pow2<T>(io, z2.as<T>(), nullptr, nb, false, s)); }
         else { io.out = z2.p; r1 = true; BDSP_TRY(fft_pow2<T>(io, z2.as<T>(), z1.as<T>(), nb, false, s)); }
         T* spec = r1 ? z2.as<T>() : z1.as<T>();
         T* scr = r1 ? z1.as<T>() : z2.as<T>();
@@ -550,7 +559,7 @@ size_t b1_overlap_discard(T* x_time, size_t x_len, T* tmp, size_t tmp_len, const
             io.n = l; io.in = dx.p; io.in_stride = step; io.out_stride = l; io.flags = 0;
             io.in_scale = (T)1; io.window_id = -1; io.window_alpha = (T)0;
             if (l <= 4096) { io.out = dz.p; BDSP_TRY(fft_pow2<T>(io, nullptr, nullptr, nb, false, s)); }
-            else if (l <= (size_t(1) << 20)) { io.out = dz.p; BDSP_TRY(fft_pow2<T>(io, dz2.as<T>(), nullptr, nb, false, s)); }
+            else if (fft_pow2_passes<T>(l) < 3) { io.out = dz.p; BDSP_TRY(fft_pow2<T>(io, dz2.as<T>(), nullptr, nb, false, s)); }
             else { io.out = dz2.p; r1 = true; BDSP_TRY(fft_pow2<T>(io, dz2.as<T>(), dz.as<T>(), nb, false, s)); }
         }
         T* spec = r1 ? dz2.as<T>() : dz.as<T>();

@@ -765,7 +765,7 @@ static int launch_pass_rp(int rp, int w, const FftIo<T>& io, const cpx<T>* src, 
 // Super-radix plan for n = 2^bits > 4096: 2 passes up to 2^20, 3 passes up to 2^30, bits split as
 // evenly as possible, largest first (the first pass is the one whose stores are always long
 // contiguous runs, so it can afford the narrowest tile).
-static int plan_passes(size_t n, size_t batch, int rp[3], int w[3])
+static int plan_passes(size_t n, size_t batch, size_t esz, int rp[3], int w[3])
 {
     int bits = 0;
     while ((size_t(1) << bits) < n) ++bits;
@@ -782,6 +782,16 @@ static int plan_passes(size_t n, size_t batch, int rp[3], int w[3])
             if (*e == ',') ++e;
         }
         if (k >= 2 && prod == n) return k;
+    }
+    // 2^21 and 2^22 points: two passes of 1024/2048-point columns beat three fully coalesced ones although their runs
+    // are only 32-64 bytes (*measured*, tools/plan_probe.py, one transform: 2^21 f32 32.9 -> 26.5 us, f64 36.6 -> 31.9;
+    // 2^22 f32 41.1 -> 38.5, f64 67.3 -> 62.0, config C4a 69.8 -> 63.7; from 2^23 on the 4096-point columns' 16-32-byte runs lose: f32
+    // 66 vs 78-93 us, f64 134 vs 135-153, 2^24 f64 319 vs 407)
+    if (bits == 21 || bits == 22) {
+        rp[0] = bits == 21 ? 1024 : 2048; rp[1] = 2048;
+        if (esz == 4) { w[0] = bits == 21 ? 8 : 4; w[1] = 4; }
+        else { w[0] = 4; w[1] = 4; } // 2^22 f64: 2-wide tiles are 2 us faster plain (59.6 vs 62.0) but 7 us slower with a fused window
+        return 2;
     }
     int passes = bits <= 20 ? 2 : 3;
     int base = bits / passes, extra = bits % passes;
@@ -837,7 +847,7 @@ int fft_pow2(const FftIo<T>& io, T* scratch_a, T* scratch_b, size_t batch, bool 
             !(io.flags & (BDSP_FFT_MAGNITUDE | FFT_OUT_REAL | FFT_IN_REAL))) return launch_wg4<T, 8192>(io, batch, inverse, s);
     }
     int rp[3], w[3];
-    int passes = plan_passes(n, batch, rp, w);
+    int passes = plan_passes(n, batch, sizeof(T), rp, w);
     if (passes == 0) { set_last_error("FFT length above 2^30 points"); return BDSP_ERR_UNSUPPORTED; }
     if (!scratch_a || (passes == 3 && !scratch_b)) {
         set_last_error("fft_pow2: scratch missing");
@@ -858,6 +868,17 @@ int fft_pow2(const FftIo<T>& io, T* scratch_a, T* scratch_b, size_t batch, bool 
     return BDSP_OK;
 }
 
+// trips through global memory a power-of-two transform of n points makes (callers size and order their ping-pong
+// buffers by it: 2 = in -> scratch_a -> out, 3 = in -> scratch_a -> scratch_b -> out)
+template <typename T>
+int fft_pow2_passes(size_t n)
+{
+    if (n <= 4096) return 1;
+    int rp[3], w[3];
+    return plan_passes(n, 1, sizeof(T), rp, w);
+}
+
 template int fft_pow2<BDSP_FFT_T>(const FftIo<BDSP_FFT_T>&, BDSP_FFT_T*, BDSP_FFT_T*, size_t, bool, hipStream_t);
+template int fft_pow2_passes<BDSP_FFT_T>(size_t);
 
 } // namespace bdsp

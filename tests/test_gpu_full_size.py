@@ -158,6 +158,31 @@ def test_c5_shard_of_64_1m_vectors_against_the_oracle():
     assert np.array_equal(piped.cpu().numpy(), out)
 
 
+@pytest.mark.parametrize("bits,dtype", [(21, np.float32), (22, np.float32), (21, np.float64), (22, np.float64)])
+def test_two_pass_lengths_2m_and_4m_with_every_fused_option(bits, dtype):
+    """2^21 and 2^22 points run as TWO passes of 1024/2048-point columns (plan_passes, fft_impl.h) -- the 2^21-point f32
+    transform with its last pass in place.  Against the oracle's f64 transform: plain_fft, fft (shift fused into the
+    last pass), windowed_fft (window fused into the first), plain_fft -> magnitude (reshaping output), and the round
+    trip through ifft."""
+    n = 1 << bits
+    tol = 1e-6 if dtype == np.float32 else 1e-12
+    x = orc.fill_uniform(2 * n, SEED_C2 + bits, -10, 10, dtype)
+    ref = orc.fft(x.astype(np.float64))
+    v = DspVec(x, is_complex=True)
+    assert v.plain_fft() == 0 and rel_l2(v.data(), ref) < tol
+    assert v.plain_ifft() == 0 and rel_l2(v.data() / n, x) < 2 * tol
+    v = DspVec(x, is_complex=True)
+    assert v.fft() == 0 and rel_l2(v.data(), orc.swap_halves(ref, True, True)) < tol
+    assert v.ifft() == 0 and rel_l2(v.data(), x) < 2 * tol
+    v = DspVec(x, is_complex=True)
+    assert v.windowed_fft(V.WINDOW_HAMMING) == 0
+    w = orc.apply_window(x.astype(np.float64), True, 1, 0.54)
+    assert rel_l2(v.data(), orc.swap_halves(orc.fft(w), True, True)) < tol
+    v = DspVec(x, is_complex=True)
+    assert v.plain_fft() == 0 and v.magnitude() == 0
+    assert len(v) == n and rel_l2(v.data(), orc.magnitude(ref)) < tol
+
+
 def test_c2_batch_of_40_fft_magnitude_in_cache_sized_chunks():
     """40 x 1 048 576-point complex f32 plain_fft -> magnitude in ONE device call (config C2 batched): 320 MB of data, which
     the library walks in two chunks of 20 vectors that share the scratch buffer (fft_two_buffers, capi.cpp).  The
