@@ -778,6 +778,197 @@ __global__ __launch_bounds__(256, WPC) void k_v2(Args a, unsigned nb_lo, unsigne
 #endif
 }
 
+
+// ------------------------------------------------------------------------------------------- wave-per-block
+// ONE WAVE per 4096-point block, 64 points per lane: 4096 = 64 x 64, each 64-point transform entirely in the lane's
+// registers (4 x 16), ONE twiddle layer (w4096^(lane k)) and ONE transposition through LDS per transform -- two
+// exchanges per block instead of four, no workgroup barrier at all, four independent waves per CU (one per SIMD).
+// Tables in LDS: TW[rho][lane] = w4096^(lane f(rho)), HT[rho][lane] = H'[lane + 64 f(rho)] / 4096, where register rho of
+// a finished 64-point transform holds frequency f(rho) = (rho >> 4) + 4 (rho & 15).  The transposition goes through a
+// 32-row buffer per wave in two halves (lanes 0..31 write, all read; lanes 32..63 write, all read): 4 x 16.5 KB + 64 KB
+// of tables = 130 KB.
+__device__ static constexpr float W64_TAB[64][2] = {
+    {1.000000000e+00f, -0.000000000e+00f}, {9.951847267e-01f, -9.801714033e-02f}, {9.807852804e-01f, -1.950903220e-01f}, {9.569403357e-01f, -2.902846773e-01f},
+    {9.238795325e-01f, -3.826834324e-01f}, {8.819212643e-01f, -4.713967368e-01f}, {8.314696123e-01f, -5.555702330e-01f}, {7.730104534e-01f, -6.343932842e-01f},
+    {7.071067812e-01f, -7.071067812e-01f}, {6.343932842e-01f, -7.730104534e-01f}, {5.555702330e-01f, -8.314696123e-01f}, {4.713967368e-01f, -8.819212643e-01f},
+    {3.826834324e-01f, -9.238795325e-01f}, {2.902846773e-01f, -9.569403357e-01f}, {1.950903220e-01f, -9.807852804e-01f}, {9.801714033e-02f, -9.951847267e-01f},
+    {6.123233996e-17f, -1.000000000e+00f}, {-9.801714033e-02f, -9.951847267e-01f}, {-1.950903220e-01f, -9.807852804e-01f}, {-2.902846773e-01f, -9.569403357e-01f},
+    {-3.826834324e-01f, -9.238795325e-01f}, {-4.713967368e-01f, -8.819212643e-01f}, {-5.555702330e-01f, -8.314696123e-01f}, {-6.343932842e-01f, -7.730104534e-01f},
+    {-7.071067812e-01f, -7.071067812e-01f}, {-7.730104534e-01f, -6.343932842e-01f}, {-8.314696123e-01f, -5.555702330e-01f}, {-8.819212643e-01f, -4.713967368e-01f},
+    {-9.238795325e-01f, -3.826834324e-01f}, {-9.569403357e-01f, -2.902846773e-01f}, {-9.807852804e-01f, -1.950903220e-01f}, {-9.951847267e-01f, -9.801714033e-02f},
+    {-1.000000000e+00f, -1.224646799e-16f}, {-9.951847267e-01f, 9.801714033e-02f}, {-9.807852804e-01f, 1.950903220e-01f}, {-9.569403357e-01f, 2.902846773e-01f},
+    {-9.238795325e-01f, 3.826834324e-01f}, {-8.819212643e-01f, 4.713967368e-01f}, {-8.314696123e-01f, 5.555702330e-01f}, {-7.730104534e-01f, 6.343932842e-01f},
+    {-7.071067812e-01f, 7.071067812e-01f}, {-6.343932842e-01f, 7.730104534e-01f}, {-5.555702330e-01f, 8.314696123e-01f}, {-4.713967368e-01f, 8.819212643e-01f},
+    {-3.826834324e-01f, 9.238795325e-01f}, {-2.902846773e-01f, 9.569403357e-01f}, {-1.950903220e-01f, 9.807852804e-01f}, {-9.801714033e-02f, 9.951847267e-01f},
+    {-1.836970199e-16f, 1.000000000e+00f}, {9.801714033e-02f, 9.951847267e-01f}, {1.950903220e-01f, 9.807852804e-01f}, {2.902846773e-01f, 9.569403357e-01f},
+    {3.826834324e-01f, 9.238795325e-01f}, {4.713967368e-01f, 8.819212643e-01f}, {5.555702330e-01f, 8.314696123e-01f}, {6.343932842e-01f, 7.730104534e-01f},
+    {7.071067812e-01f, 7.071067812e-01f}, {7.730104534e-01f, 6.343932842e-01f}, {8.314696123e-01f, 5.555702330e-01f}, {8.819212643e-01f, 4.713967368e-01f},
+    {9.238795325e-01f, 3.826834324e-01f}, {9.569403357e-01f, 2.902846773e-01f}, {9.807852804e-01f, 1.950903220e-01f}, {9.951847267e-01f, 9.801714033e-02f}};
+
+constexpr int WSTR = 66;
+__device__ __forceinline__ constexpr int f64map(int rho) { return (rho >> 4) + 4 * (rho & 15); }
+
+template <int DIR>
+__device__ __forceinline__ void dft64(C* v)
+{
+#pragma unroll
+    for (int i2 = 0; i2 < 16; ++i2) dft4<DIR>(v[i2], v[16 + i2], v[32 + i2], v[48 + i2]);
+#pragma unroll
+    for (int k1 = 1; k1 < 4; ++k1)
+#pragma unroll
+        for (int i2 = 1; i2 < 16; ++i2) {
+            const int m = i2 * k1;
+            if (m == 16) v[16 * k1 + i2] = rot_i<DIR>(v[16 * k1 + i2]);
+            else if (m == 8) v[16 * k1 + i2] = mul_w8_1<DIR>(v[16 * k1 + i2]);
+            else if (m == 24) v[16 * k1 + i2] = mul_w8_3<DIR>(v[16 * k1 + i2]);
+            else v[16 * k1 + i2] = twmul<DIR>(v[16 * k1 + i2], C{W64_TAB[m][0], W64_TAB[m][1]});
+        }
+#pragma unroll
+    for (int k1 = 0; k1 < 4; ++k1) dft16<DIR>(&v[16 * k1]);
+}
+
+// v[rho] = A[lane, f(rho)]  ->  o[r] = A[r, lane]
+__device__ __forceinline__ void wave_transpose(const C (&v)[64], C (&o)[64], int lane, C* buf)
+{
+    typedef float f4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        if ((lane >> 5) == h) {
+            C* row = buf + (lane & 31) * WSTR;
+#pragma unroll
+            for (int rho = 0; rho < 64; ++rho)
+                if ((rho & 16) == 0) { // registers rho and rho + 16 hold frequencies f and f + 1 (f even)
+                    f4 pr = {v[rho][0], v[rho][1], v[rho + 16][0], v[rho + 16][1]};
+                    *reinterpret_cast<f4*>(row + f64map(rho)) = pr;
+                }
+        }
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int r = 0; r < 32; ++r) o[32 * h + r] = buf[r * WSTR + lane];
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("" ::: "memory");
+    }
+}
+
+// natural-order input v[r] = x[lane + 64 r]; output v[rho] = X[lane + 64 f(rho)]
+template <int DIR>
+__device__ __forceinline__ void wave_fft4096(C (&v)[64], int lane, const C* TW, C* buf)
+{
+    dft64<DIR>(v);
+#pragma unroll
+    for (int rho = 1; rho < 64; ++rho) v[rho] = twmul<DIR>(v[rho], TW[rho * 64 + lane]);
+    C o[64];
+    wave_transpose(v, o, lane, buf);
+    dft64<DIR>(o);
+#pragma unroll
+    for (int rho = 0; rho < 64; ++rho) v[rho] = o[rho];
+}
+
+template <int OVROWS, bool PREFETCH>
+__global__ __launch_bounds__(256, 1) void k_wave(Args a, unsigned nb_lo, unsigned nb_hi)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    C* TW = reinterpret_cast<C*>(smem_raw);
+    C* HT = TW + 4096;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    C* buf = HT + 4096 + wave * (32 * WSTR);
+    const unsigned V = a.V, ov = (unsigned)a.ov;
+    unsigned long long c0 = 0, r0c = 0;
+    if (a.clk && t == 0) { c0 = __builtin_readcyclecounter(); asm volatile("s_memrealtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(r0c)); }
+    for (int idx = t; idx < 4096; idx += 256) {
+        const int rho = idx >> 6, l = idx & 63, f = f64map(rho);
+        TW[idx] = a.wtab[(l * f) & (L - 1)];
+        const C h = a.hs[l + 64 * f];
+        HT[idx] = C{h[0] * (1.0f / L), h[1] * (1.0f / L)};
+    }
+    __syncthreads();
+    auto transform = [&](C (&v)[64]) {
+        wave_fft4096<-1>(v, lane, TW, buf);
+        C u[64];
+#pragma unroll
+        for (int i = 0; i < 64; ++i) {
+            const int rho = 16 * (i & 3) + (i >> 2); // the register that holds frequency lane + 64 i
+            u[i] = cmul(v[rho], HT[rho * 64 + lane]);
+        }
+        wave_fft4096<1>(u, lane, TW, buf);
+#pragma unroll
+        for (int rho = 0; rho < 64; ++rho) v[rho] = u[rho];
+    };
+    const unsigned GW = gridDim.x * 4;
+    // ---- edge blocks (window wraps around the vector, or outputs run past its end): general code, first
+    {
+        const unsigned nedge = nb_lo + (a.blocks - nb_hi);
+        for (unsigned e = blockIdx.x * 4 + wave; e < nedge; e += GW) {
+            const unsigned b = e < nb_lo ? e : nb_hi + (e - nb_lo);
+            long long sb = ((long long)b * V + a.in_off) % (long long)a.n;
+            if (sb < 0) sb += a.n;
+            C v[64];
+#pragma unroll
+            for (int r = 0; r < 64; ++r) {
+                unsigned i = (unsigned)sb + lane + 64u * r; // < 2 n (n >= 4096 here)
+                if (i >= a.n) i -= a.n;
+                v[r] = a.x[i];
+            }
+            transform(v);
+            const long long obase = (long long)b * V - ov;
+            const long long room = (long long)a.n - obase;
+            unsigned lim = room <= 0 ? 0u : (room > L ? (unsigned)L : (unsigned)room);
+            if (lim > ov + V) lim = ov + V;
+            C* yb = a.y + obase;
+#pragma unroll
+            for (int rho = 0; rho < 64; ++rho) {
+                const unsigned np = lane + 64u * f64map(rho);
+                if (np >= ov && np < lim) yb[np] = v[rho];
+            }
+        }
+    }
+    // ---- interior blocks: the four waves of a workgroup take four consecutive blocks (their windows share L2 lines)
+    const unsigned slot = xcd_contiguous(blockIdx.x, gridDim.x);
+    if constexpr (PREFETCH) {
+        unsigned b = nb_lo + 4 * slot + wave;
+        C nxt[64];
+        if (b < nb_hi) {
+            const C* xb = a.x + ((long long)b * V + a.in_off);
+#pragma unroll
+            for (int r = 0; r < 64; ++r) nxt[r] = xb[lane + 64 * r];
+        }
+        for (; b < nb_hi; b += GW) {
+            C* yb = a.y + ((long long)b * V - ov);
+            C v[64];
+#pragma unroll
+            for (int r = 0; r < 64; ++r) v[r] = nxt[r];
+            // the next block's loads go out now (the last block re-reads its own window: no branch in the loop body)
+            const unsigned bn = b + GW < nb_hi ? b + GW : b;
+            const C* xn = a.x + ((long long)bn * V + a.in_off);
+#pragma unroll
+            for (int r = 0; r < 64; ++r) nxt[r] = xn[lane + 64 * r];
+            transform(v);
+#pragma unroll
+            for (int rho = 0; rho < 64; ++rho)
+                if (f64map(rho) >= OVROWS) yb[lane + 64 * f64map(rho)] = v[rho];
+        }
+    } else
+    for (unsigned b = nb_lo + 4 * slot + wave; b < nb_hi; b += GW) {
+        const C* xb = a.x + ((long long)b * V + a.in_off);
+        C* yb = a.y + ((long long)b * V - ov);
+        C v[64];
+#pragma unroll
+        for (int r = 0; r < 64; ++r) v[r] = xb[lane + 64 * r];
+        transform(v);
+#pragma unroll
+        for (int rho = 0; rho < 64; ++rho)
+            if (f64map(rho) >= OVROWS) yb[lane + 64 * f64map(rho)] = v[rho];
+    }
+    if (a.clk && t == 0) {
+        unsigned long long c1 = __builtin_readcyclecounter(), r1;
+        asm volatile("s_memrealtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(r1));
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        a.clk[4 * blockIdx.x] = r0c; a.clk[4 * blockIdx.x + 1] = r1; a.clk[4 * blockIdx.x + 2] = c1 - c0; a.clk[4 * blockIdx.x + 3] = xcc & 7;
+    }
+}
+
 // ------------------------------------------------------------------------------------------- host
 static std::vector<std::complex<double>> fft_host(std::vector<std::complex<double>> v)
 {
@@ -942,6 +1133,8 @@ int main(int argc, char** argv)
         {"v2 dif 2 skew55", (const void*)k_v2<1, 4, 0, 55, 2>, true, 2, lds_dif, 4},
         {"v2 dif 2", (const void*)k_v2<1, 4, 0, 0, 2>, true, 2, lds_dif, 4},
         {"v2 dif 2 db", (const void*)k_v2<1, 4, 0, 1, 2>, true, 2, lds_dif, 4},
+        {"wave", (const void*)k_wave<16, false>, true, 1, (size_t)(8192 + 4 * 32 * WSTR) * sizeof(C), 4},
+        {"wave pf", (const void*)k_wave<16, true>, true, 1, (size_t)(8192 + 4 * 32 * WSTR) * sizeof(C), 4},
     };
     // clock warm-up
     {
