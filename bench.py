@@ -194,13 +194,23 @@ def run_rank(args):
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback exists for the product path)")
+    # TEST HOOK (tests/test_gpu_full_size.py): BDSP_BENCH_SHARE_GPU=1 puts every rank on GPU 0 and runs the control
+    # collectives over gloo on host tensors, so that the N-rank path (launcher, rendezvous, barriers, max over ranks, the
+    # JSON line) can run on a ONE-GPU box.  RCCL refuses two ranks on one device; the line then says so in `config`.
+    share_gpu = os.environ.get("BDSP_BENCH_SHARE_GPU") == "1"
+    if share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    cdev = torch.device("cpu") if share_gpu else dev  # where the control collectives' tensors live
     ranks_seen = 1
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
-        one = torch.ones(1, device=dev, dtype=torch.int64)
+        if share_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
+        one = torch.ones(1, device=cdev, dtype=torch.int64)
         dist.all_reduce(one)
         ranks_seen = int(one.item())
         if ranks_seen != world:
@@ -281,7 +291,7 @@ def run_rank(args):
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed], device=cdev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -313,7 +323,7 @@ def run_rank(args):
     fft_avg = max(sum(fft_ms) / len(fft_ms) - event_overhead, 1e-6)
 
     e2e = None
-    if c5:
+    if c5 and not (share_gpu and world > 1):  # (the chunked scatter/gather sends device tensors: RCCL only)
         e2e = c5_end_to_end(args, bd, torch, dist, dev, rank, world, n, m, nvec)
 
     if rank == 0:
@@ -347,7 +357,8 @@ def run_rank(args):
                 "untimed_clock_prewarm_s": args.prewarm, "untimed_prewarm_steps": pre,
                 "cold_ms_per_step_first_20_steps_after_idle": cold_ms,
                 "steps_with_kernel_events": len(events),
-                "parallelism": "independent vectors per GPU, no data-path collective",
+                "parallelism": "independent vectors per GPU, no data-path collective" + (
+                    " -- TEST HOOK BDSP_BENCH_SHARE_GPU: all ranks on GPU 0, control collectives over gloo" if share_gpu else ""),
             },
             "roofline": {
                 "kernel": "k_overlap_save_v2<R0=4> (fused load->FFT4096->xH->IFFT4096->store)",

@@ -277,3 +277,44 @@ def test_bench_py_runs_both_modes_and_prints_the_contract_fields():
     assert p.returncode == 0, p.stderr[-2000:]
     d = json.loads(p.stdout.strip().splitlines()[-1])
     assert d["config"]["vectors_per_gpu"] == 16 and d["c5_end_to_end"]["vectors"] == 16 and d["c5_end_to_end"]["ms"] > 0
+
+
+def test_bench_py_two_and_three_ranks_through_its_own_launcher_on_one_gpu():
+    """`python bench.py --gpus N` starts N ranks itself (the driver's command shape).  RCCL cannot put two ranks on
+    one device, so the test hook BDSP_BENCH_SHARE_GPU=1 keeps every rank on GPU 0 and runs the control collectives over
+    gloo: everything else -- the child processes, the rendezvous, the barriers around the timed region, the maximum
+    over ranks, `ranks_seen`, the whole-job aggregate -- is the real N-rank path on real hardware.  Also under
+    torch.distributed.run, the launcher the driver uses."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env["BDSP_BENCH_SHARE_GPU"] = "1"
+    one = None
+    for ranks in (1, 2, 3):
+        p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(ranks), "--steps", "30", "--warmup", "3",
+                            "--prewarm", "0.05", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, (ranks, p.stderr[-2000:])
+        lines = [l for l in p.stdout.strip().splitlines() if l.startswith("{")]
+        assert len(lines) == 1, p.stdout[-2000:]  # rank 0 alone prints
+        d = json.loads(lines[0])
+        assert d["n_gpus"] == ranks and d["ranks_seen"] == ranks and d["steps"] == 30 and d["scaling"] == "weak"
+        if ranks == 1:
+            one = d["value"]
+        else:
+            # the ranks share one GPU here, so the whole-job rate stays near the one-rank rate (it is N x work in ~N x time)
+            assert 0.5 * one < d["value"] < 1.6 * one, (ranks, one, d["value"])
+            assert "TEST HOOK" in d["config"]["parallelism"]
+    # the same two ranks under torch.distributed.run, as the driver launches them
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", "29617", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "20",
+                        "--warmup", "3", "--prewarm", "0.05", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and json.loads(lines[0])["ranks_seen"] == 2
+    # a mismatch between --gpus and the launcher's world size must fail loudly
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", "29618", os.path.join(root, "bench.py"), "--gpus", "4", "--steps", "2",
+                        "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode != 0
