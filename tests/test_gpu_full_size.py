@@ -183,6 +183,20 @@ def test_two_pass_lengths_2m_and_4m_with_every_fused_option(bits, dtype):
     assert len(v) == n and rel_l2(v.data(), orc.magnitude(ref)) < tol
 
 
+@pytest.mark.parametrize("n,dtype", [(1_000_003, np.float32), (2_000_003, np.float32), (1_000_003, np.float64)])
+def test_bluestein_lengths_over_two_pass_transforms(n, dtype):
+    """Lengths with a large prime factor run Bluestein's chirp-z on power-of-two transforms of m >= 2n - 1 points:
+    1 000 003 -> m = 2^21, 2 000 003 -> m = 2^22, the two lengths whose plan changed to two passes this round (the f32
+    2^21 one finishes in its scratch buffer).  Against numpy's f64 transform of the same input; round trip."""
+    x = orc.fill_uniform(2 * n, 77 + n, -10, 10, dtype)
+    ref = np.fft.fft(x.astype(np.float64).view(np.complex128)).view(np.float64)
+    v = DspVec(x, is_complex=True)
+    assert v.plain_fft() == 0
+    assert rel_l2(v.data(), ref) < (2e-6 if dtype == np.float32 else 1e-12)
+    assert v.plain_ifft() == 0
+    assert rel_l2(v.data().astype(np.float64) / n, x) < (4e-6 if dtype == np.float32 else 1e-12)
+
+
 def test_c2_batch_of_40_fft_magnitude_in_cache_sized_chunks():
     """40 x 1 048 576-point complex f32 plain_fft -> magnitude in ONE device call (config C2 batched): 320 MB of data, which
     the library walks in two chunks of 20 vectors that share the scratch buffer (fft_two_buffers, capi.cpp).  The
