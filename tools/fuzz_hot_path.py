@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Randomised differential run of the hot path against the oracle: random lengths (any n, with smooth, prime and
 power-of-two ones mixed in), random tap counts, random interpolation factors, both precisions, real and complex.
-Seeded; prints the first mismatch and exits non-zero.  usage: fuzz_hot_path.py [seconds] [seed]"""
+Seeded; prints the first mismatch and exits non-zero.  usage: fuzz_hot_path.py [seconds] [seed] [size scale]
+(size scale 8 reaches the 2^21-point two-pass plans and their Bluestein users)"""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
@@ -11,6 +12,7 @@ from basic_dsp_amd import DspVec, DspMat, vector as V
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 12345)
+SCALE = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 
 def rel(got, ref):
     ref = np.asarray(ref, np.float64); got = np.asarray(got, np.float64)
@@ -18,6 +20,7 @@ def rel(got, ref):
     return np.linalg.norm(got - ref) / (d if d > 0 else 1.0)
 
 def pick_n(hi):
+    hi = hi * SCALE
     k = rng.integers(0, 5)
     if k == 0: return int(2 ** rng.integers(0, int(np.log2(hi)) + 1))
     if k == 1:  # smooth
