@@ -305,6 +305,12 @@ def test_bench_py_two_and_three_ranks_through_its_own_launcher_on_one_gpu():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
     env["BDSP_BENCH_SHARE_GPU"] = "1"
+
+    def free_port():
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            return str(sk.getsockname()[1])
     one = None
     for ranks in (1, 2, 3):
         p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(ranks), "--steps", "30", "--warmup", "3",
@@ -322,13 +328,13 @@ def test_bench_py_two_and_three_ranks_through_its_own_launcher_on_one_gpu():
             assert "TEST HOOK" in d["config"]["parallelism"]
     # the same two ranks under torch.distributed.run, as the driver launches them
     p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-                        "127.0.0.1", "--master-port", "29617", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "20",
+                        "127.0.0.1", "--master-port", free_port(), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "20",
                         "--warmup", "3", "--prewarm", "0.05", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [l for l in p.stdout.strip().splitlines() if l.startswith("{")]
     assert len(lines) == 1 and json.loads(lines[0])["ranks_seen"] == 2
     # a mismatch between --gpus and the launcher's world size must fail loudly
     p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-                        "127.0.0.1", "--master-port", "29618", os.path.join(root, "bench.py"), "--gpus", "4", "--steps", "2",
+                        "127.0.0.1", "--master-port", free_port(), os.path.join(root, "bench.py"), "--gpus", "4", "--steps", "2",
                         "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode != 0
