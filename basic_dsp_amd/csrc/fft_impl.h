@@ -109,6 +109,9 @@ template <typename T, int RP, int W>
 constexpr bool pass_lds_twiddles()
 {
     constexpr size_t base = (size_t)W * col_stride(RP, W) * sizeof(cpx<T>), tab = (size_t)RP * sizeof(cpx<T>);
+    // ... and always for the 4-wide 1024-point f32 tiles: the plan picks them only when the launch has fewer than two
+    // tiles per CU (one 2^20-point vector: 256 tiles), where the fourth resident workgroup the table costs is never there
+    if (sizeof(T) == 4 && RP == 1024 && W == 4) return true;
     return RP >= 256 && pass_wgs_per_cu(base, W * (RP / 16)) == pass_wgs_per_cu(base + tab, W * (RP / 16));
 }
 
