@@ -34,11 +34,7 @@
 //     that is already the busiest; not built.
 #include "bdsp_internal.h"
 #include <cstdlib>
-
-// 1: stage-2 twiddles in a 2 KB LDS table (130 VGPRs), 0: in registers (164 VGPRs)
-#ifndef BDSP_CONV_TW2_LDS
-#define BDSP_CONV_TW2_LDS 1
-#endif
+#include <type_traits>
 
 namespace bdsp {
 
@@ -86,21 +82,50 @@ __global__ __launch_bounds__(256, sizeof(T) == 4 ? 3 : 2) void k_overlap_save_v2
     const unsigned ut = t;
     const T hscale = (T)1 / (T)L;
     auto tww = [&](int mm) { return a.wtab[mm]; };
-    // stage-2 twiddles w256^((t & 15) r) in registers (the LDS table of the first generation cost 30 LDS reads per block
-    // inside the dependency chain: 62.1 -> 60.9 us in the lab), stage-3 twiddles as six values (w^r = w^(4a) w^b)
-    // stage-3 twiddles w4096^(t r), r = 1..15, all in registers (f32): the six-value split of the first generation (w^r =
-    // w^(4a) w^b) cost nine extra multiplies per transform -- 62.0 -> 60.6 us in the lab, and the kernel still fits three
-    // workgroups per CU (166 VGPRs).  f64 keeps the split.  Stage-2 twiddles: a 2 KB LDS table (registers measured equal).
-    C32 hreg[16], tw3[F32 ? 15 : 1], tw3a[3], tw3b[3];
-    C32* tw2l = lds + (F32 ? F::LDS_ELEMS3 : F::LDS_ELEMS);
-    const C32* tw2p = tw2l + (t & 15) * 17;
-    if (t < 240) {
-        int k = t / 15, r = t % 15 + 1;
-        tw2l[k * 17 + r - 1] = a.wtab[r * k * 16];
+    // Twiddles.  f32 (round 3): stages 2 and 3 are twiddled 16-point transforms in FMA form (fft_core.h dft16_tw: the
+    // fifteen input twiddles ride on the multiply-adds of four radix-2 layers, 96 packed instructions instead of
+    // 30 + 76) and need eight table values per stage and thread -- all sixteen in registers, no LDS table; the
+    // inverse's last stage does not compute the R0 rows the block discards.  Lab (tools/lab/conv_lab.hip, k_v3):
+    // 61.0 -> 59.8 us, 158 VGPRs.  f64 runs stage 2 in the same FMA form with its eight values read from a 2 KB LDS
+    // table and stage 3 from FOUR held values {w^8, w^4, w^2, w} (the other four are products with constants, sixteen
+    // multiply-adds per transform): 16 registers of twiddles instead of the 24 of the former six-value split
+    // (w^r = w^(4a) w^b, nine extra complex multiplies per transform) -- the f64 kernel lives at its 256-register limit.
+    constexpr int TW3_HELD = 2;
+    C32 hreg[16], tw2f[F32 ? 8 : 1], tw3f[F32 ? 8 : 1], tw3q[TW3_HELD]; // (f64: {w^2, w})
+    C32* tw2l = lds + F::LDS_ELEMS;
+    const C32* tw2p = tw2l + (t & 15) * 9;
+    if constexpr (F32) {
+        F::template load_twiddles16_fma<16>(tw2f, t, tww);
+        F::template load_twiddles16_fma<256>(tw3f, t, tww);
+    } else {
+        if (t < 128) {
+            const int k = t >> 3, j = t & 7, e = 16 * k; // the j-th value of load_twiddles16_fma<16> for thread column k
+            tw2l[k * 9 + j] = a.wtab[j == 0 ? 8 * e : j == 1 ? 4 * e : j == 2 ? 2 * e : j == 3 ? 2 * e + L / 8 : e + (j - 4) * (L / 16)];
+        }
+        if constexpr (TW3_HELD == 2) { tw3q[0] = a.wtab[2 * t]; tw3q[1] = a.wtab[t]; }
+        else F::template load_twiddles16_fma4<256>(tw3q, t, tww);
+        __syncthreads();
     }
-    if constexpr (F32) F::template load_twiddles<16, 256>(tw3, t, tww);
-    else F::template load_twiddles16_split<256>(tw3a, tw3b, t, tww);
-    __syncthreads();
+    auto stage3 = [&](C32 (&v)[16], auto D, auto P) {
+        constexpr int DIR = decltype(D)::value;
+        if constexpr (F32) dft16_tw<DIR, decltype(P)::value>(&v[0], tw3f);
+        else {
+            C32 tl[8];
+            expand_twiddles16_fma<TW3_HELD>(tw3q, tl);
+            dft16_tw<DIR, decltype(P)::value>(&v[0], tl);
+        }
+    };
+    auto stage2 = [&](C32 (&v)[16], auto D) {
+        constexpr int DIR = decltype(D)::value;
+        if constexpr (F32) dft16_tw<DIR>(&v[0], tw2f);
+        else {
+            C32 tl[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) tl[j] = tw2p[j];
+            dft16_tw<DIR>(&v[0], tl);
+        }
+    };
+    constexpr int PRUNE = R0 <= 8 ? R0 : 0;
 
     auto forward = [&](C32 (&v)[16]) {
         F::template compute<16, 1, -1>(v, t, tww);
@@ -108,12 +133,12 @@ __global__ __launch_bounds__(256, sizeof(T) == 4 ? 3 : 2) void k_overlap_save_v2
         if constexpr (F32) F::scatter_a3(v, t, lds); else F::scatter_a(v, t, lds);
         __syncthreads();
         if constexpr (F32) F::gather_a3(v, t, lds); else F::gather_a(v, t, lds);
-        F::template compute_pre<16, 16, -1>(v, tw2p);
+        stage2(v, std::integral_constant<int, -1>{});
         __syncthreads();
         if constexpr (F32) F::scatter_b3(v, t, lds); else F::scatter_b(v, t, lds);
         __syncthreads();
         F::gather_b(v, t, lds);
-        if constexpr (F32) F::template compute_pre<16, 256, -1>(v, tw3); else F::template compute_pre16_split<256, -1>(v, tw3a, tw3b);
+        stage3(v, std::integral_constant<int, -1>{}, std::integral_constant<int, 0>{});
     };
     auto inverse = [&](C32 (&v)[16]) {
         F::template compute<16, 1, 1>(v, t, tww);
@@ -121,12 +146,12 @@ __global__ __launch_bounds__(256, sizeof(T) == 4 ? 3 : 2) void k_overlap_save_v2
         if constexpr (F32) F::scatter_a3(v, t, lds); else F::scatter_a(v, t, lds);
         __syncthreads();
         if constexpr (F32) F::gather_a3(v, t, lds); else F::gather_a(v, t, lds);
-        F::template compute_pre<16, 16, 1>(v, tw2p);
+        stage2(v, std::integral_constant<int, 1>{});
         __syncthreads();
         if constexpr (F32) F::scatter_b3(v, t, lds); else F::scatter_b(v, t, lds);
         __syncthreads();
         F::gather_b(v, t, lds);
-        if constexpr (F32) F::template compute_pre<16, 256, 1>(v, tw3); else F::template compute_pre16_split<256, 1>(v, tw3a, tw3b);
+        stage3(v, std::integral_constant<int, 1>{}, std::integral_constant<int, PRUNE>{});
     };
 
     // ---- the filter spectrum, delayed by d samples, x 1/L, in register r of thread t: H'[t + 256 r]
@@ -358,7 +383,7 @@ int conv_v2_run(const T* in, T* out, size_t points, size_t batch, const T* hs, s
     if (na + nbb > interior) nbb = interior - na;
     a.na = (unsigned)na;
     a.nbb = (unsigned)nbb;
-    const size_t lds = (size_t)((sizeof(T) == 4 ? WgFft<T, L2, 256>::LDS_ELEMS3 : WgFft<T, L2, 256>::LDS_ELEMS) + 16 * 17) * sizeof(cpx<T>);
+    const size_t lds = (size_t)(sizeof(T) == 4 ? WgFft<T, L2, 256>::LDS_ELEMS3 : WgFft<T, L2, 256>::LDS_ELEMS + 16 * 17) * sizeof(cpx<T>);
     switch (r0) {
 #define BDSP_R0(N) case N: return launch_v2<T, N>(a, grid, lds, s, real);
         BDSP_R0(1) BDSP_R0(2) BDSP_R0(3) BDSP_R0(4) BDSP_R0(5) BDSP_R0(6)

@@ -327,6 +327,157 @@ BDSP_HD void dft16(bdsp_f32x2* v)
 }
 #endif
 
+// ------------------------------------------------------------------ twiddled 16-point transform, FMA form
+// X[q] = sum_r u[r] w^r W16^(r q), i.e. the radix-16 butterfly of a Stockham stage TOGETHER with its fifteen input
+// twiddles w^r, as four layers of radix-2 butterflies whose twiddle rides on the multiply-adds:
+//     s = a + (rho T) b   (two packed fma: a + Tx b, then + Ty (DIR i) b)        d = 2 a - s   (one fma)
+// Layer l (pairs 8 / 4 / 2 / 1 registers apart) needs T = w^8 | w^4 (-i)^q0 | w^2 W8^q0 (-i)^q1 |
+// w W16^(q0 + 2 q1) (-i)^q2; the rotations by -+i and the conjugation of the inverse direction are operand modifiers,
+// so EIGHT table values serve all 32 butterflies: T[0] = w^8, T[1] = w^4, T[2] = w^2, T[3] = w^2 W8, T[4 + j] = w W16^j.
+// 96 packed instructions against 30 (fifteen complex multiplies) + 76 for twiddle-then-dft16, and 8 twiddle values
+// per thread instead of 15.  Round 3: the overlap-save block kernel is bound by its instruction count.
+// PRUNE > 0 (<= 8): outputs X[0 .. PRUNE) are not needed (the block kernel discards its first rows): their
+// butterflies compute only d = a - T b (two fma).
+template <int DIR, bool ROT, typename C>
+BDSP_HD C bf_tw_s(C a, C b, C T)
+{
+    C w = DIR < 0 ? T : C{T.x, -T.y};
+    if (ROT) w = mul_dir_i<DIR>(w);
+    C u = C{a.x + w.x * b.x, a.y + w.x * b.y};
+    return C{u.x - w.y * b.y, u.y + w.y * b.x};
+}
+template <int DIR, bool ROT, typename C>
+BDSP_HD C bf_tw_d(C a, C b, C T)
+{
+    C w = DIR < 0 ? T : C{T.x, -T.y};
+    if (ROT) w = mul_dir_i<DIR>(w);
+    C u = C{a.x - w.x * b.x, a.y - w.x * b.y};
+    return C{u.x + w.y * b.y, u.y - w.y * b.x};
+}
+template <typename C>
+BDSP_HD C bf_2a_minus_s(C a, C s)
+{
+    using T = typename real_of<C>::type;
+    return C{(T)2 * a.x - s.x, (T)2 * a.y - s.y};
+}
+#ifdef BDSP_PACKED_F32
+// u = a +- (Tx | Ty) b, then s = u +- (Ty | Tx) (i b): the four (DIR, ROT) cases differ only in which half of T each
+// instruction broadcasts and which half of the swizzled b is negated.
+template <int DIR, bool ROT>
+BDSP_HD bdsp_f32x2 bf_tw_s(bdsp_f32x2 a, bdsp_f32x2 b, bdsp_f32x2 T)
+{
+    bdsp_f32x2 u, s;
+    if (!ROT) {
+        asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "=v"(u) : "v"(b), "v"(T), "v"(a));
+        if (DIR < 0) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]" : "=v"(s) : "v"(b), "v"(T), "v"(u));
+        else asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]" : "=v"(s) : "v"(b), "v"(T), "v"(u));
+    } else {
+        asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "=v"(u) : "v"(b), "v"(T), "v"(a));
+        if (DIR < 0) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[0,0,1] neg_hi:[1,0,0]" : "=v"(s) : "v"(b), "v"(T), "v"(u));
+        else asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[0,0,1] neg_lo:[1,0,0]" : "=v"(s) : "v"(b), "v"(T), "v"(u));
+    }
+    return s;
+}
+template <int DIR, bool ROT>
+BDSP_HD bdsp_f32x2 bf_tw_d(bdsp_f32x2 a, bdsp_f32x2 b, bdsp_f32x2 T)
+{
+    bdsp_f32x2 u, s;
+    if (!ROT) {
+        asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0] neg_hi:[1,0,0]" : "=v"(u) : "v"(b), "v"(T), "v"(a));
+        if (DIR < 0) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]" : "=v"(s) : "v"(b), "v"(T), "v"(u));
+        else asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]" : "=v"(s) : "v"(b), "v"(T), "v"(u));
+    } else {
+        asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]" : "=v"(u) : "v"(b), "v"(T), "v"(a));
+        if (DIR < 0) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[0,0,1] neg_lo:[1,0,0]" : "=v"(s) : "v"(b), "v"(T), "v"(u));
+        else asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[0,0,1] neg_hi:[1,0,0]" : "=v"(s) : "v"(b), "v"(T), "v"(u));
+    }
+    return s;
+}
+BDSP_HD bdsp_f32x2 bf_2a_minus_s(bdsp_f32x2 a, bdsp_f32x2 s)
+{
+    bdsp_f32x2 d;
+    asm("v_pk_fma_f32 %0, %1, 2.0, %2 op_sel_hi:[1,0,1] neg_lo:[0,0,1] neg_hi:[0,0,1]" : "=v"(d) : "v"(a), "v"(s));
+    return d;
+}
+#endif
+
+template <int DIR, bool ROT, bool NEED_S, typename C>
+BDSP_HD void bf_tw(C& a, C& b, C T)
+{
+    if (NEED_S) {
+        const C s = bf_tw_s<DIR, ROT>(a, b, T);
+        b = bf_2a_minus_s(a, s);
+        a = s;
+    } else {
+        b = bf_tw_d<DIR, ROT>(a, b, T);
+    }
+}
+
+template <int DIR, int PRUNE = 0, typename C>
+BDSP_HD void dft16_tw(C* v, const C* T)
+{
+    static_assert(PRUNE >= 0 && PRUNE <= 8, "only the last layer is pruned");
+    // layer 1: pairs (r, r + 8), q0 = 0 stays in r, q0 = 1 goes to r + 8
+#pragma unroll
+    for (int r = 0; r < 8; ++r) bf_tw<DIR, false, true>(v[r], v[r + 8], T[0]);
+    // layer 2: pairs (r, r + 4) inside each q0 half; twiddle w^4 (-i)^q0
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bf_tw<DIR, false, true>(v[r], v[r + 4], T[1]);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bf_tw<DIR, true, true>(v[8 + r], v[8 + r + 4], T[1]);
+    // layer 3: pairs (r, r + 2) inside each (q0, q1); twiddle w^2 W8^q0 (-i)^q1
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        bf_tw<DIR, false, true>(v[r], v[r + 2], T[2]);
+        bf_tw<DIR, true, true>(v[4 + r], v[4 + r + 2], T[2]);
+        bf_tw<DIR, false, true>(v[8 + r], v[8 + r + 2], T[3]);
+        bf_tw<DIR, true, true>(v[12 + r], v[12 + r + 2], T[3]);
+    }
+    // layer 4: pairs (2 m, 2 m + 1), m = q2 + 2 q1 + 4 q0; twiddle w W16^(q0 + 2 q1) (-i)^q2; the pair yields
+    // X[q] (q = q0 + 2 q1 + 4 q2 < 8) and X[q + 8]
+    bf_tw<DIR, false, (0 >= PRUNE)>(v[0], v[1], T[4]);   // q = 0
+    bf_tw<DIR, true, (4 >= PRUNE)>(v[2], v[3], T[4]);    // q = 4
+    bf_tw<DIR, false, (2 >= PRUNE)>(v[4], v[5], T[6]);   // q = 2
+    bf_tw<DIR, true, (6 >= PRUNE)>(v[6], v[7], T[6]);    // q = 6
+    bf_tw<DIR, false, (1 >= PRUNE)>(v[8], v[9], T[5]);   // q = 1
+    bf_tw<DIR, true, (5 >= PRUNE)>(v[10], v[11], T[5]);  // q = 5
+    bf_tw<DIR, false, (3 >= PRUNE)>(v[12], v[13], T[7]); // q = 3
+    bf_tw<DIR, true, (7 >= PRUNE)>(v[14], v[15], T[7]);  // q = 7
+    // v[bitrev4(q)] holds X[q]
+    C t;
+    t = v[1]; v[1] = v[8]; v[8] = t;
+    t = v[2]; v[2] = v[4]; v[4] = t;
+    t = v[3]; v[3] = v[12]; v[12] = t;
+    t = v[5]; v[5] = v[10]; v[10] = t;
+    t = v[7]; v[7] = v[14]; v[14] = t;
+    t = v[11]; v[11] = v[13]; v[13] = t;
+}
+
+// The eight values of dft16_tw from FOUR held ones q = {w^8, w^4, w^2, w}: the other four are products with the
+// constants W8, W16, W16^3 (for kernels short of registers: f64 holds 16 instead of 32 registers of twiddles per stage).
+// HELD = 2: q = {w^2, w} only; w^4 and w^8 by squaring (six more multiply-adds).
+template <int HELD = 4, typename C>
+BDSP_HD void expand_twiddles16_fma(const C* q, C* T)
+{
+    using R = typename real_of<C>::type;
+    const R h = (R)0.70710678118654752440, c1 = (R)0.92387953251128675613, s1 = (R)0.38268343236508977173;
+    const C w2 = HELD == 2 ? q[0] : q[2], w1 = HELD == 2 ? q[1] : q[3];
+    if (HELD == 2) {
+        const C w4 = C{(w2.x - w2.y) * (w2.x + w2.y), (R)2 * w2.x * w2.y};
+        T[1] = w4;
+        T[0] = C{(w4.x - w4.y) * (w4.x + w4.y), (R)2 * w4.x * w4.y};
+    } else {
+        T[0] = q[0];
+        T[1] = q[1];
+    }
+    T[2] = w2;
+    T[3] = C{(w2.x + w2.y) * h, (w2.y - w2.x) * h}; // * W8 = (h, -h)
+    T[4] = w1;
+    T[5] = cmul(w1, C{c1, -s1});
+    T[6] = C{(w1.x + w1.y) * h, (w1.y - w1.x) * h};
+    T[7] = cmul(w1, C{s1, -c1});
+}
+
 template <int R, int DIR, typename C>
 BDSP_HD void dft(C* v)
 {
@@ -410,6 +561,33 @@ struct WgFft {
             twb[i - 1] = tw(i * k * step);
             twa[i - 1] = tw(4 * i * k * step);
         }
+    }
+
+    // The eight twiddle values of dft16_tw for the radix-16 stage with previous product NS (w = w_N^(k N / (16 NS)),
+    // k = t mod NS): all of them exact table entries.
+    template <int NS, class TW>
+    static BDSP_HD void load_twiddles16_fma(cpx<T>* tws, int t, TW tw)
+    {
+        static_assert(E == 16 && N % 16 == 0, "one radix-16 butterfly per thread");
+        const int e = (t % NS) * (N / (NS * 16));
+        tws[0] = tw(8 * e);
+        tws[1] = tw(4 * e);
+        tws[2] = tw(2 * e);
+        tws[3] = tw(2 * e + N / 8);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) tws[4 + j] = tw(e + j * (N / 16));
+    }
+
+    // the four held values of expand_twiddles16_fma
+    template <int NS, class TW>
+    static BDSP_HD void load_twiddles16_fma4(cpx<T>* q, int t, TW tw)
+    {
+        static_assert(E == 16 && N % 16 == 0, "one radix-16 butterfly per thread");
+        const int e = (t % NS) * (N / (NS * 16));
+        q[0] = tw(8 * e);
+        q[1] = tw(4 * e);
+        q[2] = tw(2 * e);
+        q[3] = tw(e);
     }
 
     template <int R, int NS, class TW>

@@ -28,7 +28,9 @@ static std::vector<std::complex<double>> naive(const std::vector<cpx<T>>& x, int
     return out;
 }
 
-template <typename T, int N, int DIR>
+// FMA: the radix-16 stages after the first use the twiddled 16-point transform in FMA form (dft16_tw, eight twiddle
+// values per thread) instead of fifteen complex multiplies + dft16; PRUNE: the last stage skips outputs X[.. < PRUNE)
+template <typename T, int N, int DIR, bool FMA = false, int PRUNE = 0>
 static double run()
 {
     constexpr int NT = N / 16;
@@ -55,6 +57,11 @@ static double run()
         for (int t = 0; t < NT; ++t) {
             cpx<T>(&v)[16] = *reinterpret_cast<cpx<T>(*)[16]>(regs[t].data());
             F::template gather<P::R2>(v, t, lds.data());
+            if constexpr (FMA && P::R2 == 16) {
+                cpx<T> tws[8];
+                F::template load_twiddles16_fma<P::R1>(tws, t, tw);
+                if constexpr (P::R3 == 1) dft16_tw<DIR, PRUNE>(&v[0], tws); else dft16_tw<DIR>(&v[0], tws);
+            } else
             F::template compute<P::R2, P::R1, DIR>(v, t, tw);
         }
     }
@@ -66,6 +73,11 @@ static double run()
         for (int t = 0; t < NT; ++t) {
             cpx<T>(&v)[16] = *reinterpret_cast<cpx<T>(*)[16]>(regs[t].data());
             F::template gather<P::R3>(v, t, lds.data());
+            if constexpr (FMA && P::R3 == 16) {
+                cpx<T> tws[8];
+                F::template load_twiddles16_fma<P::R1 * P::R2>(tws, t, tw);
+                dft16_tw<DIR, PRUNE>(&v[0], tws);
+            } else
             F::template compute<P::R3, P::R1 * P::R2, DIR>(v, t, tw);
         }
     }
@@ -87,6 +99,7 @@ static double run()
     auto ref = naive<T>(x, DIR);
     double num = 0, den = 0;
     for (int k = 0; k < N; ++k) {
+        if (k < PRUNE * (N / 16)) continue; // rows the pruned last stage does not produce
         std::complex<double> d = std::complex<double>(out[k].x, out[k].y) - ref[k];
         num += std::norm(d);
         den += std::norm(ref[k]);
@@ -102,9 +115,25 @@ static int check(double tol)
     return (ef < tol && ei < tol) ? 0 : 1;
 }
 
+template <typename T, int N, int PRUNE>
+static int check_fma(double tol)
+{
+    double ef = run<T, N, -1, true, PRUNE>(), ei = run<T, N, +1, true, PRUNE>();
+    printf("%s N=%5d  FMA form, prune %d: fwd rel-L2 %.3e  inv rel-L2 %.3e\n", sizeof(T) == 4 ? "f32" : "f64", N, PRUNE, ef, ei);
+    return (ef < tol && ei < tol) ? 0 : 1;
+}
+
 int main()
 {
     int bad = 0;
+    bad += check_fma<float, 256, 0>(5e-7);
+    bad += check_fma<float, 4096, 0>(5e-7);
+    bad += check_fma<float, 4096, 4>(5e-7);
+    bad += check_fma<float, 4096, 8>(5e-7);
+    bad += check_fma<float, 4096, 1>(5e-7);
+    bad += check_fma<double, 256, 3>(1e-14);
+    bad += check_fma<double, 4096, 0>(1e-14);
+    bad += check_fma<double, 4096, 5>(1e-14);
     bad += check<float, 16>(5e-7);
     bad += check<float, 32>(5e-7);
     bad += check<float, 64>(5e-7);

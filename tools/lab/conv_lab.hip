@@ -379,6 +379,10 @@ __global__ __launch_bounds__(256, WPC) void k_v2(Args a, unsigned nb_lo, unsigne
     C tw2r[(CORE != 1 && (TWR & 1)) ? 15 : 1], tw3r[(CORE != 1 && (TWR & 2)) ? 15 : 1], tw3a[3], tw3b[3];
     C* tw2l = lds + (CORE == 2 ? F::LDS_ELEMS3 : F::LDS_ELEMS);
     const C* tw2p = tw2l + (t & 15) * 17;
+    // CORE 3 (round 3): L3 exchange layouts, stages 2 and 3 as twiddled 16-point transforms in FMA form (dft16_tw:
+    // 96 packed instructions instead of 30 + 76, eight twiddle values per stage, all in registers); TWR bit 0: the
+    // inverse's last stage does not compute the R0 rows the block discards
+    C tw2f[CORE == 3 ? 8 : 1], tw3f[CORE == 3 ? 8 : 1];
     // DIF twiddles
     C tw1[CORE == 1 ? 15 : 1], tw2[CORE == 1 ? 15 : 1];
     C* const cross = lds;
@@ -387,7 +391,15 @@ __global__ __launch_bounds__(256, WPC) void k_v2(Args a, unsigned nb_lo, unsigne
     C* const cr = cross + (t & 15) + 16 * (t >> 4);
     C* const pw = priv + 272 * (lane >> 4) + (lane & 15);
     const C* const pr = priv + 272 * (lane >> 4) + 17 * (lane & 15);
-    if constexpr (CORE == 0 || CORE == 2) {
+    if constexpr (CORE == 3) {
+        F::template load_twiddles16_fma<16>(tw2f, t, tww);
+        F::template load_twiddles16_fma<256>(tw3f, t, tww);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            C hv = a.hs[ut + 256u * r];
+            hreg[r] = C{hv.x * hscale, hv.y * hscale};
+        }
+    } else if constexpr (CORE == 0 || CORE == 2) {
         if constexpr ((TWR & 1) != 0) {
 #pragma unroll
             for (int r = 1; r < 16; ++r) tw2r[r - 1] = a.wtab[16 * r * (t & 15)];
@@ -421,7 +433,19 @@ __global__ __launch_bounds__(256, WPC) void k_v2(Args a, unsigned nb_lo, unsigne
         }
     }
     auto forward = [&](C (&v)[16]) {
-        if constexpr (CORE == 2) {
+        if constexpr (CORE == 3) {
+            F::template compute<16, 1, -1>(v, t, tww);
+            __syncthreads();
+            F::scatter_a3(v, t, lds);
+            __syncthreads();
+            F::gather_a3(v, t, lds);
+            dft16_tw<-1>(&v[0], tw2f);
+            __syncthreads();
+            F::scatter_b3(v, t, lds);
+            __syncthreads();
+            F::gather_b(v, t, lds);
+            dft16_tw<-1>(&v[0], tw3f);
+        } else if constexpr (CORE == 2) {
             constexpr int PX = (TWR & 4) ? 2 : ((TWR & 8) ? 0 : -1), PC = (TWR & 4) ? 0 : ((TWR & 8) ? 2 : -1);
             if constexpr (PC >= 0) __builtin_amdgcn_s_setprio(PC);
             F::template compute<16, 1, -1>(v, t, tww);
@@ -473,7 +497,19 @@ __global__ __launch_bounds__(256, WPC) void k_v2(Args a, unsigned nb_lo, unsigne
         for (int r = 0; r < 16; ++r) v[r] = cmul(v[r], hreg[r]);
     };
     auto inverse = [&](C (&v)[16]) {
-        if constexpr (CORE == 2) {
+        if constexpr (CORE == 3) {
+            F::template compute<16, 1, 1>(v, t, tww);
+            __syncthreads();
+            F::scatter_a3(v, t, lds);
+            __syncthreads();
+            F::gather_a3(v, t, lds);
+            dft16_tw<1>(&v[0], tw2f);
+            __syncthreads();
+            F::scatter_b3(v, t, lds);
+            __syncthreads();
+            F::gather_b(v, t, lds);
+            dft16_tw<1, ((TWR & 1) && R0 <= 8) ? R0 : 0>(&v[0], tw3f);
+        } else if constexpr (CORE == 2) {
             constexpr int PX = (TWR & 4) ? 2 : ((TWR & 8) ? 0 : -1), PC = (TWR & 4) ? 0 : ((TWR & 8) ? 2 : -1);
             if constexpr (PC >= 0) __builtin_amdgcn_s_setprio(PC);
             F::template compute<16, 1, 1>(v, t, tww);
@@ -779,6 +815,256 @@ __global__ __launch_bounds__(256, WPC) void k_v2(Args a, unsigned nb_lo, unsigne
 }
 
 
+
+// ------------------------------------------------------------------------------------------- v3 (round 3)
+// The round-3 block kernel on its own: L3 exchange layouts, stages 2 and 3 as FMA-form twiddled 16-point transforms
+// (dft16_tw), the inverse's last stage pruned by the R0 rows the block discards, WPC dispatch groups with the shares
+// RA / RB (whole rounds; the last group takes the rest).  ABL switches pieces OFF for timing-only ablations (the
+// output is then garbage): 1 global loads, 2 global stores, 4 LDS scatter/gather, 8 butterflies + filter multiply,
+// 16 barriers.
+// PF 1: two register sets take turns -- the next block's loads are issued half a block ahead (in the middle of the
+// other set's transform); PF 2: the same with all sixteen twiddle values read from LDS tables (17 KB) instead of held in
+// registers, which pays for the second register set at three workgroups per CU
+template <int R0, int ABL, int WPC, int RA, int RB, int PF = 0>
+__global__ __launch_bounds__(256, WPC) void k_v3(Args a, unsigned nb_lo, unsigned nb_hi)
+{
+    using F = WgFft<float, L, 256>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    C* lds = reinterpret_cast<C*>(smem_raw);
+    const int t = threadIdx.x;
+    const unsigned ut = t;
+    const unsigned V = a.V;
+    const float hscale = 1.0f / L;
+    auto tww = [&](int mm) { return a.wtab[mm]; };
+    C hreg[16], tw2f[8], tw3f[8];
+    F::template load_twiddles16_fma<16>(tw2f, t, tww);
+    F::template load_twiddles16_fma<256>(tw3f, t, tww);
+    C* const tab3 = lds + F::LDS_ELEMS3 + t;            // [j][256]
+    C* const tab2 = lds + F::LDS_ELEMS3 + 2048 + (t & 15); // [j][16]
+    if constexpr (PF == 2) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            tab3[256 * j] = tw3f[j];
+            if (t < 16) tab2[16 * j] = tw2f[j];
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        C hv = a.hs[ut + 256u * r];
+        hreg[r] = C{hv.x * hscale, hv.y * hscale};
+    }
+    __syncthreads();
+    auto bar = [&]() { if constexpr (!(ABL & 16)) __syncthreads(); };
+    auto half = [&](C (&v)[16], auto D) {
+        constexpr int DIR = decltype(D)::value;
+        if constexpr (!(ABL & 8)) F::template compute<16, 1, DIR>(v, t, tww);
+        bar();
+        if constexpr (!(ABL & 4)) F::scatter_a3(v, t, lds);
+        bar();
+        if constexpr (!(ABL & 4)) F::gather_a3(v, t, lds);
+        if constexpr (!(ABL & 8)) {
+            if constexpr (PF == 2) {
+                C tl[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) tl[j] = tab2[16 * j];
+                dft16_tw<DIR>(&v[0], tl);
+            } else dft16_tw<DIR>(&v[0], tw2f);
+        }
+        bar();
+        if constexpr (!(ABL & 4)) F::scatter_b3(v, t, lds);
+        bar();
+        if constexpr (!(ABL & 4)) F::gather_b(v, t, lds);
+        if constexpr (!(ABL & 8)) {
+            if constexpr (PF == 2) {
+                C tl[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) tl[j] = tab3[256 * j];
+                dft16_tw<DIR, (DIR > 0 && R0 <= 8) ? R0 : 0>(&v[0], tl);
+            } else dft16_tw<DIR, (DIR > 0 && R0 <= 8) ? R0 : 0>(&v[0], tw3f);
+        }
+    };
+    auto transform = [&](C (&v)[16]) {
+        half(v, std::integral_constant<int, -1>{});
+        if constexpr (!(ABL & 8)) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = cmul(v[r], hreg[r]);
+        }
+        half(v, std::integral_constant<int, 1>{});
+    };
+    const unsigned G = gridDim.x;
+    {
+        const unsigned nwrap = nb_lo + (a.blocks - nb_hi);
+        for (unsigned w = blockIdx.x; w < nwrap; w += G) {
+            const unsigned b = w < nb_lo ? w : nb_hi + (w - nb_lo);
+            C v[16];
+            load_block(a, b, V, ut, v);
+            transform(v);
+            store_block<false>(a, b, V, ut, v);
+        }
+    }
+    const unsigned total = nb_hi - nb_lo, gs = G / WPC;
+    unsigned na = RA * gs, nbb = WPC >= 3 ? RB * gs : 0;
+    if (na > total) na = total;
+    if (na + nbb > total) nbb = total - na;
+    const unsigned grp = blockIdx.x / gs;
+    if (grp >= (unsigned)WPC) return;
+    const unsigned lo = grp == 0 ? nb_lo : ((grp == 1 && WPC == 3) ? nb_lo + na : nb_lo + na + nbb);
+    const unsigned hi = grp == 0 ? nb_lo + na : ((grp == 1 && WPC == 3) ? nb_lo + na + nbb : nb_hi);
+    const unsigned w2 = xcd_contiguous(blockIdx.x - grp * gs, gs);
+    if constexpr (PF != 0) {
+        auto load_fast = [&](unsigned b, C (&v)[16]) {
+            const C* xb = a.x + ((long long)b * V + a.in_off);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = xb[ut + 256u * r];
+        };
+        auto store_fast = [&](unsigned b, const C (&v)[16]) {
+            C* yb = a.y + ((long long)b * V - 256 * R0);
+#pragma unroll
+            for (int r = R0; r < 16; ++r) yb[ut + 256u * r] = v[r];
+        };
+        unsigned b = lo + w2;
+        C va[16], vb[16];
+        if (b < hi) load_fast(b, va);
+        for (; b < hi; b += 2 * gs) {
+            const bool has_b = b + gs < hi;
+            if (has_b) load_fast(b + gs, vb);
+            transform(va);
+            store_fast(b, va);
+            if (has_b) {
+                half(vb, std::integral_constant<int, -1>{});
+#pragma unroll
+                for (int r = 0; r < 16; ++r) vb[r] = cmul(vb[r], hreg[r]);
+                if (b + 2 * gs < hi) load_fast(b + 2 * gs, va);
+                half(vb, std::integral_constant<int, 1>{});
+                store_fast(b + gs, vb);
+            }
+        }
+        return;
+    }
+    for (unsigned b = lo + w2; b < hi; b += gs) {
+        C v[16];
+        if constexpr (!(ABL & 1)) {
+            const C* xb = a.x + ((long long)b * V + a.in_off);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = xb[ut + 256u * r];
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) asm volatile("" : "=v"(v[r]));
+        }
+        transform(v);
+        if constexpr (!(ABL & 2)) {
+            C* yb = a.y + ((long long)b * V - 256 * R0);
+#pragma unroll
+            for (int r = R0; r < 16; ++r) yb[ut + 256u * r] = v[r];
+        } else {
+#pragma unroll
+            for (int r = R0; r < 16; ++r) asm volatile("" : : "v"(v[r]));
+        }
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------- v4 (round 3): prefetch by hand
+// Ablations of k_v3 (profiles/r03_conv_lab_variants.txt): the memory traffic alone takes 40 us at ONE workgroup per
+// CU (32 KB in flight per CU saturate the fabric), butterflies + exchanges alone 37 us at three per CU, the kernel
+// 58-61: a workgroup has requests in flight only during the ~2 us load phase of its ~8 us block, so the memory
+// system idles a third of the time.  hipcc turns a C++ double buffer into load + immediate vmcnt(0).  Here the loads
+// of block i+1 are issued by UNTRACKED inline-asm loads right after block i's data has been taken out of the
+// prefetch registers, and awaited by an explicit s_waitcnt at the end of block i (vmcnt counts loads and stores in
+// order: the twelve stores of block i, issued after the loads, may stay in flight).
+template <int R0, int WPC, int RA, int RB, int MODE = 0>
+__global__ __launch_bounds__(256, WPC) void k_v4(Args a, unsigned nb_lo, unsigned nb_hi)
+{
+    using F = WgFft<float, L, 256>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    C* lds = reinterpret_cast<C*>(smem_raw);
+    const int t = threadIdx.x;
+    const unsigned ut = t;
+    const unsigned V = a.V;
+    const float hscale = 1.0f / L;
+    auto tww = [&](int mm) { return a.wtab[mm]; };
+    C hreg[16], tw2f[8], tw3f[8];
+    F::template load_twiddles16_fma<16>(tw2f, t, tww);
+    F::template load_twiddles16_fma<256>(tw3f, t, tww);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        C hv = a.hs[ut + 256u * r];
+        hreg[r] = C{hv.x * hscale, hv.y * hscale};
+    }
+    auto half = [&](C (&v)[16], auto D) {
+        constexpr int DIR = decltype(D)::value;
+        F::template compute<16, 1, DIR>(v, t, tww);
+        __syncthreads();
+        F::scatter_a3(v, t, lds);
+        __syncthreads();
+        F::gather_a3(v, t, lds);
+        dft16_tw<DIR>(&v[0], tw2f);
+        __syncthreads();
+        F::scatter_b3(v, t, lds);
+        __syncthreads();
+        F::gather_b(v, t, lds);
+        dft16_tw<DIR, (DIR > 0 && R0 <= 8) ? R0 : 0>(&v[0], tw3f);
+    };
+    auto transform = [&](C (&v)[16]) {
+        half(v, std::integral_constant<int, -1>{});
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = cmul(v[r], hreg[r]);
+        half(v, std::integral_constant<int, 1>{});
+    };
+    const unsigned G = gridDim.x;
+    {
+        const unsigned nwrap = nb_lo + (a.blocks - nb_hi);
+        for (unsigned w = blockIdx.x; w < nwrap; w += G) {
+            const unsigned b = w < nb_lo ? w : nb_hi + (w - nb_lo);
+            C v[16];
+            load_block(a, b, V, ut, v);
+            transform(v);
+            store_block<false>(a, b, V, ut, v);
+        }
+    }
+    const unsigned total = nb_hi - nb_lo, gs = G / WPC;
+    unsigned na = RA * gs, nbb = WPC >= 3 ? RB * gs : 0;
+    if (na > total) na = total;
+    if (na + nbb > total) nbb = total - na;
+    const unsigned grp = blockIdx.x / gs;
+    if (grp >= (unsigned)WPC) return;
+    const unsigned lo = grp == 0 ? nb_lo : ((grp == 1 && WPC == 3) ? nb_lo + na : nb_lo + na + nbb);
+    const unsigned hi = grp == 0 ? nb_lo + na : ((grp == 1 && WPC == 3) ? nb_lo + na + nbb : nb_hi);
+    const unsigned w2 = xcd_contiguous(blockIdx.x - grp * gs, gs);
+    const unsigned voff = ut * 8u;
+    auto issue_loads = [&](unsigned b, C (&p)[16]) {
+        const C* xb = a.x + ((long long)b * V + a.in_off);
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+            const C* base = xb + 256 * r;
+            asm volatile("global_load_dwordx2 %0, %2, %3\n\tglobal_load_dwordx2 %1, %2, %3 offset:2048"
+                         : "=&v"(p[r]), "=&v"(p[r + 1]) : "v"(voff), "s"(base));
+        }
+    };
+    auto wait_loads = [&](C (&p)[16]) {
+        // all sixteen loads have landed; the (younger) twelve stores of the block may still be in flight
+        asm volatile("s_waitcnt vmcnt(12)"
+                     : "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3]), "+v"(p[4]), "+v"(p[5]), "+v"(p[6]), "+v"(p[7]),
+                       "+v"(p[8]), "+v"(p[9]), "+v"(p[10]), "+v"(p[11]), "+v"(p[12]), "+v"(p[13]), "+v"(p[14]), "+v"(p[15]));
+    };
+    unsigned b = lo + w2;
+    if (b >= hi) return;
+    C p[16];
+    issue_loads(b, p);
+    wait_loads(p);
+    for (; b < hi; b += gs) {
+        C v[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = p[r];
+        if (b + gs < hi) issue_loads(b + gs, p);
+        transform(v);
+        C* yb = a.y + ((long long)b * V - 256 * R0);
+#pragma unroll
+        for (int r = R0; r < 16; ++r) yb[ut + 256u * r] = v[r];
+        wait_loads(p);
+    }
+}
+
 // ------------------------------------------------------------------------------------------- wave-per-block
 // ONE WAVE per 4096-point block, 64 points per lane: 4096 = 64 x 64, each 64-point transform entirely in the lane's
 // registers (4 x 16), ONE twiddle layer (w4096^(lane k)) and ONE transposition through LDS per transform -- two
@@ -1065,6 +1351,7 @@ int main(int argc, char** argv)
     struct Variant { const char* name; const void* fn; bool aligned; int per_cu; size_t lds; int r0 = 0; };
     const size_t lds_base = (size_t)(WgFft<float, L, 256>::LDS_ELEMS + 16 * 17) * sizeof(C);
     const size_t lds_l3 = (size_t)(WgFft<float, L, 256>::LDS_ELEMS3 + 16 * 17) * sizeof(C);
+    const size_t lds_pf2 = (size_t)(WgFft<float, L, 256>::LDS_ELEMS3 + 2048 + 128) * sizeof(C);
     const size_t lds_dif = (size_t)(CROSS_ELEMS + 4 * PRIV_ELEMS) * sizeof(C);
     std::vector<Variant> vars = {
         {"base", (const void*)k_base<false>, false, 3, lds_base},
@@ -1126,6 +1413,52 @@ int main(int argc, char** argv)
         {"v2 L3 tw3full hyb 8/7/5", (const void*)k_v2<2, 4, 2, 3000000 + 80705, 3>, true, 3, lds_l3, 4},
         {"v2 L3 tw3full hyb 9/7/3", (const void*)k_v2<2, 4, 2, 3000000 + 90703, 3>, true, 3, lds_l3, 4},
         {"v2 L3 tw0 3 even", (const void*)k_v2<2, 4, 0, 0, 3>, true, 3, lds_l3, 4},
+        {"k3 full", (const void*)k_v3<4, 0, 3, 9, 8>, true, 3, lds_l3, 4},
+        {"k3 pf1 2wg 12", (const void*)k_v3<4, 0, 2, 12, 0, 1>, true, 2, lds_l3, 4},
+        {"k3 pf1 2wg 11", (const void*)k_v3<4, 0, 2, 11, 0, 1>, true, 2, lds_l3, 4},
+        {"k3 pf0 2wg 12", (const void*)k_v3<4, 0, 2, 12, 0, 0>, true, 2, lds_l3, 4},
+        {"k3 pf1 3wg 9/8", (const void*)k_v3<4, 0, 3, 9, 8, 1>, true, 3, lds_l3, 4},
+        {"k3 pf1 3wg 8/7", (const void*)k_v3<4, 0, 3, 8, 7, 1>, true, 3, lds_l3, 4},
+        {"k3 pf1 3wg 7/7", (const void*)k_v3<4, 0, 3, 7, 7, 1>, true, 3, lds_l3, 4},
+        {"k3 pf2 3wg 9/8", (const void*)k_v3<4, 0, 3, 9, 8, 2>, true, 3, lds_pf2, 4},
+        {"k3 pf2 3wg 8/7", (const void*)k_v3<4, 0, 3, 8, 7, 2>, true, 3, lds_pf2, 4},
+        {"k3 pf2 3wg 7/7", (const void*)k_v3<4, 0, 3, 7, 7, 2>, true, 3, lds_pf2, 4},
+        {"k3 pf2 2wg 12", (const void*)k_v3<4, 0, 2, 12, 0, 2>, true, 2, lds_pf2, 4},
+        {"k4 3wg 9/8", (const void*)k_v4<4, 3, 9, 8>, true, 3, lds_l3, 4},
+        {"k4 3wg 8/7", (const void*)k_v4<4, 3, 8, 7>, true, 3, lds_l3, 4},
+        {"k4 3wg 7/7", (const void*)k_v4<4, 3, 7, 7>, true, 3, lds_l3, 4},
+        {"k4 3wg 8/8", (const void*)k_v4<4, 3, 8, 8>, true, 3, lds_l3, 4},
+        {"k4 2wg 12", (const void*)k_v4<4, 2, 12, 0>, true, 2, lds_l3, 4},
+        {"k4 2wg 11", (const void*)k_v4<4, 2, 11, 0>, true, 2, lds_l3, 4},
+        {"k4 1wg", (const void*)k_v4<4, 1, 30, 0>, true, 1, lds_l3, 4},
+        {"k3 1wg full", (const void*)k_v3<4, 0, 1, 30, 0>, true, 1, lds_l3, 4},
+        {"k3 1wg nomem", (const void*)k_v3<4, 3, 1, 30, 0>, true, 1, lds_l3, 4},
+        {"k3 1wg memonly", (const void*)k_v3<4, 28, 1, 30, 0>, true, 1, lds_l3, 4},
+        {"k3 1wg noload", (const void*)k_v3<4, 1, 1, 30, 0>, true, 1, lds_l3, 4},
+        {"k3 1wg nostore", (const void*)k_v3<4, 2, 1, 30, 0>, true, 1, lds_l3, 4},
+        {"k3 2wg full", (const void*)k_v3<4, 0, 2, 12, 0>, true, 2, lds_l3, 4},
+        {"k3 2wg nomem", (const void*)k_v3<4, 3, 2, 12, 0>, true, 2, lds_l3, 4},
+        {"k3 abl noload", (const void*)k_v3<4, 1, 3, 9, 8>, true, 3, lds_l3, 4},
+        {"k3 abl nostore", (const void*)k_v3<4, 2, 3, 9, 8>, true, 3, lds_l3, 4},
+        {"k3 abl nomem", (const void*)k_v3<4, 3, 3, 9, 8>, true, 3, lds_l3, 4},
+        {"k3 abl nolds", (const void*)k_v3<4, 4, 3, 9, 8>, true, 3, lds_l3, 4},
+        {"k3 abl noldsbar", (const void*)k_v3<4, 20, 3, 9, 8>, true, 3, lds_l3, 4},
+        {"k3 abl novalu", (const void*)k_v3<4, 8, 3, 9, 8>, true, 3, lds_l3, 4},
+        {"k3 abl memonly", (const void*)k_v3<4, 28, 3, 9, 8>, true, 3, lds_l3, 4},
+        {"k3 abl membar", (const void*)k_v3<4, 12, 3, 9, 8>, true, 3, lds_l3, 4},
+        {"k3 abl valuonly", (const void*)k_v3<4, 23, 3, 9, 8>, true, 3, lds_l3, 4},
+        {"k3 abl valubar", (const void*)k_v3<4, 7, 3, 9, 8>, true, 3, lds_l3, 4},
+        {"k3 abl ldsonly", (const void*)k_v3<4, 11, 3, 9, 8>, true, 3, lds_l3, 4},
+        {"k3 abl valu+lds", (const void*)k_v3<4, 3, 3, 9, 8>, true, 3, lds_l3, 4},
+        {"k3 abl memonly even", (const void*)k_v3<4, 28, 3, 7, 7>, true, 3, lds_l3, 4},
+        {"k3 abl memonly 2wg", (const void*)k_v3<4, 28, 2, 11, 0>, true, 2, lds_l3, 4},
+        {"k3 abl memonly 4wg", (const void*)k_v3<4, 28, 4, 5, 5>, true, 4, lds_l3, 4},
+        {"v3 fma 3 rounds 9/8", (const void*)k_v2<3, 4, 0, 2000 + 908, 3>, true, 3, lds_l3, 4},
+        {"v3 fma prune 3 rounds 9/8", (const void*)k_v2<3, 4, 1, 2000 + 908, 3>, true, 3, lds_l3, 4},
+        {"v3 fma prune 3 rounds 10/8", (const void*)k_v2<3, 4, 1, 2000 + 1008, 3>, true, 3, lds_l3, 4},
+        {"v3 fma prune 3 rounds 9/7", (const void*)k_v2<3, 4, 1, 2000 + 907, 3>, true, 3, lds_l3, 4},
+        {"v3 fma prune 3 even", (const void*)k_v2<3, 4, 1, 0, 3>, true, 3, lds_l3, 4},
+        {"v3 fma prune 4 rounds 8/7/4", (const void*)k_v2<3, 4, 1, 1000000 + 80704, 4>, true, 4, lds_l3, 4},
         {"v2 st tw0 3 rounds 9/7", (const void*)k_v2<0, 4, 0, 2000 + 907, 3>, true, 3, lds_base, 4},
         {"v2 st tw3 2 rounds 12", (const void*)k_v2<0, 4, 3, 2000 + 1200, 2>, true, 2, lds_base, 4},
         {"v2 st tw3 2 rounds 13", (const void*)k_v2<0, 4, 3, 2000 + 1300, 2>, true, 2, lds_base, 4},
@@ -1150,7 +1483,18 @@ int main(int argc, char** argv)
     CK(hipMalloc(&dclk, 32 * 4096));
     std::vector<C> hy(n);
     for (auto& v : vars) {
-        if (*only && std::string(v.name) != only) continue;
+        if (*only) { // a '|'-separated list of substrings of variant names
+            bool hit = false;
+            std::string o(only);
+            size_t p0 = 0;
+            while (p0 <= o.size()) {
+                size_t p1 = o.find('|', p0);
+                if (p1 == std::string::npos) p1 = o.size();
+                if (p1 > p0 && std::string(v.name).find(o.substr(p0, p1 - p0)) != std::string::npos) hit = true;
+                p0 = p1 + 1;
+            }
+            if (!hit) continue;
+        }
         const int ov = v.r0 ? 256 * v.r0 : (v.aligned ? ov_al : ov_plain);
         unsigned V = (unsigned)(L - ov);
         if (V >= 16) V &= ~15u; // every block starts on a 128-byte line of the input
