@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstddef>
+#include <cstdlib>
 #include <cstdint>
 #include <string>
 #include <vector>
@@ -51,6 +52,16 @@ void ws_free(void* p, hipStream_t stream);
 int ws_capture_begin(hipStream_t stream);
 void ws_capture_end(hipStream_t stream, std::vector<void*>* pinned);
 int num_cus();
+
+// Experiment switches (tools/plan_probe.py, tools/chunk_probe.py, A/B runs) exist only in the LAB build of the library
+// (`make -C basic_dsp_amd/csrc lab` -> lib/libbasic_dsp_hip_lab.so, -DBDSP_LAB); the product reads no environment
+// variable and carries no kernel that only such a switch could reach.
+#ifdef BDSP_LAB
+inline const char* lab_env(const char* name) { return getenv(name); }
+#else
+inline const char* lab_env(const char*) { return nullptr; }
+#endif
+inline bool lab_flag(const char* name) { return lab_env(name) != nullptr; }
 
 struct WsBlock { // RAII workspace
     void* p = nullptr;

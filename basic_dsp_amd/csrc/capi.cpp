@@ -61,7 +61,7 @@ int fft_two_buffers(T* a, T* b, size_t points, size_t batch, bool inverse, unsig
         // a -> b -> b for ONE 2^21-point f32 transform: the last pass reads and writes the same index set per workgroup,
         // so it may run in place, and at this size (16 MB per buffer) that measured 31.9 -> 27.0 us (tools/plan_probe.py);
         // every other two-pass size measured equal or slower in place (2^20 f64: 20.8 -> 25.3 us), as did 2^24 (above)
-        static const bool force_inplace = getenv("BDSP_FFT_LAST_INPLACE") != nullptr;
+        static const bool force_inplace = lab_flag("BDSP_FFT_LAST_INPLACE");
         if (!reshaping && (force_inplace || (sizeof(T) == 4 && points == (size_t(1) << 21) && batch == 1))) {
             io.out = b;
             *in_b = true;
@@ -72,7 +72,7 @@ int fft_two_buffers(T* a, T* b, size_t points, size_t batch, bool inverse, unsig
         // 64 x 1M-point f32 -> magnitude): 402 us in one piece, 372 us in chunks of 16 (128 MB + 128 MB), 424 at 32,
         // 451 at 8 (launches too small) -- so only batches of at least two such chunks are split.  A chunk's output
         // never reaches an unprocessed chunk's input (real input, whose output is larger than the input, is excluded).
-        static const bool no_chunks = getenv("BDSP_FFT_NO_CHUNKS") != nullptr;
+        static const bool no_chunks = lab_flag("BDSP_FFT_NO_CHUNKS");
         const size_t vec_bytes = sizeof(T) * 2 * points, k0 = (size_t(128) << 20) / vec_bytes;
         if (!no_chunks && !(flags & FFT_IN_REAL) && k0 >= 1 && batch >= 2 * k0) {
             const size_t nchunks = batch / k0, k = (batch + nchunks - 1) / nchunks;
@@ -178,7 +178,7 @@ int fft_any_len(T* a, T* b, size_t n, size_t batch, bool inverse, unsigned flags
                 int window_id, T window_alpha, bool* in_b, hipStream_t s)
 {
     *in_b = false;
-    static const bool no_mixed = getenv("BDSP_FFT_NO_MIXED_RADIX") != nullptr;
+    static const bool no_mixed = lab_flag("BDSP_FFT_NO_MIXED_RADIX");
     if (!no_mixed && mr_supported<T>(n) && (batch <= 65535 || mr_resident<T>(n))) {
         // 2,3,5,7-smooth lengths: mixed-radix Stockham (mixed_radix.hip).  The four-step form goes a -> b -> a; the
         // workgroup-resident form runs in place unless the output has another shape than the input.
@@ -504,7 +504,7 @@ int b1_convolve(int is_complex, const T* src, size_t src_len, T* dst, size_t dst
     int c = check_device();
     if (c != BDSP_OK) return c;
     hipStream_t s = lib_stream();
-    static const bool no_pipeline = getenv("BDSP_B1_NO_PIPELINE") != nullptr;
+    static const bool no_pipeline = lab_flag("BDSP_B1_NO_PIPELINE");
     if (is_complex && !no_pipeline && points >= (size_t(1) << 20) && ntaps <= FUSED_MAX_TAPS && points < (size_t(1) << 31)) {
         BDSP_TRY(b1_convolve_pipelined<T>(src, dst, points, imp, ntaps));
         if (range_start) *range_start = 0;

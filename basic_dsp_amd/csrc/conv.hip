@@ -17,6 +17,7 @@
 // transform's first stage wants, so the spectrum never visits LDS.  Inner-stage twiddles live in
 // registers for the whole (persistent) workgroup in the f32 build.
 #include "bdsp_internal.h"
+#include <type_traits>
 #include <cstdlib>
 
 namespace bdsp {
@@ -90,9 +91,23 @@ __global__ __launch_bounds__(256, sizeof(T) == 4 ? (BDSP_CONV_HL2 ? 4 : 3) : 2) 
     auto tw = [&](int mm) { return wtab[mm]; };
 
     constexpr bool HREG = !BDSP_CONV_HL2;
-    cpx<T> tw3a[3], tw3b[3], hreg[HREG ? 16 : 1];
+    // stage 3 in FMA form (fft_core.h dft16_tw, round 3): f32 holds its eight twiddle values, f64 two (w^2, w) and
+    // derives the rest -- the six-value split it replaces cost nine complex multiplies per transform and 8 more registers
+    // (the f64 REAL instantiation spilled 28 bytes per lane)
+    constexpr bool F32 = sizeof(T) == 4;
+    cpx<T> tw3f[F32 ? 8 : 2], hreg[HREG ? 16 : 1];
     cpx<T>* tw2l = lds + F::LDS_ELEMS;
-    F::template load_twiddles16_split<256>(tw3a, tw3b, t, tw);
+    if constexpr (F32) F::template load_twiddles16_fma<256>(tw3f, t, tw);
+    else { tw3f[0] = wtab[2 * t]; tw3f[1] = wtab[t]; }
+    auto stage3 = [&](cpx<T> (&v)[16], auto D) {
+        constexpr int DIR = decltype(D)::value;
+        if constexpr (F32) dft16_tw<DIR>(&v[0], tw3f);
+        else {
+            cpx<T> tl[8];
+            expand_twiddles16_fma<2>(tw3f, tl);
+            dft16_tw<DIR>(&v[0], tl);
+        }
+    };
     {
         if constexpr (HREG) {
             if (!(store_all & 2)) {
@@ -134,7 +149,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 4 ? (BDSP_CONV_HL2 ? 4 : 3) : 2) 
             F::scatter_b(hv, t, lds);
             __syncthreads();
             F::gather_b(hv, t, lds);
-            F::template compute_pre16_split<256, -1>(hv, tw3a, tw3b);
+            stage3(hv, std::integral_constant<int, -1>{});
 #pragma unroll
             for (int r = 0; r < 16; ++r) hreg[r] = cpx<T>{hv[r].x * hscale, hv[r].y * hscale};
             __syncthreads();
@@ -227,7 +242,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 4 ? (BDSP_CONV_HL2 ? 4 : 3) : 2) 
         F::scatter_b(v, t, lds);
         __syncthreads();
         F::gather_b(v, t, lds);
-        F::template compute_pre16_split<256, -1>(v, tw3a, tw3b);
+        stage3(v, std::integral_constant<int, -1>{});
 
         // ---- spectrum product
 #pragma unroll
@@ -250,7 +265,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 4 ? (BDSP_CONV_HL2 ? 4 : 3) : 2) 
         F::scatter_b(v, t, lds);
         __syncthreads();
         F::gather_b(v, t, lds);
-        F::template compute_pre16_split<256, 1>(v, tw3a, tw3b);
+        stage3(v, std::integral_constant<int, 1>{});
 
         // ---- store: z[n'] for n' >= M-1 is output b*V + out_off + (n' - (M-1))
         if constexpr (REAL) {
@@ -452,7 +467,7 @@ int convolve_overlap_save(const T* in, T* out, size_t points, size_t batch, cons
                           T* last_block_out, const T* h_freq_dev, hipStream_t s)
 {
     // with the taps in hand the block kernel transforms them itself (one launch for the whole convolution)
-    static const bool no_fused_taps = getenv("BDSP_CONV_NO_FUSED_TAPS") != nullptr;
+    static const bool no_fused_taps = lab_flag("BDSP_CONV_NO_FUSED_TAPS");
     if (!BDSP_CONV_HL2 && taps_dev && !h_freq_dev && !last_block_out && !no_fused_taps)
         return conv_run_blocks<T>(in, out, points, batch, taps_dev, taps, in_off, out_off, nblocks_limit, nullptr, s,
                                   false, true);

@@ -319,7 +319,7 @@ size_t conv_v2_block_step(size_t taps)
 
 bool conv_v2_applies(size_t points, size_t taps)
 {
-    static const bool off = getenv("BDSP_CONV_V1") != nullptr;
+    static const bool off = lab_flag("BDSP_CONV_V1");
     return !off && taps >= 1 && taps - 1 <= 3 * (size_t)L2 / 4 && points >= 1 && points < (size_t(1) << 31);
 }
 

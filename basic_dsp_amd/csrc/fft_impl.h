@@ -419,8 +419,8 @@ __device__ __forceinline__ cpx<double> unit_root<double>(size_t e, size_t n)
 // stores are then compiled out: the branches themselves are free, but hipcc's code around their merge points is not
 // (the same lesson as in conv_v2.hip).
 template <typename T, int RP, int W, int DIR, bool ROWMAP, bool GEN, bool SIMPLE = false>
-__global__ __launch_bounds__(W * (RP / 16)) void k_fft_pass(FftIo<T> io, const cpx<T>* __restrict__ src,
-                                                   cpx<T>* __restrict__ dst,
+__global__ __launch_bounds__(W * (RP / 16)) void k_fft_pass(FftIo<T> io, const cpx<T>* src, // (src may equal dst: the in-place last pass)
+                                                   cpx<T>* dst,
                                                    const cpx<T>* __restrict__ wtab, size_t n,
                                                    size_t nsg, size_t tiles_per_vec, int last)
 {
@@ -758,8 +758,13 @@ static int launch_pass_rp(int rp, int w, const FftIo<T>& io, const cpx<T>* src, 
 #define BDSP_CASE(RPV, WV)                                                                         \
     if (rp == RPV && w == WV)                                                                      \
         return launch_pass<T, RPV, WV>(io, src, dst, n, nsg, batch, inverse, first, last, s);
+    // every pair plan_passes can choose by itself ...
     BDSP_CASE(64, 64) BDSP_CASE(128, 32) BDSP_CASE(256, 16) BDSP_CASE(512, 8) BDSP_CASE(1024, 4)
-    BDSP_CASE(1024, 8) BDSP_CASE(2048, 2) BDSP_CASE(2048, 4) BDSP_CASE(4096, 2) BDSP_CASE(4096, 4)
+    BDSP_CASE(1024, 8) BDSP_CASE(2048, 4)
+#ifdef BDSP_LAB
+    // ... and the ones only a BDSP_FFT_PLAN experiment reaches (the f64 4096 x 4 tiles spill 12-76 bytes per lane)
+    BDSP_CASE(2048, 2) BDSP_CASE(4096, 2) BDSP_CASE(4096, 4)
+#endif
 #undef BDSP_CASE
     set_last_error("unsupported super-radix / tile width");
     return BDSP_ERR_UNSUPPORTED;
@@ -773,8 +778,8 @@ static int plan_passes(size_t n, size_t batch, size_t esz, int rp[3], int w[3])
     int bits = 0;
     while ((size_t(1) << bits) < n) ++bits;
     if (bits > 30) return 0;
-    // experiment hook: BDSP_FFT_PLAN="4096x2,4096x2" (radix x tile width per pass)
-    if (const char* e = getenv("BDSP_FFT_PLAN")) {
+    // experiment hook (lab build only): BDSP_FFT_PLAN="4096x2,4096x2" (radix x tile width per pass)
+    if (const char* e = lab_env("BDSP_FFT_PLAN")) {
         int k = 0;
         size_t prod = 1;
         while (*e && k < 3) {
@@ -845,7 +850,7 @@ int fft_pow2(const FftIo<T>& io, T* scratch_a, T* scratch_b, size_t batch, bool 
         // *measured*: 8192 points, batch 2048: 94.8 us as two passes, 73.3 us in one workgroup each (batch 256:
         // 19.8 -> 13.2 us, a single transform 7.7 vs 7.9 us); the 16384-point instantiation (1024 threads, one
         // workgroup per CU) measured SLOWER than two passes at every batch size and is not built
-        static const bool no_wg4 = getenv("BDSP_FFT_NO_WG4") != nullptr;
+        static const bool no_wg4 = lab_flag("BDSP_FFT_NO_WG4");
         if (!no_wg4 && n == 8192 && !io_is_generic(io) && io.window_id < 0 &&
             !(io.flags & (BDSP_FFT_MAGNITUDE | FFT_OUT_REAL | FFT_IN_REAL))) return launch_wg4<T, 8192>(io, batch, inverse, s);
     }

@@ -508,7 +508,7 @@ int mr_fft(const T* in, T* out, T* scratch, size_t n, size_t batch, bool inverse
     int W = wmax;
     const int wmin = n >= 200000 ? 4 : 2; // *measured* 10^6 points: W = 8 / 4 / 2 -> 45.7 / 36.5 / 48.5 us; 10^5: 18.0 / 14.7 / 14.1
     while (W > wmin && ((n2 + W - 1) / W) * batch < (size_t)num_cus()) W /= 2;
-    static const int w_env = [] { const char* e = getenv("BDSP_MR_W"); return e ? atoi(e) : 0; }();
+    static const int w_env = [] { const char* e = lab_env("BDSP_MR_W"); return e ? atoi(e) : 0; }();
     if (w_env > 0 && w_env <= wmax) W = w_env;
     const size_t lds1 = sizeof(cpx<T>) * (2 * n1 * W + n1), lds2 = sizeof(cpx<T>) * (2 * n2 * W + n2);
     cpx<T>* tmp = reinterpret_cast<cpx<T>*>(scratch);

@@ -943,7 +943,15 @@ __global__ __launch_bounds__(256, WPC) void k_v3(Args a, unsigned nb_lo, unsigne
     }
     for (unsigned b = lo + w2; b < hi; b += gs) {
         C v[16];
-        if constexpr (!(ABL & 1)) {
+        if constexpr (ABL & 64) { // timing only: the same 32 KB as eight 16-byte loads per thread
+            const float4* xb = reinterpret_cast<const float4*>(a.x + ((long long)b * V + a.in_off));
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const float4 q = xb[ut + 256u * r];
+                v[2 * r] = C{q.x, q.y};
+                v[2 * r + 1] = C{q.z, q.w};
+            }
+        } else if constexpr (!(ABL & 1)) {
             const C* xb = a.x + ((long long)b * V + a.in_off);
 #pragma unroll
             for (int r = 0; r < 16; ++r) v[r] = xb[ut + 256u * r];
@@ -952,7 +960,11 @@ __global__ __launch_bounds__(256, WPC) void k_v3(Args a, unsigned nb_lo, unsigne
             for (int r = 0; r < 16; ++r) asm volatile("" : "=v"(v[r]));
         }
         transform(v);
-        if constexpr (!(ABL & 2)) {
+        if constexpr (ABL & 32) { // timing only: the same 24 KB as six 16-byte stores per thread
+            float4* yb = reinterpret_cast<float4*>(a.y + (long long)b * V);
+#pragma unroll
+            for (int r = R0; r < 16; r += 2) yb[ut + 128u * (r - R0)] = float4{v[r].x, v[r].y, v[r + 1].x, v[r + 1].y};
+        } else if constexpr (!(ABL & 2)) {
             C* yb = a.y + ((long long)b * V - 256 * R0);
 #pragma unroll
             for (int r = R0; r < 16; ++r) yb[ut + 256u * r] = v[r];
@@ -1438,6 +1450,11 @@ int main(int argc, char** argv)
         {"k3 1wg nostore", (const void*)k_v3<4, 2, 1, 30, 0>, true, 1, lds_l3, 4},
         {"k3 2wg full", (const void*)k_v3<4, 0, 2, 12, 0>, true, 2, lds_l3, 4},
         {"k3 2wg nomem", (const void*)k_v3<4, 3, 2, 12, 0>, true, 2, lds_l3, 4},
+        {"k3 wide st", (const void*)k_v3<4, 32, 3, 9, 8>, true, 3, lds_l3, 4},
+        {"k3 wide ld", (const void*)k_v3<4, 64, 3, 9, 8>, true, 3, lds_l3, 4},
+        {"k3 wide ldst", (const void*)k_v3<4, 96, 3, 9, 8>, true, 3, lds_l3, 4},
+        {"k3 wide ldst memonly", (const void*)k_v3<4, 96 + 28, 3, 9, 8>, true, 3, lds_l3, 4},
+        {"k3 wide ldst nolds", (const void*)k_v3<4, 96 + 4, 3, 9, 8>, true, 3, lds_l3, 4},
         {"k3 abl noload", (const void*)k_v3<4, 1, 3, 9, 8>, true, 3, lds_l3, 4},
         {"k3 abl nostore", (const void*)k_v3<4, 2, 3, 9, 8>, true, 3, lds_l3, 4},
         {"k3 abl nomem", (const void*)k_v3<4, 3, 3, 9, 8>, true, 3, lds_l3, 4},
@@ -1528,6 +1545,22 @@ int main(int argc, char** argv)
         float ms;
         CK(hipEventElapsedTime(&ms, e0, e1));
         const double us = ms * 1e3 / reps;
+        if (const char* ls = getenv("LAB_SECONDS")) { // a long run of this variant (power / clock sampling from outside)
+            const double secs = atof(ls);
+            double total_ms = 0;
+            long launches = 0;
+            while (total_ms < secs * 1e3) {
+                CK(hipEventRecord(e0, 0));
+                for (int i = 0; i < 2000; ++i) { a.x = dx[i % 3]; CK(hipLaunchKernel(v.fn, dim3(grid), dim3(256), params, v.lds, 0)); }
+                CK(hipEventRecord(e1, 0));
+                CK(hipDeviceSynchronize());
+                float m2;
+                CK(hipEventElapsedTime(&m2, e0, e1));
+                total_ms += m2; launches += 2000;
+            }
+            printf("    sustained over %.1f s: %.2f us per launch\n", total_ms / 1e3, total_ms * 1e3 / launches);
+            fflush(stdout);
+        }
         std::vector<unsigned long long> hclk(4 * grid, 0);
         CK(hipMemset(dclk, 0, 32 * 4096));
         a.clk = dclk;
