@@ -163,11 +163,18 @@ def scatter_process_gather_chunked(batch, taps, points, process_fn, chunk_vector
 
     def run_chunk(k, x):
         if cuda:
-            side.wait_stream(torch.cuda.current_stream(device))
+            main = torch.cuda.current_stream(device)
+            side.wait_stream(main)
             with torch.cuda.stream(side):
                 results[k] = process_fn(x, taps, points)
                 done[k] = torch.cuda.Event()
                 done[k].record(side)
+            # The caching allocator recycles a block for the stream it was allocated on as soon as the tensor dies:
+            # tell it about the OTHER stream that touches each buffer.  The result (allocated on the side stream) is
+            # sent / copied on the main stream after this function's caller has dropped it; the input (allocated on
+            # the main stream) is still being read by the side stream's kernels when the round loop moves on.
+            results[k].record_stream(main)
+            x.record_stream(side)
         else:
             results[k] = process_fn(x, taps, points)
 

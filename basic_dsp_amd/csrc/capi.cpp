@@ -2400,6 +2400,12 @@ int bdsp_hip_dev_convolve(int elem, const void* in, void* out, size_t points, si
 
 size_t bdsp_hip_conv_spectrum_points(void) { return conv_fft_len(0); }
 
+int bdsp_hip_fft_passes(int elem, size_t points)
+{
+    if (points == 0 || (points & (points - 1)) != 0 || points > (size_t(1) << 30)) return 0;
+    return elem == 0 ? fft_pow2_passes<float>(points) : fft_pow2_passes<double>(points);
+}
+
 int bdsp_hip_dev_conv_prepare(int elem, const void* taps_dev, size_t taps, void* spectrum_dev, void* stream)
 {
     BDSP_TRY(check_device());

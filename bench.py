@@ -63,6 +63,14 @@ def parse(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-points", type=int, default=1 << 23)
     ap.add_argument("--dry-run-launch", action="store_true", help="print the per-rank child launches of --gpus N and exit")
+    ap.add_argument("--launch-timeout", type=float, default=900.0, help="own launcher: seconds before the ranks are ended")
+    ap.add_argument("--dist-timeout", type=float, default=180.0, help="seconds a rank waits in the rendezvous / a collective")
+    ap.add_argument("--init-dist", action="store_true",
+                    help="join the RCCL process group even at world size 1 (every control collective then really runs "
+                         "through librccl on the one GPU)")
+    ap.add_argument("--test-share-gpu", action="store_true",
+                    help="TEST HOOK, needs BDSP_BENCH_SHARE_GPU=1 as well: all ranks on GPU 0, control collectives over gloo; "
+                         "the line is marked test_hook and carries no `value`")
     return ap.parse_args(argv)
 
 
@@ -83,8 +91,10 @@ def launch_ranks(args):
     child_argv = [a for a in sys.argv[1:] if a != "--dry-run-launch"]
     launches = []
     for r in range(world):
+        # (HSA_ENABLE_IPC_MODE_LEGACY=0 is set by every rank itself, run_rank(), so that this launcher and torchrun give
+        # the ranks the same environment)
         env = {"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(world), "LOCAL_WORLD_SIZE": str(world),
-               "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "HSA_ENABLE_IPC_MODE_LEGACY": "0"}
+               "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)}
         launches.append({"cmd": [sys.executable, os.path.abspath(__file__)] + child_argv, "env": env})
     if args.dry_run_launch:
         for l in launches:
@@ -95,14 +105,51 @@ def launch_ranks(args):
         env = dict(os.environ)
         env.update(l["env"])
         procs.append(subprocess.Popen(l["cmd"], env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out0, _ = procs[0].communicate()
-    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    failed, out0 = supervise(procs, args.launch_timeout)
     sys.stdout.write(out0.decode())
     sys.stdout.flush()
-    if any(codes):
-        sys.stderr.write("bench.py: rank exit codes %s\n" % codes)
+    if failed:
+        sys.stderr.write("bench.py: %s; exit codes %s\n" % (failed, [p.returncode for p in procs]))
         return 1
     return 0
+
+
+def supervise(procs, timeout_s):
+    """Waits for ALL rank processes at once.  procs[0].stdout is a pipe (rank 0 prints the JSON line) and is drained by
+    a helper thread, so a full pipe cannot block rank 0 while this thread polls.  The first rank that exits non-zero --
+    or the deadline -- ends the others at once (terminate, then kill) instead of leaving them in a rendezvous or a
+    collective until the store / RCCL timeout, minutes later.  Returns (None or what went wrong, rank 0's output)."""
+    import threading
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    deadline = time.monotonic() + timeout_s
+    failed = None
+    while True:
+        codes = [p.poll() for p in procs]
+        bad = [r for r, c in enumerate(codes) if c not in (None, 0)]
+        if bad:
+            failed = "rank %d exited with code %d" % (bad[0], codes[bad[0]])
+            break
+        if all(c == 0 for c in codes):
+            break
+        if time.monotonic() > deadline:
+            failed = "no result after %.0f s (--launch-timeout)" % timeout_s
+            break
+        time.sleep(0.05)
+    if failed:
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        t_kill = time.monotonic() + 5
+        for p in procs:
+            try:
+                p.wait(timeout=max(0.1, t_kill - time.monotonic()))
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+    reader.join(timeout=5)
+    return failed, b"".join(c for c in chunks if c)
 
 
 # ------------------------------------------------------------------------------------------ CPU baseline
@@ -122,64 +169,126 @@ def usable_cores():
     return n
 
 
-def cpu_baseline(points, taps, sample_points):
-    """The oracle on the host cores, on a bounded prefix of the workload (~10-20 s in all):
+def cpu_baseline(points, taps, sample_points, vectors=1):
+    """The oracle on the host cores, on a bounded sample of the workload (~10-20 s in all):
       reference_schedule_1core  overlap_discard exactly as the reference schedules it (scalar head, O(N*M/2) scalar
                                 tail, blocks; convolution.rs:304-461) + the FFT, one thread = the reference's default
                                 MultiCoreSettings (threading.rs:210-217)
       fair_1core                overlap-save with every output from a block (no scalar tail) + FFT, one thread
       fair_allcores             the same with blocks / butterflies spread over all host cores (OpenMP in the oracle;
                                 the reference's `parallel()` setting would use half of them, threading.rs:220-231)
-    `value` is the all-cores figure, `cores` the threads it used."""
+    Headline: one `sample_points`-point prefix of the vector.  --mode c5 (vectors > 1): as many WHOLE vectors of
+    `points` points as fit in `sample_points`, one after the other like the matrix crate's row loop
+    (matrix/src/lib.rs:195-208).  `value` is the all-cores figure, `cores` the threads it used."""
     import numpy as np
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as orc
-    n = min(points, sample_points)
+    if vectors > 1:
+        n, k = points, max(1, min(vectors, sample_points // points))
+    else:
+        n, k = min(points, sample_points), 1
     cores = usable_cores()
-    x = orc.fill_uniform(2 * n, 201601171, -10, 10, np.float32)
     h = orc.fill_uniform(2 * taps, 201601172, -1, 1, np.float32) / np.float32(taps)
     l = orc.next_power_of_two(taps)
-    t0 = time.perf_counter()
-    code, y = orc.overlap_discard(x, h, l, fair=False)
-    t1 = time.perf_counter()
-    orc.fft(y)
-    t2 = time.perf_counter()
-    code2, y2 = orc.overlap_discard(x, h, l, fair=True)
-    t3 = time.perf_counter()
-    code3, y3 = orc.overlap_save_mt(x, h, l, cores)
-    t4 = time.perf_counter()
-    orc.fft_pow2_mt(y3, False, cores)
-    t5 = time.perf_counter()
-    assert code == 0 and code2 == 0 and code3 == 0 and np.array_equal(y2, y3)
-    ref1 = n / (t2 - t0) / 1e6
-    fair1 = n / ((t3 - t2) + (t2 - t1)) / 1e6
-    fair_all = n / (t5 - t3) / 1e6
+    sec = {"reference_overlap_discard_1core": 0.0, "fft_1core": 0.0, "fair_overlap_save_1core": 0.0,
+           "fair_overlap_save_allcores": 0.0, "fft_allcores": 0.0}
+    for v in range(k):
+        x = orc.fill_uniform(2 * n, 201601171 + v, -10, 10, np.float32)
+        t0 = time.perf_counter()
+        code, y = orc.overlap_discard(x, h, l, fair=False)
+        t1 = time.perf_counter()
+        orc.fft(y)
+        t2 = time.perf_counter()
+        code2, y2 = orc.overlap_discard(x, h, l, fair=True)
+        t3 = time.perf_counter()
+        code3, y3 = orc.overlap_save_mt(x, h, l, cores)
+        t4 = time.perf_counter()
+        orc.fft_pow2_mt(y3, False, cores)
+        t5 = time.perf_counter()
+        assert code == 0 and code2 == 0 and code3 == 0 and np.array_equal(y2, y3)
+        for key, dt in zip(sec, (t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4)):
+            sec[key] += dt
+    tot = n * k
+    ref1 = tot / (sec["reference_overlap_discard_1core"] + sec["fft_1core"]) / 1e6
+    fair1 = tot / (sec["fair_overlap_save_1core"] + sec["fft_1core"]) / 1e6
+    fair_all = tot / (sec["fair_overlap_save_allcores"] + sec["fft_allcores"]) / 1e6
+    if vectors > 1:
+        sample = "%d whole vectors of %d points of the batch (convolve_signal with %d taps -> FFT each), f32" % (k, n, taps)
+    else:
+        sample = "%d-point prefix of the workload (convolve_signal with %d taps -> FFT), f32" % (n, taps)
     return {
         "value": fair_all, "unit": "Msamples/s", "cores": cores, "kind": "port",
-        "sample": "%d-point prefix of the workload (convolve_signal with %d taps -> FFT), f32" % (n, taps),
+        "sample": sample,
         "machine_logical_cores": os.cpu_count(),
         "reference_schedule_1core_Msamples_s": ref1,
         "fair_1core_Msamples_s": fair1,
         "fair_allcores_Msamples_s": fair_all,
-        "seconds": {"reference_overlap_discard_1core": t1 - t0, "fft_1core": t2 - t1, "fair_overlap_save_1core": t3 - t2,
-                    "fair_overlap_save_allcores": t4 - t3, "fft_allcores": t5 - t4},
+        "seconds": sec,
     }
 
 
-def pmc_traffic(kernel_prefix):
-    """HBM bytes per launch of a kernel as measured by rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE in separate
-    runs, gfx950 read-size correction applied) -- collected with tools/pmc.sh on this same command and committed as
-    profiles/r02_hbm_traffic.json; the live run cannot collect counters itself.  None if the profile is missing."""
-    for name in ("r02_hbm_traffic.json", "r01_hbm_traffic.json"):
-        try:
-            with open(os.path.join(ROOT, "profiles", name)) as f:
-                k = json.load(f)["kernels"]
-            for kn, v in k.items():
-                if kn.startswith(kernel_prefix):
-                    return v["hbm_bytes_per_launch"]
-        except (OSError, KeyError, ValueError):
-            pass
-    return None
+PROFILE_TAG = "r03"  # profiles/<tag>_* are the files tools/profile_r03.sh writes
+
+
+def kernel_source_sha16():
+    """Hash of the kernel sources the profiles were collected on (tools/profile_r03.sh stores it in
+    profiles/<tag>_profile_meta.json): figures from a profile of OTHER sources are not quoted."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "basic_dsp_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(d, "*.hip")) + glob.glob(os.path.join(d, "*.h")) + glob.glob(os.path.join(d, "*.cpp"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def profile_figures():
+    """What the committed rocprofv3 runs of THIS command say (tools/profile_r03.sh): HBM bytes per launch from the PMC
+    passes (FETCH_SIZE and WRITE_SIZE in separate runs, gfx950 read-size correction applied) and the kernel-trace
+    average durations.  The live run cannot collect counters itself.  Everything is None when the profile is missing
+    or was collected on other kernel sources than the ones in this tree."""
+    out = {"conv_traffic": None, "fft_traffic": None, "conv_avg_ns": None, "conv_min_ns": None, "fft_avg_ns": None, "stale": None}
+    pdir = os.path.join(ROOT, "profiles")
+    try:
+        with open(os.path.join(pdir, PROFILE_TAG + "_profile_meta.json")) as f:
+            meta = json.load(f)
+    except (OSError, ValueError):
+        return out
+    out["stale"] = meta.get("source_sha16") != kernel_source_sha16()
+    if out["stale"]:
+        return out
+    try:
+        with open(os.path.join(pdir, PROFILE_TAG + "_hbm_traffic.json")) as f:
+            k = json.load(f)["kernels"]
+        conv = [v["hbm_bytes_per_launch"] for kn, v in k.items() if kn.startswith("k_overlap_save_v2")]
+        fft = [v["hbm_bytes_per_launch"] for kn, v in k.items() if kn.startswith("k_fft_pass")]
+        if conv:
+            out["conv_traffic"] = conv[0]
+        if len(fft) == 2:  # the first-pass instantiation runs once per transform, the later-pass one twice (3 passes)
+            first = [v["hbm_bytes_per_launch"] for kn, v in k.items() if kn.startswith("k_fft_pass") and ", true, false, true>" in kn]
+            later = [v["hbm_bytes_per_launch"] for kn, v in k.items() if kn.startswith("k_fft_pass") and ", false, false, true>" in kn]
+            if first and later:
+                out["fft_traffic"] = first[0] + 2 * later[0]
+    except (OSError, KeyError, ValueError):
+        pass
+    try:
+        import csv
+        with open(os.path.join(pdir, PROFILE_TAG + "_bench_kernel_stats.csv")) as f:
+            fft_ns = 0.0
+            for row in csv.DictReader(f):
+                name = row["Name"]
+                if "bdsp::k_overlap_save_v2" in name:
+                    out["conv_avg_ns"] = float(row["AverageNs"])
+                    out["conv_min_ns"] = float(row["MinNs"])
+                elif "bdsp::k_fft_pass<float, 256, 16, -1, true" in name:
+                    fft_ns += float(row["AverageNs"])
+                elif "bdsp::k_fft_pass<float, 256, 16, -1, false" in name:
+                    fft_ns += 2 * float(row["AverageNs"])
+            out["fft_avg_ns"] = fft_ns or None
+    except (OSError, KeyError, ValueError):
+        pass
+    return out
 
 
 # ------------------------------------------------------------------------------------------ one rank
@@ -189,27 +298,38 @@ def run_rank(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus is not None and args.gpus != world:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE is %d" % (args.gpus, world))
+    # the host driver only supports dmabuf IPC; set here (before torch loads HSA) so that the own launcher and torchrun
+    # give every rank the same environment
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import datetime
     import torch
     import torch.distributed as dist
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback exists for the product path)")
-    # TEST HOOK (tests/test_gpu_full_size.py): BDSP_BENCH_SHARE_GPU=1 puts every rank on GPU 0 and runs the control
-    # collectives over gloo on host tensors, so that the N-rank path (launcher, rendezvous, barriers, max over ranks, the
-    # JSON line) can run on a ONE-GPU box.  RCCL refuses two ranks on one device; the line then says so in `config`.
-    share_gpu = os.environ.get("BDSP_BENCH_SHARE_GPU") == "1"
+    # TEST HOOK (tests/test_gpu_full_size.py): --test-share-gpu TOGETHER WITH BDSP_BENCH_SHARE_GPU=1 puts every rank on
+    # GPU 0 and runs the control collectives over gloo on host tensors, so that the N-rank path (launcher, rendezvous,
+    # barriers, max over ranks, the JSON line) can run on a ONE-GPU box.  RCCL refuses two ranks on one device.  The
+    # line is then marked `test_hook` and its `value` is null: a leaked environment variable alone changes nothing.
+    share_gpu = args.test_share_gpu and os.environ.get("BDSP_BENCH_SHARE_GPU") == "1"
     if share_gpu:
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     cdev = torch.device("cpu") if share_gpu else dev  # where the control collectives' tensors live
     ranks_seen = 1
-    if world > 1:
+    use_dist = world > 1 or args.init_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:
+            os.environ.setdefault("MASTER_PORT", str(_free_port()))
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
+        tmo = datetime.timedelta(seconds=args.dist_timeout)
         if share_gpu:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", timeout=tmo)
         else:
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, timeout=tmo)
         one = torch.ones(1, device=cdev, dtype=torch.int64)
         dist.all_reduce(one)
         ranks_seen = int(one.item())
@@ -279,18 +399,18 @@ def run_rank(args):
     for i in range(args.warmup):
         step(i)
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i, events.get(i))
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], device=cdev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -324,13 +444,17 @@ def run_rank(args):
 
     e2e = None
     if c5 and not (share_gpu and world > 1):  # (the chunked scatter/gather sends device tensors: RCCL only)
-        e2e = c5_end_to_end(args, bd, torch, dist, dev, rank, world, n, m, nvec)
+        e2e = c5_end_to_end(args, bd, torch, dist, dev, rank, world, n, m, nvec, use_dist)
 
     if rank == 0:
         samples = n * nvec * world * args.steps
         algo_bytes = 16.0 * n * nvec  # 8 B read + 8 B written per complex f32 sample
-        passes = 3 if n > (1 << 20) else (2 if n > 8192 else 1)
+        passes = int(lib.bdsp_hip_fft_passes(0, n)) or 1  # what bdsp_hip_dev_fft launches for this length
         achieved = algo_bytes / (conv_avg * 1e-3) / 1e9
+        headline = (n, m, nvec) == (POINTS, TAPS, 1)
+        prof = profile_figures() if headline else {}
+        fft_algo_gbs = 16.0 * n * nvec / (fft_avg * 1e-3) / 1e9
+        step_algo_gbs = 32.0 * n * nvec / ((conv_avg + fft_avg) * 1e-3) / 1e9
         if c5:
             workload = ("c5: %d vectors of %d complex f32 points per GPU (%d in all), batched convolve_signal(%d taps, fused "
                         "overlap-save) -> plain_fft; value = compute only, shards resident" % (nvec, n, nvec * world, m))
@@ -338,8 +462,9 @@ def run_rank(args):
             workload = ("c3+fft16m: convolve_signal(%d-pt complex f32, %d complex taps, fused overlap-save) -> "
                         "plain_fft(%d-pt), one vector per GPU" % (n, m, n))
         out = {
-            "metric": "Msamples/s for f32 complex FFT + overlap-save conv, 16M-pt",
-            "value": samples / elapsed / 1e6,
+            "metric": ("Msamples/s for f32 complex FFT + overlap-save conv, 16M-pt" if not c5 else
+                       "Msamples/s for f32 complex FFT + overlap-save conv, batch of %d x %d-pt vectors per GPU (BASELINE config C5)" % (nvec, n)),
+            "value": None if share_gpu else samples / elapsed / 1e6,
             "unit": "Msamples/s",
             "n_gpus": world,
             "ranks_seen": ranks_seen,
@@ -367,35 +492,51 @@ def run_rank(args):
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": pmc_traffic("k_overlap_save_v2") if (n, m, nvec) == (POINTS, TAPS, 1) else None,
+                "traffic": prof.get("conv_traffic"),
                 "algorithmic_bytes_per_launch": algo_bytes,
                 "avg_launch_ms": conv_avg,
                 "event_delta_ms": conv_raw, "event_pair_overhead_ms": event_overhead,
                 "dominant_per_launch": bool(conv_avg >= fft_avg / passes),
                 "share_of_step": conv_avg / (conv_avg + fft_avg),
+                # the whole step and the transform, in the same terms (algorithmic bytes: 32 B per sample for the step,
+                # 16 B per sample for the transform whatever its number of passes) -- the block kernel is a third of the step
+                "step_frac": step_algo_gbs / HBM_PEAK_GBS,
+                "fft_frac_algorithmic": fft_algo_gbs / HBM_PEAK_GBS,
+                "fft_passes": passes,
+                # HBM bytes the transform's passes moved per algorithmic byte (PMC, profiles/) -- 3.0 = three full trips
+                "fft_traffic_ratio": (prof["fft_traffic"] / (16.0 * n * nvec)) if prof.get("fft_traffic") else None,
+                # the same fraction from the committed rocprofv3 kernel trace of this command (average over ALL launches
+                # incl. the clock ramp and the cold steps, and the fastest launch)
+                "frac_rocprof": (algo_bytes / (prof["conv_avg_ns"] * 1e-9) / 1e9 / HBM_PEAK_GBS) if prof.get("conv_avg_ns") else None,
+                "frac_rocprof_min_launch": (algo_bytes / (prof["conv_min_ns"] * 1e-9) / 1e9 / HBM_PEAK_GBS) if prof.get("conv_min_ns") else None,
+                "profile": ("profiles/%s_* (%s)" % (PROFILE_TAG, "collected on these kernel sources" if prof.get("stale") is False else
+                            ("STALE: collected on other kernel sources, figures withheld" if prof.get("stale") else "missing"))) if headline else None,
             },
             "kernels": {
                 "conv_ms": conv_avg, "conv_Msamples_s": n * nvec / (conv_avg * 1e-3) / 1e6,
                 "fft_ms": fft_avg, "fft_Msamples_s": n * nvec / (fft_avg * 1e-3) / 1e6,
                 "fft_passes": passes,
-                "fft_achieved_algorithmic_GBs": 16.0 * n * nvec / (fft_avg * 1e-3) / 1e9,
-                "fft_achieved_pass_adjusted_GBs": 16.0 * n * nvec * passes / (fft_avg * 1e-3) / 1e9,
-                "fft_frac_of_roofline_algorithmic": 16.0 * n * nvec / (fft_avg * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                "step_frac_of_roofline_algorithmic": 32.0 * n * nvec / ((conv_avg + fft_avg) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "fft_achieved_algorithmic_GBs": fft_algo_gbs,
+                "fft_achieved_pass_adjusted_GBs": fft_algo_gbs * passes,
+                "fft_frac_of_roofline_algorithmic": fft_algo_gbs / HBM_PEAK_GBS,
+                "step_frac_of_roofline_algorithmic": step_algo_gbs / HBM_PEAK_GBS,
             },
         }
+        if share_gpu:
+            out["test_hook"] = True
+            out["test_hook_value"] = samples / elapsed / 1e6
         if e2e is not None:
             out["c5_end_to_end"] = e2e
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(n * nvec if c5 else n, m, args.cpu_sample_points)
+            out["cpu_baseline"] = cpu_baseline(n, m, args.cpu_sample_points, nvec if c5 else 1)
         print(json.dumps(out))
         sys.stdout.flush()
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 
 
-def c5_end_to_end(args, bd, torch, dist, dev, rank, world, n, m, nvec):
+def c5_end_to_end(args, bd, torch, dist, dev, rank, world, n, m, nvec, use_dist):
     """BASELINE config C5 end to end: rank 0 holds all `nvec * world` vectors in its HBM, scatters them in chunks,
     every rank runs the batched kernels on its chunks while the next ones are in flight, the spectra travel back two
     rounds behind (basic_dsp_amd.batch.scatter_process_gather_chunked).  Reported next to the compute-only `value`
@@ -411,12 +552,12 @@ def c5_end_to_end(args, bd, torch, dist, dev, rank, world, n, m, nvec):
     times = []
     for it in range(4):
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         t0 = time.perf_counter()
         out = scatter_process_gather_chunked(batch, taps, n, process_shard_gpu, chunk_vectors=args.chunk_vectors, device=dev)
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         times.append(time.perf_counter() - t0)
         del out

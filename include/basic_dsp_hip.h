@@ -740,6 +740,10 @@ int32_t bdsp_hip_mat_multiply_frequency_response64(MatBuf64 *m, int32_t frequenc
 int bdsp_hip_dev_fft(int elem, void *data, void *scratch, size_t points, size_t batch,
                      unsigned flags, double in_scale, int window_id, double window_alpha,
                      int *result_in_scratch, void *stream);
+/* Trips through device memory a power-of-two transform of `points` complex points makes (1: one workgroup-resident
+ * kernel, 2 or 3: global Stockham passes) -- what bdsp_hip_dev_fft will launch; 0 for lengths that are not a power
+ * of two (mixed-radix / chirp-z plans) or out of range.  The benchmark's per-pass figures read it from here. */
+int bdsp_hip_fft_passes(int elem, size_t points);
 
 /* Centred circular convolution (reference a9) of `batch` contiguous complex vectors of `points`
  * points with ONE shared filter of `taps` complex taps (device pointer), by fused overlap-save.

@@ -44,6 +44,61 @@ def test_children_that_fail_make_the_parent_fail():
         assert p.returncode != 0
 
 
+def test_a_rank_that_dies_takes_the_others_down_at_once():
+    """One rank exits non-zero while the others would sit in a rendezvous for minutes: the launcher's supervisor ends
+    them within seconds and reports the failure; and an overall deadline ends ranks that never finish."""
+    import time
+    sys.path.insert(0, ROOT)
+    import bench
+    hang = [sys.executable, "-c", "import time; print('partial', flush=True); time.sleep(600)"]
+    die = [sys.executable, "-c", "import sys, time; time.sleep(0.3); sys.exit(7)"]
+    procs = [subprocess.Popen(hang, stdout=subprocess.PIPE), subprocess.Popen(die), subprocess.Popen(hang, stdout=subprocess.DEVNULL)]
+    t0 = time.monotonic()
+    failed, out = bench.supervise(procs, 120.0)
+    assert failed and "rank 1" in failed and "7" in failed
+    assert time.monotonic() - t0 < 20
+    assert all(p.returncode is not None for p in procs) and procs[0].returncode != 0
+    assert b"partial" in out
+    procs = [subprocess.Popen(hang, stdout=subprocess.PIPE), subprocess.Popen(hang, stdout=subprocess.DEVNULL)]
+    t0 = time.monotonic()
+    failed, _ = bench.supervise(procs, 1.0)
+    assert failed and "launch-timeout" in failed and time.monotonic() - t0 < 20
+    assert all(p.returncode is not None for p in procs)
+    ok = [sys.executable, "-c", "print('{}')"]
+    procs = [subprocess.Popen(ok, stdout=subprocess.PIPE), subprocess.Popen(ok, stdout=subprocess.DEVNULL)]
+    failed, out = bench.supervise(procs, 60.0)
+    assert failed is None and out.strip() == b"{}"
+
+
+def test_stale_profiles_are_not_quoted(tmp_path, monkeypatch):
+    """roofline.traffic / frac_rocprof come from committed rocprofv3 runs; a profile collected on other kernel sources
+    than the ones in the tree must yield None, not an old number."""
+    sys.path.insert(0, ROOT)
+    import bench
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    (tmp_path / "profiles").mkdir()
+    (tmp_path / "basic_dsp_amd" / "csrc").mkdir(parents=True)
+    (tmp_path / "basic_dsp_amd" / "csrc" / "k.hip").write_text("kernel v1")
+    sha = bench.kernel_source_sha16()
+    tag = bench.PROFILE_TAG
+    (tmp_path / "profiles" / (tag + "_profile_meta.json")).write_text(json.dumps({"source_sha16": sha}))
+    (tmp_path / "profiles" / (tag + "_hbm_traffic.json")).write_text(json.dumps({"kernels": {
+        "k_overlap_save_v2<4, false>": {"hbm_bytes_per_launch": 271e6},
+        "k_fft_pass<float, 256, 16, -1, true, false, true>": {"hbm_bytes_per_launch": 268e6},
+        "k_fft_pass<float, 256, 16, -1, false, false, true>": {"hbm_bytes_per_launch": 269e6}}}))
+    (tmp_path / "profiles" / (tag + "_bench_kernel_stats.csv")).write_text(
+        '"Name","Calls","TotalDurationNs","AverageNs","Percentage","MinNs","MaxNs","StdDev"\n'
+        '"void bdsp::k_overlap_save_v2<4, false>(bdsp::ConvV2Args)",10,600000,60000.0,30,57000,70000,1.0\n'
+        '"void bdsp::k_fft_pass<float, 256, 16, -1, true, false, true>(x)",10,450000,45000.0,20,1,2,1.0\n'
+        '"void bdsp::k_fft_pass<float, 256, 16, -1, false, false, true>(x)",20,820000,41000.0,40,1,2,1.0\n')
+    f = bench.profile_figures()
+    assert f["stale"] is False and f["conv_traffic"] == 271e6 and f["fft_traffic"] == 268e6 + 2 * 269e6
+    assert f["conv_avg_ns"] == 60000.0 and f["conv_min_ns"] == 57000.0 and f["fft_avg_ns"] == 45000.0 + 2 * 41000.0
+    (tmp_path / "basic_dsp_amd" / "csrc" / "k.hip").write_text("kernel v2")
+    f = bench.profile_figures()
+    assert f["stale"] is True and f["conv_traffic"] is None and f["conv_avg_ns"] is None and f["fft_traffic"] is None
+
+
 def test_cpu_baseline_fields_are_numeric():
     sys.path.insert(0, ROOT)
     import bench
@@ -51,3 +106,6 @@ def test_cpu_baseline_fields_are_numeric():
     assert b["kind"] == "port" and b["cores"] >= 1 and b["unit"] == "Msamples/s"
     for k in ("value", "reference_schedule_1core_Msamples_s", "fair_1core_Msamples_s", "fair_allcores_Msamples_s"):
         assert isinstance(b[k], float) and b[k] > 0
+    # --mode c5: whole vectors, one after the other
+    b = bench.cpu_baseline(1 << 13, 64, 1 << 15, vectors=64)
+    assert "4 whole vectors of 8192 points" in b["sample"] and b["value"] > 0
