@@ -534,6 +534,7 @@ size_t b1_overlap_discard(T* x_time, size_t x_len, T* tmp, size_t tmp_len, const
                           size_t h_len, size_t imp_len, size_t step_size)
 {
     const size_t l = h_len / 2, xp = x_len / 2, m = imp_len / 2, step = step_size / 2;
+    set_last_error(""); // the error channel of this call: the return value is a position, never an error code
     if (l == 0 || !is_pow2(l) || step == 0 || xp < l || tmp_len < h_len || m == 0 || m > l) {
         set_last_error("overlap_discard: unsupported argument combination");
         return 0;
@@ -2472,6 +2473,20 @@ int bdsp_hip_set_device(int ordinal)
 {
     BDSP_HIP_TRY(hipSetDevice(ordinal));
     return device_ready();
+}
+
+int bdsp_hip_compute_units(void)
+{
+    if (check_device() != BDSP_OK) return 0;
+    return num_cus();
+}
+
+int bdsp_hip_conv_block_shares(int first_pct, int second_pct)
+{
+    if (first_pct < 0 && second_pct < 0) { conv_v2_set_shares(-1, -1); return 0; }
+    if (first_pct < 1 || second_pct < 0 || first_pct + second_pct > 99) return -1;
+    conv_v2_set_shares(first_pct, second_pct);
+    return 0;
 }
 
 void* bdsp_hip_event_create(void)

@@ -33,6 +33,7 @@
 //     them needs radix 16 x 4 x 16 x 4 -- 55 more packed instructions per transform than 16 x 16 x 16 on the unit
 //     that is already the busiest; not built.
 #include "bdsp_internal.h"
+#include <atomic>
 #include <cstdlib>
 #include <type_traits>
 
@@ -317,6 +318,13 @@ size_t conv_v2_block_step(size_t taps)
     return (size_t)L2 - 256 * r0;
 }
 
+static std::atomic<int> g_share_a{-1}, g_share_b{-1};
+void conv_v2_set_shares(int first_pct, int second_pct)
+{
+    g_share_a.store(first_pct);
+    g_share_b.store(second_pct);
+}
+
 bool conv_v2_applies(size_t points, size_t taps)
 {
     static const bool off = lab_flag("BDSP_CONV_V1");
@@ -376,7 +384,11 @@ int conv_v2_run(const T* in, T* out, size_t points, size_t batch, const T* hs, s
     // shares in whole rounds of gs blocks.  Three groups: ~43 % / ~37 % / rest (measured optimum 9 / 8 / 4.3 rounds of
     // 21.3); two groups: ~55 % / rest (12 of 21.3 rounds measured best for two workgroups per CU)
     const unsigned long long rounds = (interior + gs - 1) / gs;
-    unsigned long long ra = (rounds * (GROUPS == 3 ? 43 : 55) + 50) / 100, rb = GROUPS == 3 ? (rounds * 37 + 50) / 100 : 0;
+    // (bdsp_hip_conv_block_shares overrides the percentages: the guard test times equal shares against these)
+    const int sa = g_share_a.load(), sb = g_share_b.load();
+    const unsigned long long pa = sa > 0 ? (unsigned long long)sa : (GROUPS == 3 ? 43 : 55);
+    const unsigned long long pb = GROUPS == 3 ? (sa > 0 ? (unsigned long long)sb : 37) : 0;
+    unsigned long long ra = (rounds * pa + 50) / 100, rb = (rounds * pb + 50) / 100;
     if (rounds && ra == 0) ra = 1;
     unsigned long long na = ra * gs, nbb = rb * gs;
     if (na > interior) na = interior;

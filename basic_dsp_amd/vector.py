@@ -538,6 +538,8 @@ def gpu_overlap_discard(x_time, tmp, h_freq, imp_len, step_size):
     pos = fn(x_time.ctypes.data_as(C.c_void_p), x_time.size, tmp.ctypes.data_as(C.c_void_p),
              tmp.size, x_freq.ctypes.data_as(C.c_void_p), x_freq.size,
              h_freq.ctypes.data_as(C.c_void_p), h_freq.size, int(imp_len), int(step_size))
-    if pos == 0:
-        raise _lib.BackendError("overlap_discard failed: %s" % _lib.last_error())
+    # the return value is a position; failure comes out of band (the call clears last_error on entry), as in shim/hip.rs
+    err = _lib.last_error()
+    if err:
+        raise _lib.BackendError("overlap_discard failed: %s" % err)
     return pos

@@ -109,7 +109,9 @@ int bdsp_hip_convolve_vector_f64(int is_complex, const double *src, size_t src_l
  * final position is returned (ocl/mod.rs:426-520).  tmp[0 .. imp_len/2] (the caller's scalar
  * head, convolution.rs:376-385) is copied to x_time[0 .. imp_len/2] first, as the OpenCL impl
  * does.  The 1/fft_len scaling is applied here (h_freq arrives unscaled).  x_freq is scratch the
- * reference passes along; it is not touched.  Returns 0 on backend failure (see last_error). */
+ * reference passes along; it is not touched.  The return value is a POSITION; failure is reported out of band:
+ * the call clears the calling thread's bdsp_hip_last_error() on entry and leaves a message there (and returns 0)
+ * if the backend failed -- check the message, not the position. */
 size_t bdsp_hip_overlap_discard_f32(float *x_time, size_t x_len, float *tmp, size_t tmp_len,
                                     float *x_freq, size_t x_freq_len, const float *h_freq,
                                     size_t h_len, size_t imp_len, size_t step_size);
@@ -778,6 +780,15 @@ int bdsp_hip_dev_interpolatef(int elem, const void *in, void *out, size_t len, i
 int bdsp_hip_synchronize(void *stream);
 /* Binds the calling thread's work to HIP device `ordinal` (one process per GPU: call once). */
 int bdsp_hip_set_device(int ordinal);
+/* Compute units of the bound device (256 on MI355X: 8 XCDs of 32); 0 without a device. */
+int bdsp_hip_compute_units(void);
+/* Tuning knob of the fused overlap-save block kernel, also what its guard test turns: the persistent workgroups of
+ * a CU are dispatched in groups (three for f32), and the groups dispatched first get a larger share of the blocks
+ * because the hardware issues the oldest wave first.  first_pct / second_pct = percent of the blocks
+ * for the first / second dispatch group (f32 default 43 / 37, f64 55 / -); (33, 33) = equal shares; (-1, -1)
+ * restores the defaults.  Process-wide, takes effect from the next launch.  Returns 0, or -1 for shares that do not
+ * leave the last group anything to do. */
+int bdsp_hip_conv_block_shares(int first_pct, int second_pct);
 
 /* Timing hooks for bench.py: HIP events recorded on `stream`; elapsed milliseconds between
  * two recorded events.  (torch.cuda.Event only sees torch's current stream.) */

@@ -16,7 +16,8 @@ use crate::RealNumber;
 use rustfft::FftDirection;
 use std::mem;
 use std::ops::Range;
-use std::os::raw::c_int;
+use std::ffi::CStr;
+use std::os::raw::{c_char, c_int};
 
 #[link(name = "basic_dsp_hip")]
 extern "C" {
@@ -34,6 +35,12 @@ extern "C" {
         x_freq: *mut f32, x_freq_len: usize, h_freq: *const f32, h_len: usize, imp_len: usize, step_size: usize) -> usize;
     fn bdsp_hip_overlap_discard_f64(x_time: *mut f64, x_len: usize, tmp: *mut f64, tmp_len: usize,
         x_freq: *mut f64, x_freq_len: usize, h_freq: *const f64, h_len: usize, imp_len: usize, step_size: usize) -> usize;
+    fn bdsp_hip_last_error() -> *const c_char;   // per-thread; overlap_discard clears it on entry
+}
+
+/// The backend's error channel: a position is a position (0 included), a failure is a non-empty message.
+fn last_error() -> String {
+    unsafe { CStr::from_ptr(bdsp_hip_last_error()).to_string_lossy().into_owned() }
 }
 
 pub type Gpu32 = f32;            // as fallback.rs:8-24
@@ -85,7 +92,10 @@ impl<T: RealNumber> GpuSupport<T> for T {
             bdsp_hip_overlap_discard_f64(x_time.as_mut_ptr() as *mut f64, x_time.len(), tmp.as_mut_ptr() as *mut f64, tmp.len(),
                 x_freq.as_mut_ptr() as *mut f64, x_freq.len(), h_freq.as_ptr() as *const f64, h_freq.len(), imp_len, step_size)
         } };
-        assert!(pos != 0, "HIP overlap_discard failed");
+        // Failure is reported OUT OF BAND: the return value is a position, and every position -- 0 included -- is a
+        // legal one (convolution.rs:400-412 continues the scalar tail from wherever the blocks stopped).
+        let err = last_error();
+        assert!(err.is_empty(), "HIP overlap_discard failed: {}", err);
         pos
     }
 }

@@ -351,6 +351,137 @@ def test_bench_py_two_and_three_ranks_through_its_own_launcher_on_one_gpu():
     assert p.returncode != 0
 
 
+
+def _bin_by_definition(xc64, k, n, chunk=1 << 22):
+    """X[k] = sum_j x[j] exp(-2 pi i (j k mod n) / n) in f64, in chunks (the phase table of 2^27 points would be 2 GiB)."""
+    acc = 0.0 + 0.0j
+    for a in range(0, n, chunk):
+        idx = np.arange(a, min(a + chunk, n), dtype=np.int64)
+        acc += np.sum(xc64[a:a + chunk].astype(np.complex128) * np.exp(-2j * np.pi * ((idx * k) % n) / n))
+    return acc
+
+
+def test_above_2_24_points_fft_2_25_whole_spectrum_and_round_trip():
+    """2^25 points: beyond 2^24 the f32 inter-pass twiddle argument 2e/n is no longer exact in float and unit_root<float>
+    takes its double branch (fft_impl.h); three passes of 512 / 256 / 256-point columns.  Whole spectrum against the
+    oracle's f64 transform of the same f32 input (north_star: 1e-6), Parseval, round trip.  The reference accepts any
+    length (vector/src/vector_types/time_freq/mod.rs:32-63)."""
+    n = 1 << 25
+    x = orc.fill_uniform(2 * n, SEED_C3_X + 25, -10, 10, np.float32)
+    v = DspVec(x, is_complex=True)
+    assert v.plain_fft() == 0
+    X = v.data()
+    ref = orc.fft_pow2_mt(x.astype(np.float64), False, max(1, len(os.sched_getaffinity(0))))
+    assert rel_l2(X, ref) < 1e-6
+    del ref
+    e_t = float(np.sum(x.astype(np.float64) ** 2))
+    e_f = float(np.sum(X.astype(np.float64) ** 2)) / n
+    assert abs(e_f - e_t) / e_t < 1e-6
+    del X
+    assert v.plain_ifft() == 0 and v.scale(1.0 / n) == 0
+    assert rel_l2(v.data(), x) < 2e-6
+
+
+def test_above_2_24_points_fft_2_27_bins_and_parseval():
+    """2^27 points (1 GiB per buffer): two bins against the DFT definition in f64, Parseval, and the round trip."""
+    n = 1 << 27
+    x = orc.fill_uniform(2 * n, SEED_C3_X + 27, -10, 10, np.float32)
+    v = DspVec(x, is_complex=True)
+    assert v.plain_fft() == 0
+    X = v.datac()
+    xc = x.view(np.complex64)
+    scale = np.sqrt(n) * 10.0
+    for k in (1, n // 3):
+        assert abs(X[k] - _bin_by_definition(xc, k, n)) / scale < 3e-6, k
+    e_t = float(np.sum(x.astype(np.float64) ** 2))
+    e_f = 0.0
+    for a in range(0, n, 1 << 24):  # (in pieces: the f64 copy of the whole spectrum would be 2 GiB)
+        e_f += float(np.sum(np.abs(X[a:a + (1 << 24)].astype(np.complex128)) ** 2))
+    assert abs(e_f / n - e_t) / e_t < 1e-6
+    del X
+    assert v.plain_ifft() == 0 and v.scale(1.0 / n) == 0
+    assert rel_l2(v.data(), x) < 3e-6
+
+
+def test_above_2_24_points_convolution_2_25_with_257_taps():
+    """convolve_signal on 2^25 points with 257 taps (R0 = 1: 3840 outputs per block, 8739 blocks; the block kernel's
+    32-bit element indices are good to 2^31): three windows -- both wrap-around ends and an interior seam -- against the
+    f64 direct form (convolution.rs:304-461)."""
+    n, m = 1 << 25, 257
+    x = orc.fill_uniform(2 * n, SEED_C3_X + 26, -10, 10, np.float32)
+    h = (orc.fill_uniform(2 * m, SEED_C3_H + 26, -1, 1, np.float32) / np.float32(m)).astype(np.float32)
+    c = DspVec(x, is_complex=True)
+    assert c.convolve_signal(DspVec(h, is_complex=True)) == 0
+    y = c.data()
+    x64, h64 = x.astype(np.float64), h.astype(np.float64)
+    for first in (0, n - 2000, (n // 2 // 3840) * 3840 - 1000):
+        ref = orc.convolve_direct(x64, h64, True, first, 2000)
+        assert rel_l2(y[2 * first:2 * (first + 2000)], ref) < 1e-6, first
+
+
+
+def test_block_kernel_dispatch_order_assumptions_still_hold():
+    """The fused block kernel gives the workgroups dispatched FIRST a larger share of the blocks (43 / 37 / 20 %) and
+    maps workgroup b to XCD b mod 8 -- properties OBSERVED on this firmware (the oldest wave is issued first), not
+    architectural ones.  If a driver or firmware flips the dispatch order the skew silently costs
+    ~10 us per launch: time the default against equal shares through bdsp_hip_conv_block_shares and fail if the skew
+    has become more than 3 % SLOWER; the CU count must stay a multiple of the 8 XCDs the block-to-XCD map assumes.
+    The shares only move blocks between workgroups: the output is bit-identical."""
+    import ctypes as C
+    import torch
+    import basic_dsp_amd as bd
+    lib = bd.lib
+    cus = lib.bdsp_hip_compute_units()
+    assert cus > 0 and cus % 8 == 0, cus
+    n, m = 1 << 24, 1024
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev)
+    g.manual_seed(5)
+    xs = [torch.rand(2 * n, generator=g, device=dev, dtype=torch.float32) * 20 - 10 for _ in range(3)]
+    taps = (torch.rand(2 * m, generator=g, device=dev, dtype=torch.float32) * 2 - 1) / m
+    y = torch.empty(2 * n, device=dev, dtype=torch.float32)
+    sp = bd._lib.torch_stream_arg()
+
+    def run(i):
+        bd._lib.check(lib.bdsp_hip_dev_convolve(0, xs[i % 3].data_ptr(), y.data_ptr(), n, 1, taps.data_ptr(), m, sp))
+
+    def timed(reps):
+        e0, e1 = lib.bdsp_hip_event_create(), lib.bdsp_hip_event_create()
+        lib.bdsp_hip_event_record(e0, sp)
+        for i in range(reps):
+            run(i)
+        lib.bdsp_hip_event_record(e1, sp)
+        torch.cuda.synchronize()
+        ms = C.c_float(0)
+        lib.bdsp_hip_event_elapsed_ms(e0, e1, C.byref(ms))
+        lib.bdsp_hip_event_destroy(e0)
+        lib.bdsp_hip_event_destroy(e1)
+        return ms.value / reps * 1e3
+    try:
+        assert lib.bdsp_hip_conv_block_shares(60, 45) == -1  # nothing left for the last group: refused
+        for i in range(2500):  # clock ramp (DESIGN.md 5)
+            run(i)
+        torch.cuda.synchronize()
+        t_skew, t_equal = [], []
+        for rep in range(3):  # interleaved, so a drifting clock hits both alike
+            assert lib.bdsp_hip_conv_block_shares(-1, -1) == 0
+            t_skew.append(timed(300))
+            assert lib.bdsp_hip_conv_block_shares(33, 33) == 0
+            t_equal.append(timed(300))
+        run(0)
+        torch.cuda.synchronize()
+        y_equal = y.clone()
+        assert lib.bdsp_hip_conv_block_shares(-1, -1) == 0
+        run(0)
+        torch.cuda.synchronize()
+        assert torch.equal(y, y_equal)
+        skew, equal = min(t_skew), min(t_equal)
+        print("block kernel: default shares %.1f us, equal shares %.1f us" % (skew, equal))
+        assert skew < 1.03 * equal, (t_skew, t_equal)
+    finally:
+        lib.bdsp_hip_conv_block_shares(-1, -1)
+
+
 RCCL_CHILD = r"""
 import os, sys
 sys.path.insert(0, sys.argv[1])

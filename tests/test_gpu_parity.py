@@ -448,6 +448,12 @@ def test_b1_overlap_discard_drop_in(n, m, dtype):
     code, ref = orc.overlap_discard(x, h, 0)
     assert code == 0
     assert rel_l2(sig, ref) < 4 * tol_for(dtype)
+    # failure is reported out of band (shim/hip.rs checks bdsp_hip_last_error(), not the position): an unsupported
+    # argument combination leaves a message, and the next good call clears it
+    with pytest.raises(bd._lib.BackendError):
+        V.gpu_overlap_discard(x.copy(), tmp.copy(), h_freq[:-2].copy(), 2 * m, 2 * step)   # fft_len not a power of two
+    assert bd._lib.last_error() != ""
+    assert V.gpu_overlap_discard(x.copy(), tmp.copy(), h_freq, 2 * m, 2 * step) // 2 == pos and bd._lib.last_error() == ""
 
 
 # ------------------------------------------------------------------ interpolatef
