@@ -13,6 +13,9 @@
 //           y[i] = sum_m x[c + L - 1 - m] * taps_{(f - i mod f) mod f}[m],      c = ceil(i/f)
 // All tap arguments are accumulated in T by repeated +1 exactly as the reference does.
 #include "bdsp_internal.h"
+#include <cstring>
+#include <map>
+#include <mutex>
 #include "dsp_funcs.h"
 #include <vector>
 
@@ -53,22 +56,21 @@ __global__ void k_interp_taps(T* __restrict__ taps, int fid, T rolloff, int conv
     taps[id] = conv_time_value<T>(fid, rolloff, j - offset);
 }
 
+// The table path for the outputs outside [skip_lo, skip_hi) (all of them when the range is empty): workgroup `block` of
+// `nblocks`.  lt: LDS room for the ntaps * factor taps.
 template <typename T, bool CPLX>
-__global__ __launch_bounds__(256) void k_interp_table(const T* __restrict__ x, T* __restrict__ y,
-                                                       const T* __restrict__ taps, long long points,
-                                                       long long new_points, int conv_len, int factor,
-                                                       long long skip_lo, long long skip_hi)
+__device__ __forceinline__ void interp_table_body(const T* __restrict__ x, T* __restrict__ y, const T* __restrict__ taps, T* lt,
+                                                  long long points, long long new_points, int conv_len, int factor,
+                                                  long long skip_lo, long long skip_hi, unsigned block, unsigned nblocks)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    T* lt = reinterpret_cast<T*>(smem_raw);
     const int ntaps = 2 * conv_len + 1;
     for (int k = threadIdx.x; k < ntaps * factor; k += blockDim.x) lt[k] = taps[k];
     __syncthreads();
     const long long scalar_len = (long long)ntaps * factor;
     // outputs in [skip_lo, skip_hi) belong to the blocked inner kernel: walk only the two edge runs
     const long long nskip = skip_hi > skip_lo ? skip_hi - skip_lo : 0;
-    for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < new_points - nskip;
-         g += (long long)gridDim.x * blockDim.x) {
+    for (long long g = (long long)block * blockDim.x + threadIdx.x; g < new_points - nskip;
+         g += (long long)nblocks * blockDim.x) {
         const long long i = (nskip && g >= skip_lo) ? g + nskip : g;
         T sr = 0, si = 0;
         const bool edge = i < scalar_len || i + scalar_len >= new_points || new_points < 2 * scalar_len;
@@ -102,6 +104,18 @@ __global__ __launch_bounds__(256) void k_interp_table(const T* __restrict__ x, T
     }
 }
 
+
+template <typename T, bool CPLX>
+__global__ __launch_bounds__(256) void k_interp_table(const T* __restrict__ x, T* __restrict__ y,
+                                                       const T* __restrict__ taps, long long points,
+                                                       long long new_points, int conv_len, int factor,
+                                                       long long skip_lo, long long skip_hi)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    interp_table_body<T, CPLX>(x, y, taps, reinterpret_cast<T*>(smem_raw), points, new_points, conv_len, factor, skip_lo, skip_hi,
+                               blockIdx.x, gridDim.x);
+}
+
 // Inner region of the integer-factor ("simd") path, register/LDS blocked: a thread owns one input
 // position q and produces the FACTOR outputs i = FACTOR*q + s.  With c = ceil(i/f) the reference sums
 //   s = 0 :  sum_m x[q + L - 1 - m] * taps_0[m]          s > 0 :  sum_m x[q + L - m] * taps_{f-s}[m]
@@ -114,14 +128,23 @@ __global__ __launch_bounds__(256) void k_interp_table(const T* __restrict__ x, T
 // QB consecutive positions per thread: a tap read from LDS (a broadcast, but still an LDS instruction) then
 // feeds QB * FACTOR multiply-adds instead of FACTOR -- with one position per thread the kernel was bound
 // by LDS instruction issue (39 LDS reads per output point; *measured* 98 us for config C4b).
+// Round 3: the two edge runs (the few hundred outputs next to the vector's ends, which take the table path with its
+// wrap-around) ride in the SAME launch: the workgroups past `inner_blocks` run interp_table_body on them.  As a separate
+// launch in front of this one they cost 4.8 us of config C4b's 88.
 template <typename T, bool CPLX, int FACTOR, int QB>
 __global__ __launch_bounds__(256) void k_interp_inner(const T* __restrict__ x, T* __restrict__ y,
                                                       const T* __restrict__ taps, long long q_lo,
-                                                      long long q_hi, int conv_len, long long points)
+                                                      long long q_hi, int conv_len, long long points,
+                                                      long long new_points, unsigned inner_blocks)
 {
     constexpr int E = CPLX ? 2 : 1;
     constexpr int TILE = 256 * QB;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    if (blockIdx.x >= inner_blocks) {
+        interp_table_body<T, CPLX>(x, y, taps, reinterpret_cast<T*>(smem_raw), points, new_points, conv_len, FACTOR,
+                                   q_lo * FACTOR, q_hi * FACTOR, blockIdx.x - inner_blocks, gridDim.x - inner_blocks);
+        return;
+    }
     const int ntaps = 2 * conv_len + 1;
     T* lt = reinterpret_cast<T*>(smem_raw);                 // [ntaps + 1][FACTOR]
     T* lx = lt + ((FACTOR * (ntaps + 1) + 3) & ~3);         // [TILE + 2L + 2][E]
@@ -200,25 +223,57 @@ __global__ __launch_bounds__(256) void k_interp_inner(const T* __restrict__ x, T
         }
     }
     }
-#pragma unroll
-    for (int k = 0; k < QB; ++k)
-#pragma unroll
-        for (int s = 0; s < FACTOR; ++s) {
-            lo[((QB * t + k) * FACTOR + s) * E] = ar[k][s];
-            if (CPLX) lo[((QB * t + k) * FACTOR + s) * E + 1] = ai[k][s];
-        }
-    __syncthreads();
     long long nq = q_hi - q0;
     if (nq > TILE) nq = TILE;
     const long long out0 = q0 * FACTOR * E, nout = nq * FACTOR * E;
     constexpr int VN = 16 / sizeof(T); // scalars per 16-byte packet
+    constexpr int PER_THREAD = QB * FACTOR * E; // scalars a thread hands over
     if constexpr ((FACTOR * E) % VN == 0) {
-        // every position contributes whole 16-byte packets and out0 is a multiple of FACTOR*E scalars
+        // Every POSITION contributes whole 16-byte packets (so out0, a multiple of FACTOR*E scalars, is 16-byte aligned)
+        // and every thread PP of them, contiguous in the output.  Written as they lie, the PP
+        // ds_write_b128 of a thread start PP*16 bytes after its neighbour's: the hardware serves such a store in groups
+        // of 8 lanes over 32 dword banks, so with PP = 4 lanes 0/2/4/6 meet on one bank -- four-way conflicts, the 20 %
+        // LDS conflict cycles the round-2 PMC showed for config C4b.  The packets of thread t are therefore ROTATED
+        // within its own PP slots by (t / (8 / PP)) mod PP (PP < 8) or t mod PP: eight consecutive lanes then cover
+        // eight different 16-byte bank groups, and the reader -- which takes packet k = PP*t' + part from slot
+        // PP*t' + ((part + rot(t')) mod PP) -- still sees each aligned run of PP slots exactly once per PP lanes.
+        constexpr int PP = PER_THREAD / VN;
         typedef T vecT __attribute__((ext_vector_type(VN)));
-        const vecT* lov = reinterpret_cast<const vecT*>(lo);
+        vecT* lov = reinterpret_cast<vecT*>(lo);
+        auto rot = [](int q) { return PP >= 8 ? (q & (PP - 1)) : (PP > 1 ? ((q / (8 / (PP > 1 ? PP : 1))) & (PP - 1)) : 0); };
+        static_assert((PP & (PP - 1)) == 0 || PP == 3 || PP == 6 || PP == 12, "rotation below handles any PP");
+        T flat[PER_THREAD];
+#pragma unroll
+        for (int k = 0; k < QB; ++k)
+#pragma unroll
+            for (int s = 0; s < FACTOR; ++s) {
+                flat[(k * FACTOR + s) * E] = ar[k][s];
+                if (CPLX) flat[(k * FACTOR + s) * E + 1] = ai[k][s];
+            }
+        constexpr bool POW2 = (PP & (PP - 1)) == 0;
+        const int r = POW2 ? rot(t) : 0;
+#pragma unroll
+        for (int part = 0; part < PP; ++part) {
+            vecT pk;
+#pragma unroll
+            for (int e = 0; e < VN; ++e) pk[e] = flat[part * VN + e];
+            lov[PP * t + (POW2 ? ((part + r) & (PP - 1)) : part)] = pk;
+        }
+        __syncthreads();
         vecT* yv = reinterpret_cast<vecT*>(y + out0);
-        for (long long k = t; k < nout / VN; k += 256) yv[k] = lov[k];
+        for (long long k = t; k < nout / VN; k += 256) {
+            const int q = (int)(k / PP), part = (int)(k % PP);
+            yv[k] = lov[PP * q + (POW2 ? ((part + rot(q)) & (PP - 1)) : part)];
+        }
     } else {
+#pragma unroll
+        for (int k = 0; k < QB; ++k)
+#pragma unroll
+            for (int s = 0; s < FACTOR; ++s) {
+                lo[((QB * t + k) * FACTOR + s) * E] = ar[k][s];
+                if (CPLX) lo[((QB * t + k) * FACTOR + s) * E + 1] = ai[k][s];
+            }
+        __syncthreads();
         for (long long k = t; k < nout; k += 256) y[out0 + k] = lo[k];
     }
 }
@@ -308,6 +363,54 @@ __global__ __launch_bounds__(256) void k_interp_scalar_tab(const T* __restrict__
     }
 }
 
+// The per-phase tap table of the integer-factor path, CACHED per (device, precision, function, roll-off, conv_len, factor,
+// delay): a caller that interpolates vector after vector with one filter -- the normal case -- pays the table kernel
+// (4.6 us of config C4b's 88) once.  Entries live in plain device memory for the life of the process (at most 32 of at
+// most 60 KB); a 33rd parameter set takes the uncached route through the workspace.  The stream is synchronised once when
+// an entry is created, so any stream may read it afterwards (warm the plan before a graph capture, like every other table).
+struct TapKey {
+    int dev, prec, fid, conv_len, factor;
+    unsigned long long rolloff_bits, delay_bits;
+    bool operator<(const TapKey& o) const
+    {
+        if (dev != o.dev) return dev < o.dev;
+        if (prec != o.prec) return prec < o.prec;
+        if (fid != o.fid) return fid < o.fid;
+        if (conv_len != o.conv_len) return conv_len < o.conv_len;
+        if (factor != o.factor) return factor < o.factor;
+        if (rolloff_bits != o.rolloff_bits) return rolloff_bits < o.rolloff_bits;
+        return delay_bits < o.delay_bits;
+    }
+};
+static std::mutex g_tap_mu;
+static std::map<TapKey, void*> g_tap_cache;
+
+template <typename T>
+static int interp_tap_table(int fid, T rolloff, int conv_len, int f, T delay, hipStream_t s, WsBlock* fallback, const T** table)
+{
+    const int ntaps = 2 * conv_len + 1;
+    const size_t bytes = sizeof(T) * (size_t)ntaps * f;
+    int dev = 0;
+    BDSP_HIP_TRY(hipGetDevice(&dev));
+    TapKey key{dev, (int)sizeof(T), fid, conv_len, f, 0, 0};
+    { double r = (double)rolloff, d = (double)delay; memcpy(&key.rolloff_bits, &r, 8); memcpy(&key.delay_bits, &d, 8); }
+    std::lock_guard<std::mutex> lk(g_tap_mu);
+    auto it = g_tap_cache.find(key);
+    if (it != g_tap_cache.end()) { *table = static_cast<const T*>(it->second); return BDSP_OK; }
+    T* dst = nullptr;
+    const bool cache = g_tap_cache.size() < 32;
+    if (cache) BDSP_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dst), bytes));
+    else { BDSP_TRY(fallback->alloc(bytes, s)); dst = fallback->as<T>(); }
+    hipLaunchKernelGGL((k_interp_taps<T>), dim3((f * ntaps + 63) / 64), dim3(64), 0, s, dst, fid, rolloff, conv_len, f, delay);
+    BDSP_LAUNCH_CHECK();
+    if (cache) {
+        BDSP_HIP_TRY(hipStreamSynchronize(s));
+        g_tap_cache[key] = dst;
+    }
+    *table = dst;
+    return BDSP_OK;
+}
+
 template <typename T>
 int interpolatef_dev(const T* in, T* out, size_t len, bool is_complex, int fid, T rolloff, T factor,
                      T delay, size_t conv_len, T delta, hipStream_t s, T (*host_fn)(const void*, T),
@@ -332,8 +435,9 @@ int interpolatef_dev(const T* in, T* out, size_t len, bool is_complex, int fid, 
         int f = (int)rf;
         int ntaps = 2 * (int)conv_len + 1;
         WsBlock tb;
-        BDSP_TRY(tb.alloc(sizeof(T) * (size_t)ntaps * f, s));
+        const T* taps_dev = nullptr;
         if (host_fn) { // the callback variant: the same table, sampled on the host
+            BDSP_TRY(tb.alloc(sizeof(T) * (size_t)ntaps * f, s));
             std::vector<T> ht((size_t)ntaps * f);
             for (int sft = 0; sft < f; ++sft) {
                 const T offset = (T)sft / (T)f;
@@ -342,52 +446,46 @@ int interpolatef_dev(const T* in, T* out, size_t len, bool is_complex, int fid, 
             }
             BDSP_HIP_TRY(hipMemcpyAsync(tb.p, ht.data(), sizeof(T) * ht.size(), hipMemcpyHostToDevice, s));
             BDSP_HIP_TRY(hipStreamSynchronize(s));
+            taps_dev = tb.as<T>();
         } else {
-            hipLaunchKernelGGL((k_interp_taps<T>), dim3((f * ntaps + 63) / 64), dim3(64), 0, s, tb.as<T>(), fid,
-                               rolloff, (int)conv_len, f, delay);
-            BDSP_LAUNCH_CHECK();
+            BDSP_TRY(interp_tap_table<T>(fid, rolloff, (int)conv_len, f, delay, s, &tb, &taps_dev));
         }
         size_t lds = sizeof(T) * (size_t)ntaps * f;
         if (lds > 60 * 1024) { set_last_error("interpolatef: tap table exceeds LDS"); return BDSP_ERR_UNSUPPORTED; }
-        // edges (and everything, for factors without a blocked instantiation) by the generic kernel;
-        // the inner region is then overwritten by the blocked kernel where one exists
+        // edges (and everything, for factors without a blocked instantiation) by the table path; the inner region by
+        // the blocked kernel where one exists -- one launch then, the edge runs taken by its last workgroups
         const long long scalar_len = (long long)ntaps * f;
         long long q_lo = (scalar_len + f - 1) / f;                   // first q with f*q >= scalar_len
         long long q_hi = ((long long)new_points - scalar_len) / f;   // f*q + f - 1 < new_points - scalar_len
         const bool blocked = (f == 2 || f == 3 || f == 4 || f == 8) && q_hi > q_lo &&
                              (long long)new_points >= 2 * scalar_len;
-        // with the inner region left to the blocked kernel only the two edge runs remain here: size the grid for them
-        // (a 2048-workgroup launch for a few hundred outputs cost 5 us of the 88 us of config C4b)
-        size_t eblocks = blocks;
-        if (blocked) {
+        if (!blocked) {
+            if (is_complex)
+                hipLaunchKernelGGL((k_interp_table<T, true>), dim3((unsigned)blocks), dim3(256), lds, s, in, out,
+                                   taps_dev, (long long)points, (long long)new_points, (int)conv_len, f, -1LL, -1LL);
+            else
+                hipLaunchKernelGGL((k_interp_table<T, false>), dim3((unsigned)blocks), dim3(256), lds, s, in, out,
+                                   taps_dev, (long long)points, (long long)new_points, (int)conv_len, f, -1LL, -1LL);
+        } else {
             const size_t edge_outputs = new_points - (size_t)((q_hi - q_lo) * f);
-            eblocks = (edge_outputs + 255) / 256;
+            size_t eblocks = (edge_outputs + 255) / 256;
             if (eblocks > blocks) eblocks = blocks;
             if (eblocks < 1) eblocks = 1;
-        }
-        if (is_complex)
-            hipLaunchKernelGGL((k_interp_table<T, true>), dim3((unsigned)eblocks), dim3(256), lds, s, in, out,
-                               tb.as<T>(), (long long)points, (long long)new_points, (int)conv_len, f,
-                               blocked ? q_lo * f : -1LL, blocked ? q_hi * f : -1LL);
-        else
-            hipLaunchKernelGGL((k_interp_table<T, false>), dim3((unsigned)eblocks), dim3(256), lds, s, in, out,
-                               tb.as<T>(), (long long)points, (long long)new_points, (int)conv_len, f,
-                               blocked ? q_lo * f : -1LL, blocked ? q_hi * f : -1LL);
-        if (blocked) {
-            BDSP_LAUNCH_CHECK();
             const int e = is_complex ? 2 : 1;
             // positions per thread: as many as keep the output staging buffer at 32 KB
             constexpr int QB = 1;
             const int qb = is_complex ? QB : (sizeof(T) == 4 ? 4 : 1);
             const size_t tile = 256 * (size_t)qb;
             size_t lds2 = sizeof(T) * ((((size_t)f * (ntaps + 1) + 3) & ~(size_t)3) + (((tile + 2 * conv_len + 2) * e + 3) & ~(size_t)3) + tile * (size_t)f * e);
-            unsigned g = (unsigned)((q_hi - q_lo + (long long)tile - 1) / (long long)tile);
+            if (lds2 < lds) lds2 = lds;
+            const unsigned g = (unsigned)((q_hi - q_lo + (long long)tile - 1) / (long long)tile);
 #define BDSP_INNER2(FV, CP, QV)                                                                    \
     do {                                                                                           \
         auto kk = k_interp_inner<T, CP, FV, QV>;                                                   \
         if (lds2 > 64 * 1024)                                                                      \
             BDSP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2)); \
-        hipLaunchKernelGGL(kk, dim3(g), dim3(256), lds2, s, in, out, tb.as<T>(), q_lo, q_hi, (int)conv_len, (long long)points); \
+        hipLaunchKernelGGL(kk, dim3(g + (unsigned)eblocks), dim3(256), lds2, s, in, out, taps_dev, q_lo, q_hi, (int)conv_len, \
+                           (long long)points, (long long)new_points, g);                           \
     } while (0)
 #define BDSP_INNER(FV)                                                                             \
     do {                                                                                           \
