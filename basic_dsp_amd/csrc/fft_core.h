@@ -453,6 +453,27 @@ BDSP_HD void dft16_tw(C* v, const C* T)
     t = v[11]; v[11] = v[13]; v[13] = t;
 }
 
+// The twiddled 8-point transform in the same FMA form: X[q] = sum_r u[r] w^r W8^(r q) as three radix-2 layers, twelve
+// butterflies of three instructions; T[0] = w^4, T[1] = w^2, T[2] = w, T[3] = w W8 (four table values instead of seven).
+template <int DIR, typename C>
+BDSP_HD void dft8_tw(C* v, const C* T)
+{
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bf_tw<DIR, false, true>(v[r], v[r + 4], T[0]);
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        bf_tw<DIR, false, true>(v[r], v[r + 2], T[1]);
+        bf_tw<DIR, true, true>(v[4 + r], v[6 + r], T[1]);
+    }
+    bf_tw<DIR, false, true>(v[0], v[1], T[2]); // X[0], X[4]
+    bf_tw<DIR, true, true>(v[2], v[3], T[2]);  // X[2], X[6]
+    bf_tw<DIR, false, true>(v[4], v[5], T[3]); // X[1], X[5]
+    bf_tw<DIR, true, true>(v[6], v[7], T[3]);  // X[3], X[7]
+    C t;
+    t = v[1]; v[1] = v[4]; v[4] = t;
+    t = v[3]; v[3] = v[6]; v[6] = t;
+}
+
 // The eight values of dft16_tw from FOUR held ones q = {w^8, w^4, w^2, w}: the other four are products with the
 // constants W8, W16, W16^3 (for kernels short of registers: f64 holds 16 instead of 32 registers of twiddles per stage).
 // HELD = 2: q = {w^2, w} only; w^4 and w^8 by squaring (six more multiply-adds).
@@ -487,6 +508,14 @@ BDSP_HD void dft(C* v)
     else if (R == 16) dft16<DIR>(v);
 }
 
+// The real (IM = false) or imaginary parts of a register array of plain-struct complex values, indexable like an array
+// of scalars: what WgFft::scatter / gather move when a kernel exchanges the two parts one after the other.
+template <typename C, bool IM>
+struct PartRef {
+    C* v;
+    BDSP_HD typename real_of<C>::type& operator[](int i) const { return IM ? v[i].y : v[i].x; }
+};
+
 // ------------------------------------------------------------------ workgroup FFT
 // N points, NT cooperating threads, E = N/NT elements per thread (E in {2,4,8,16}, E >= every
 // radix used).  LDS holds N elements padded by one element per 16 so the stride-R scatter of the
@@ -513,6 +542,23 @@ struct WgFft {
     template <int R, int NS, int DIR, class TW>
     static BDSP_HD void compute(cpx<T> (&v)[E], int t, TW tw)
     {
+        if constexpr (R == 16 && NS > 1 && E == 16 && N % (16 * NS) == 0) {
+            // a twiddled radix-16 stage: the FMA form (dft16_tw, round 3) -- eight table values instead of fifteen
+            // (they come from L2 or an LDS table in the pass kernels) and 96 instead of 106 packed instructions
+            cpx<T> tws[8];
+            load_twiddles16_fma<NS>(tws, t, tw);
+            dft16_tw<DIR>(&v[0], tws);
+            return;
+        }
+        if constexpr (R == 8 && NS > 1 && N % (8 * NS) == 0) {
+#pragma unroll
+            for (int b = 0; b < E / R; ++b) {
+                const int e = ((t + b * NT) % NS) * (N / (NS * 8));
+                const cpx<T> tws[4] = {tw(4 * e), tw(2 * e), tw(e), tw(e + N / 8)};
+                dft8_tw<DIR>(&v[b * R], tws);
+            }
+            return;
+        }
 #pragma unroll
         for (int b = 0; b < E / R; ++b) {
             if (NS > 1) {
@@ -605,18 +651,20 @@ struct WgFft {
     // into the 16-bit immediate offset of ds_read/ds_write and no per-register address VGPRs are
     // held across the persistent block loop:
     //   pad(i + 16*c) = pad(i) + 17*c, and for the first stage (NS = 1, R = 16) pad(16*j + r) = 17*j + r.
-    template <int R, int NS>
-    static BDSP_HD void scatter(const cpx<T> (&v)[E], int t, cpx<T>* lds)
+    // (EL: the element that crosses -- cpx<T>, or T when a kernel short of LDS exchanges real and imaginary parts one
+    // after the other through a buffer of half the size)
+    template <int R, int NS, typename EL, typename ARR>
+    static BDSP_HD void scatter(const ARR& v, int t, EL* lds)
     {
 #pragma unroll
         for (int b = 0; b < E / R; ++b) {
             const int j = t + b * NT;
             if (NS % 16 == 0) {
-                cpx<T>* p = lds + pad((j / NS) * NS * R + (j % NS));
+                EL* p = lds + pad((j / NS) * NS * R + (j % NS));
 #pragma unroll
                 for (int r = 0; r < R; ++r) p[r * (NS / 16) * 17] = v[b * R + r];
             } else if (NS == 1 && R == 16) {
-                cpx<T>* p = lds + 17 * j;
+                EL* p = lds + 17 * j;
 #pragma unroll
                 for (int r = 0; r < R; ++r) p[r] = v[b * R + r];
             } else {
@@ -710,13 +758,13 @@ struct WgFft {
         for (int r = 0; r < 16; ++r) p[16 * r + 2 * (r >> 1)] = v[r];
     }
 
-    template <int R>
-    static BDSP_HD void gather(cpx<T> (&v)[E], int t, const cpx<T>* lds)
+    template <int R, typename EL, typename ARR>
+    static BDSP_HD void gather(ARR&& v, int t, const EL* lds)
     {
 #pragma unroll
         for (int b = 0; b < E / R; ++b) {
             if ((N / R) % 16 == 0) {
-                const cpx<T>* p = lds + pad(t + b * NT);
+                const EL* p = lds + pad(t + b * NT);
 #pragma unroll
                 for (int r = 0; r < R; ++r) v[b * R + r] = p[r * ((N / R) / 16) * 17];
             } else {

@@ -18,6 +18,7 @@
 // (reference: time_to_freq.rs:158-175, freq_to_time.rs:160-177 run them as separate passes).
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 
 #include "bdsp_internal.h"
 #include "dsp_funcs.h"
@@ -105,10 +106,33 @@ __host__ __device__ constexpr int pass_wgs_per_cu(size_t lds_bytes, int threads)
     if (k > 8) k = 8;
     return (int)k;
 }
-template <typename T, int RP, int W>
+// SPLIT exchange (round 3): an f64 tile of 2048 x 4 or 1024 x 8 points is 136 KB of LDS -- ONE 512-thread workgroup per
+// CU, which loads, transforms and stores its tile with nothing to overlap any phase (config C4a's 4M points are two such
+// tiles per CU in all).  These tiles therefore cross their real and imaginary parts one after the other through a
+// buffer of HALF the size (8-byte elements: twice the LDS instructions and barriers, the same bytes), which lets two
+// workgroups share a CU.  Not for the GEN instantiations, which stage whole complex values through the buffer.
+template <typename T, int RP, int W, bool GEN>
+constexpr bool pass_split_exchange()
+{
+    return !GEN && sizeof(T) == 8 && (size_t)W * col_stride(RP, W) * sizeof(cpx<T>) > 80 * 1024;
+}
+template <typename T, int RP, int W, bool GEN>
+constexpr size_t pass_tile_lds_bytes()
+{
+    return (size_t)W * col_stride(RP, W) * (pass_split_exchange<T, RP, W, GEN>() ? sizeof(T) : sizeof(cpx<T>));
+}
+
+// waves per SIMD the pass kernel is compiled for: the split tiles want two 512-thread workgroups per CU = 4 (128 VGPRs)
+template <typename T, int RP, int W, bool GEN>
+constexpr int pass_min_waves()
+{
+    return pass_split_exchange<T, RP, W, GEN>() ? 2 * (W * (RP / 16)) / 256 : 1;
+}
+
+template <typename T, int RP, int W, bool GEN = true>
 constexpr bool pass_lds_twiddles()
 {
-    constexpr size_t base = (size_t)W * col_stride(RP, W) * sizeof(cpx<T>), tab = (size_t)RP * sizeof(cpx<T>);
+    constexpr size_t base = pass_tile_lds_bytes<T, RP, W, GEN>(), tab = (size_t)RP * sizeof(cpx<T>);
     // ... and always for the 4-wide 1024-point f32 tiles: the plan picks them only when the launch has fewer than two
     // tiles per CU (one 2^20-point vector: 256 tiles), where the fourth resident workgroup the table costs is never there
     if (sizeof(T) == 4 && RP == 1024 && W == 4) return true;
@@ -419,7 +443,7 @@ __device__ __forceinline__ cpx<double> unit_root<double>(size_t e, size_t n)
 // stores are then compiled out: the branches themselves are free, but hipcc's code around their merge points is not
 // (the same lesson as in conv_v2.hip).
 template <typename T, int RP, int W, int DIR, bool ROWMAP, bool GEN, bool SIMPLE = false>
-__global__ __launch_bounds__(W * (RP / 16)) void k_fft_pass(FftIo<T> io, const cpx<T>* src, // (src may equal dst: the in-place last pass)
+__global__ __launch_bounds__(W * (RP / 16), (pass_min_waves<T, RP, W, GEN>())) void k_fft_pass(FftIo<T> io, const cpx<T>* src, // (src may equal dst: the in-place last pass)
                                                    cpx<T>* dst,
                                                    const cpx<T>* __restrict__ wtab, size_t n,
                                                    size_t nsg, size_t tiles_per_vec, int last)
@@ -429,7 +453,9 @@ __global__ __launch_bounds__(W * (RP / 16)) void k_fft_pass(FftIo<T> io, const c
     using F = WgFft<T, RP, NT>;
     using P = Radix16Plan<RP>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    cpx<T>* lds = reinterpret_cast<cpx<T>*>(smem_raw);
+    constexpr bool SPLIT = pass_split_exchange<T, RP, W, GEN>();
+    using LE = typename std::conditional<SPLIT, T, cpx<T>>::type; // what an LDS slot holds
+    LE* lds = reinterpret_cast<LE*>(smem_raw);
 
     const int tid = threadIdx.x;
     size_t blk = blockIdx.x;
@@ -440,8 +466,9 @@ __global__ __launch_bounds__(W * (RP / 16)) void k_fft_pass(FftIo<T> io, const c
     if ((tiles_per_vec & 7) == 0) tile = (tile & 7) * (tiles_per_vec >> 3) + (tile >> 3);
     const size_t j0 = tile * W;
     const size_t stride_in = n / RP;
-    constexpr bool LTW = pass_lds_twiddles<T, RP, W>();
-    cpx<T>* ltw = lds + (size_t)W * CS; // [RP] copy of the twiddle table (visible after the first barrier below)
+    constexpr bool LTW = pass_lds_twiddles<T, RP, W, GEN>();
+    static_assert(!(LTW && SPLIT), "a split tile has no room for the table");
+    cpx<T>* ltw = reinterpret_cast<cpx<T>*>(lds + (size_t)W * CS); // [RP] copy of the twiddle table (visible after the first barrier below)
     if constexpr (LTW) {
         for (int i = tid; i < RP; i += W * NT) ltw[i] = wtab[i];
     }
@@ -515,41 +542,59 @@ __global__ __launch_bounds__(W * (RP / 16)) void k_fft_pass(FftIo<T> io, const c
         }
     }
     if (!ROWMAP) { // (nsg > 1 exactly on the later passes)
-        // inter-pass twiddle w_n^{row*q}, q = k * n/(nsg*RP); row = ti + r*NT
+        // inter-pass twiddle w_n^{row*q}, q = k * n/(nsg*RP); row = ti + r*NT: register r carries bs * d1^r with
+        // bs = w_n^(ti q), d1 = w_n^(NT q) -- i.e. the first inner stage IS a twiddled 16-point transform with base
+        // d1 on inputs scaled by bs (round 3: dft16_tw from d1, d1^2 and their products with constants; before, fifteen
+        // powers of d1 were built and multiplied in one by one: 44 complex multiplies and 64 more f64 registers)
         const size_t k = j % nsg;
         const size_t q = k * (n / (nsg * RP));
         const cpx<T> bs = unit_root<T>(((size_t)ti * q) & (n - 1), n);
         const cpx<T> d1 = unit_root<T>(((size_t)NT * q) & (n - 1), n);
-        cpx<T> p[16];
-        p[1] = d1;
-        p[2] = cmul(d1, d1);
-        p[3] = cmul(p[2], d1);
-        p[4] = cmul(p[2], p[2]);
-        p[5] = cmul(p[4], p[1]);
-        p[6] = cmul(p[4], p[2]);
-        p[7] = cmul(p[4], p[3]);
-        p[8] = cmul(p[4], p[4]);
 #pragma unroll
-        for (int r = 9; r < 16; ++r) p[r] = cmul(p[8], p[r - 8]);
-        v[0] = twmul<DIR>(v[0], bs);
-#pragma unroll
-        for (int r = 1; r < 16; ++r) v[r] = twmul<DIR>(v[r], cmul(bs, p[r]));
+        for (int r = 0; r < 16; ++r) v[r] = twmul<DIR>(v[r], bs);
+        const cpx<T> held[2] = {cmul(d1, d1), d1};
+        cpx<T> t8[8];
+        expand_twiddles16_fma<2>(held, t8);
+        dft16_tw<DIR>(&v[0], t8);
+    } else {
+        F::template compute<16, 1, DIR>(v, ti, tw);
     }
 
     // ---- RP-point sub-FFT of every column
-    F::template compute<16, 1, DIR>(v, ti, tw);
-    F::template scatter<16, 1>(v, ti, lds + (size_t)c * CS);
-    __syncthreads();
     const int c2 = ROWMAP ? tid / NT : tid % W;
     const int t2 = ROWMAP ? tid % NT : tid / W;
-    cpx<T>* l2 = lds + (size_t)c2 * CS;
-    F::template gather<P::R2>(v, t2, l2);
+    LE* l1 = lds + (size_t)c * CS;
+    LE* l2 = lds + (size_t)c2 * CS;
+    if constexpr (SPLIT) {
+        // real parts, then imaginary parts, through the half-size buffer (straight from / into the registers' halves)
+        F::template scatter<16, 1>(PartRef<cpx<T>, false>{v}, ti, l1);
+        __syncthreads();
+        F::template gather<P::R2>(PartRef<cpx<T>, false>{v}, t2, l2);
+        __syncthreads();
+        F::template scatter<16, 1>(PartRef<cpx<T>, true>{v}, ti, l1);
+        __syncthreads();
+        F::template gather<P::R2>(PartRef<cpx<T>, true>{v}, t2, l2);
+    } else {
+        F::template scatter<16, 1>(v, ti, l1);
+        __syncthreads();
+        F::template gather<P::R2>(v, t2, l2);
+    }
     F::template compute<P::R2, 16, DIR>(v, t2, tw);
     if constexpr (P::R3 > 1) {
         __syncthreads();
-        F::template scatter<P::R2, 16>(v, t2, l2);
-        __syncthreads();
-        F::template gather<P::R3>(v, t2, l2);
+        if constexpr (SPLIT) {
+            F::template scatter<P::R2, 16>(PartRef<cpx<T>, false>{v}, t2, l2);
+            __syncthreads();
+            F::template gather<P::R3>(PartRef<cpx<T>, false>{v}, t2, l2);
+            __syncthreads();
+            F::template scatter<P::R2, 16>(PartRef<cpx<T>, true>{v}, t2, l2);
+            __syncthreads();
+            F::template gather<P::R3>(PartRef<cpx<T>, true>{v}, t2, l2);
+        } else {
+            F::template scatter<P::R2, 16>(v, t2, l2);
+            __syncthreads();
+            F::template gather<P::R3>(v, t2, l2);
+        }
         F::template compute<P::R3, 16 * P::R2, DIR>(v, t2, tw);
     }
 
@@ -558,20 +603,25 @@ __global__ __launch_bounds__(W * (RP / 16)) void k_fft_pass(FftIo<T> io, const c
     constexpr int NSL = RP / RL;
     const size_t jj = j0 + c2;
     const size_t base = (jj / nsg) * nsg * RP + (jj % nsg);
-    if (GEN && !ROWMAP && last) {
-        __syncthreads();
+    bool staged = false;
+    if constexpr (GEN && !ROWMAP) {
+        if (last) {
+            staged = true;
+            __syncthreads();
 #pragma unroll
-        for (int b = 0; b < 16 / RL; ++b)
+            for (int b = 0; b < 16 / RL; ++b)
 #pragma unroll
-            for (int r = 0; r < RL; ++r)
-                l2[F::pad(F::template out_index<RL, NSL>(t2, b, r))] = v[b * RL + r];
-        __syncthreads();
+                for (int r = 0; r < RL; ++r)
+                    l2[F::pad(F::template out_index<RL, NSL>(t2, b, r))] = v[b * RL + r];
+            __syncthreads();
 #pragma unroll 1
-        for (int e = 0; e < 16; ++e) {
-            int row = t2 + e * NT;
-            io_store(io, vec, base + (size_t)row * nsg, l2[F::pad(row)]);
+            for (int e = 0; e < 16; ++e) {
+                int row = t2 + e * NT;
+                io_store(io, vec, base + (size_t)row * nsg, l2[F::pad(row)]);
+            }
         }
-    } else {
+    }
+    if (!staged) {
         cpx<T>* out = dst + vec * n + base;
         // last pass: fft_shift = the row index's top bit flipped; the last inner stage's digit r is that top digit
         const int sx = (!SIMPLE && last && !ROWMAP && (io.flags & BDSP_FFT_SHIFT_OUT)) ? RL / 2 : 0;
@@ -719,8 +769,6 @@ static int launch_pass(const FftIo<T>& io, const cpx<T>* src, cpx<T>* dst, size_
     const cpx<T>* wtab;
     BDSP_TRY(twiddle_table<T>(RP, &wtab));
     constexpr int THREADS = W * (RP / 16);
-    size_t lds = (size_t)W * col_stride(RP, W) * sizeof(cpx<T>);
-    if (pass_lds_twiddles<T, RP, W>()) lds += (size_t)RP * sizeof(cpx<T>);
     size_t tiles = (n / RP) / W;
     dim3 grid((unsigned)(tiles * batch));
     const bool rowmap = nsg == 1; // the first pass
@@ -732,6 +780,8 @@ static int launch_pass(const FftIo<T>& io, const cpx<T>* src, cpx<T>* dst, size_
                                         : (!last || (io.flags & (BDSP_FFT_SHIFT_OUT | BDSP_FFT_MAGNITUDE | FFT_OUT_REAL)) == 0));
 #define BDSP_PASS(DIRV, RM, GENV, SV)                                                              \
     do {                                                                                           \
+        constexpr size_t lds = pass_tile_lds_bytes<T, RP, W, GENV>() +                             \
+                               (pass_lds_twiddles<T, RP, W, GENV>() ? (size_t)RP * sizeof(cpx<T>) : 0); \
         BDSP_TRY(set_lds(k_fft_pass<T, RP, W, DIRV, RM, GENV, SV>, lds));                          \
         hipLaunchKernelGGL((k_fft_pass<T, RP, W, DIRV, RM, GENV, SV>), grid, dim3(THREADS), lds, s, \
                            io, src, dst, wtab, n, nsg, tiles, (int)last);                          \
