@@ -283,6 +283,7 @@ _proto("bdsp_hip_dev_fft", _I, _I, _P, _P, _SZ, _SZ, _U, _D, _I, _D, C.POINTER(_
 _proto("bdsp_hip_dev_convolve", _I, _I, _P, _P, _SZ, _SZ, _P, _SZ, _P)
 _proto("bdsp_hip_conv_spectrum_points", _SZ)
 _proto("bdsp_hip_fft_passes", _I, _I, _SZ)
+_proto("bdsp_hip_capture_abort", _I, _P)
 _proto("bdsp_hip_compute_units", _I)
 _proto("bdsp_hip_conv_block_shares", _I, _I, _I)
 _proto("bdsp_hip_dev_conv_prepare", _I, _I, _P, _SZ, _P, _P)
@@ -339,10 +340,11 @@ class Graph:
         check(lib.bdsp_hip_capture_begin(sp), "capture_begin")
         try:
             fn()
-        finally:
-            h = C.c_void_p(None)
-            code = lib.bdsp_hip_capture_end(sp, C.byref(h))
-        check(code, "capture_end")
+        except BaseException:
+            lib.bdsp_hip_capture_abort(sp)  # the sequence failed half way: leave capture mode, release what it pinned
+            raise
+        h = C.c_void_p(None)
+        check(lib.bdsp_hip_capture_end(sp, C.byref(h)), "capture_end")
         return cls(h, sp)
 
     def launch(self):

@@ -110,10 +110,15 @@ struct BsPlan {
 static std::mutex g_bs_mu;
 static std::vector<BsPlan> g_bs_plans;
 static unsigned long long g_bs_clock = 0;
-// capture bookkeeping (bdsp_hip_capture_begin/_end): plans looked up while a capture is open are pinned to the graph
+// capture bookkeeping (bdsp_hip_capture_begin/_end/_abort): ONE capture at a time per process, owned by the thread that
+// opened it.  Plans that thread looks up while its capture is open are pinned to the graph; what OTHER threads do in the
+// meantime (plan look-ups, buffer trades) is none of the capture's business -- the moves word below is per thread.
 static int g_capture_open = 0;
+static std::thread::id g_capture_thread;
+static hipStream_t g_capture_stream = nullptr;
 static std::vector<void*> g_capture_plans; // chirp pointers identify plans
-static unsigned long long g_capture_moves = 0; // g_buffer_moves when the capture was opened
+static unsigned long long g_capture_moves = 0; // the capturing thread's t_buffer_moves when the capture was opened
+static bool capturing_here() { return g_capture_open && g_capture_thread == std::this_thread::get_id(); }
 struct GraphHandle {
     hipGraphExec_t exec = nullptr;
     hipStream_t stream = nullptr;
@@ -130,11 +135,16 @@ int bs_plan(size_t n, size_t m, bool inverse, hipStream_t s, const T** chirp, co
     for (auto& p : g_bs_plans)
         if (p.n == n && p.inverse == inverse && p.esz == (int)sizeof(T) && p.dev == dev) {
             p.stamp = ++g_bs_clock;
-            if (g_capture_open) { ++p.pins; g_capture_plans.push_back(p.chirp); }
+            if (capturing_here()) { ++p.pins; g_capture_plans.push_back(p.chirp); }
             *chirp = (const T*)p.chirp;
             *bspec = (const T*)p.bspec;
             return BDSP_OK;
         }
+    if (capturing_here()) {
+        // building a plan synchronises the stream (and may free memory): both would invalidate the open capture
+        set_last_error("chirp-z plan missing while a capture is open: run the sequence once before capturing it (warm the plan)");
+        return BDSP_ERR_UNSUPPORTED;
+    }
     BsPlan p;
     p.n = n; p.m = m; p.inverse = inverse; p.esz = (int)sizeof(T); p.dev = dev;
     p.bytes = sizeof(T) * 2 * (n + m);
@@ -166,7 +176,6 @@ int bs_plan(size_t n, size_t m, bool inverse, hipStream_t s, const T** chirp, co
     if (c == BDSP_OK && hipStreamSynchronize(s) != hipSuccess) c = BDSP_ERR_HIP;
     if (c != BDSP_OK) { (void)hipFree(p.chirp); (void)hipFree(p.bspec); return c; }
     p.stamp = ++g_bs_clock;
-    if (g_capture_open) { ++p.pins; g_capture_plans.push_back(p.chirp); }
     g_bs_plans.push_back(p);
     *chirp = (const T*)p.chirp;
     *bspec = (const T*)p.bspec;
@@ -588,7 +597,7 @@ size_t b1_overlap_discard(T* x_time, size_t x_len, T* tmp, size_t tmp_len, const
 // Every buffer trade (and every reallocation) of a handle XORs a token into this word; two trades of the same
 // vector cancel.  A captured HIP graph records device addresses, so a capture may only contain sequences that
 // leave every vector's (live, trade) pair as they found it: bdsp_hip_capture_end compares the word.
-static std::atomic<unsigned long long> g_buffer_moves{0};
+static thread_local unsigned long long t_buffer_moves = 0; // (per thread: a capture only answers for its own thread's calls)
 static std::atomic<unsigned long long> g_realloc_ticket{1};
 
 template <typename T>
@@ -605,7 +614,7 @@ struct DevVec {
     size_t points() const { return complex_ ? valid_len / 2 : valid_len; }
     bool erroneous() const { return valid_len == 0 && std::isnan((double)delta); }
     void poison() { valid_len = 0; delta = std::numeric_limits<T>::quiet_NaN(); } // mod.rs:226-229
-    void trade() { T* t = data; data = buf; buf = t; g_buffer_moves ^= (unsigned long long)(uintptr_t)this * 0x9E3779B97F4A7C15ull; }
+    void trade() { T* t = data; data = buf; buf = t; t_buffer_moves ^= (unsigned long long)(uintptr_t)this * 0x9E3779B97F4A7C15ull; }
 
     int reserve(size_t scalars)
     {
@@ -623,7 +632,7 @@ struct DevVec {
         data = (T*)nd;
         buf = (T*)nb;
         cap = ncap;
-        g_buffer_moves ^= g_realloc_ticket.fetch_add(1) * 0xD1B54A32D192ED03ull; // never cancels: no capture across a reallocation
+        t_buffer_moves ^= g_realloc_ticket.fetch_add(1) * 0xD1B54A32D192ED03ull; // never cancels: no capture across a reallocation
         return BDSP_OK;
     }
     ~DevVec()
@@ -2522,11 +2531,16 @@ int bdsp_hip_capture_begin(void* stream)
     hipStream_t st = pick_stream(stream);
     {
         std::lock_guard<std::mutex> lk(g_bs_mu);
-        if (g_capture_open) { set_last_error("capture_begin: a capture is already open"); return BDSP_ERR_UNSUPPORTED; }
+        if (g_capture_open) {
+            set_last_error("capture_begin: a capture is already open (finish it with bdsp_hip_capture_end or drop it with bdsp_hip_capture_abort)");
+            return BDSP_ERR_UNSUPPORTED;
+        }
         BDSP_TRY(ws_capture_begin(st));
         g_capture_open = 1;
+        g_capture_thread = std::this_thread::get_id();
+        g_capture_stream = st;
         g_capture_plans.clear();
-        g_capture_moves = g_buffer_moves.load();
+        g_capture_moves = t_buffer_moves;
     }
     hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed);
     if (e != hipSuccess) {
@@ -2538,11 +2552,43 @@ int bdsp_hip_capture_begin(void* stream)
     }
     return BDSP_OK;
 }
+// Drops an open capture without building a graph: ends the stream capture, releases what the captured calls pinned and
+// re-opens the library for the next capture_begin.  For a caller whose captured sequence failed half way.  No-op (0)
+// when no capture is open.
+int bdsp_hip_capture_abort(void* stream)
+{
+    hipStream_t st = pick_stream(stream);
+    std::vector<void*> blocks, plans;
+    {
+        std::lock_guard<std::mutex> lk(g_bs_mu);
+        if (!g_capture_open) return BDSP_OK;
+        if (g_capture_stream != st) { set_last_error("capture_abort: the open capture is on another stream"); return BDSP_ERR_UNSUPPORTED; }
+        ws_capture_end(st, &blocks);
+        plans.swap(g_capture_plans);
+        for (void* c : plans)
+            for (auto& p : g_bs_plans)
+                if (p.chirp == c && p.pins > 0) { --p.pins; break; }
+        g_capture_open = 0;
+    }
+    hipGraph_t g = nullptr;
+    (void)hipStreamEndCapture(st, &g); // (fails harmlessly if the capture was already invalidated)
+    if (g) (void)hipGraphDestroy(g);
+    (void)hipGetLastError();
+    for (void* p : blocks) ws_free(p, st);
+    return BDSP_OK;
+}
 int bdsp_hip_capture_end(void* stream, void** graph_exec)
 {
     if (!graph_exec) return BDSP_ERR_ARG_LENGTH;
     *graph_exec = nullptr;
     hipStream_t st = pick_stream(stream);
+    {
+        std::lock_guard<std::mutex> lk(g_bs_mu);
+        if (!g_capture_open || g_capture_stream != st || g_capture_thread != std::this_thread::get_id()) {
+            set_last_error("capture_end: no capture opened by this thread on this stream");
+            return BDSP_ERR_UNSUPPORTED;
+        }
+    }
     hipGraph_t g = nullptr;
     hipError_t ec = hipStreamEndCapture(st, &g);
     GraphHandle* h = new GraphHandle;
@@ -2552,7 +2598,7 @@ int bdsp_hip_capture_end(void* stream, void** graph_exec)
         std::lock_guard<std::mutex> lk(g_bs_mu);
         ws_capture_end(st, &h->pinned_blocks);
         h->pinned_plans.swap(g_capture_plans);
-        moved = g_buffer_moves.load() != g_capture_moves;
+        moved = t_buffer_moves != g_capture_moves;
         g_capture_open = 0;
     }
     auto fail = [&](const char* msg, int code) {

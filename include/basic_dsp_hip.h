@@ -804,6 +804,10 @@ void bdsp_hip_event_destroy(void *event);
  * stream: hipStream_t as void*, NULL = the library's own stream (the one B2 handles use). */
 int bdsp_hip_capture_begin(void *stream);
 int bdsp_hip_capture_end(void *stream, void **graph_exec);
+/* Drops an open capture without building a graph (a captured sequence that failed half way): the stream leaves capture
+ * mode, pinned workspace and plans are released, the next capture_begin is accepted.  One capture at a time per
+ * process, owned by the thread that opened it; other threads' calls neither disturb it nor are recorded by it. */
+int bdsp_hip_capture_abort(void *stream);
 int bdsp_hip_graph_launch(void *graph_exec, void *stream);
 void bdsp_hip_graph_destroy(void *graph_exec);
 

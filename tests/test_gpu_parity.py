@@ -991,12 +991,28 @@ def test_hip_graph_capture_and_replay():
     # a graph replays addresses: a captured sequence that leaves a vector's (live, trade) buffers swapped is refused
     big = DspVec(orc.fill_uniform(2 * (1 << 21), 6, -10, 10, np.float32), is_complex=True)
     ref3 = np.fft.fft(big.datac().astype(np.complex128))
+    warm = DspVec(orc.fill_uniform(2 * (1 << 21), 7, -10, 10, np.float32), is_complex=True)
+    assert warm.plain_fft() == 0 and warm.plain_ifft() == 0   # twiddle tables and workspace of this length exist now
     with pytest.raises(bd.BackendError):
         Graph.capture(lambda: big.plain_fft(), warmup=False)   # three passes: the result ends in the trade buffer
     # ... the capture attempt still ran nothing twice and left the library usable
     assert big.domain() == V.FREQ
     g5 = Graph.capture(lambda: (big.plain_ifft(), big.plain_fft()), warmup=False)  # two trades cancel
-    del g, g2, g3, g4, g5   # releases the workspace blocks and plans the graphs pinned
+    # a captured sequence that fails half way is dropped (bdsp_hip_capture_abort) and the next capture is accepted
+    def boom():
+        w.scale(1.0)
+        raise RuntimeError("the caller's own failure inside a capture")
+    with pytest.raises(RuntimeError):
+        Graph.capture(boom, warmup=False)
+    g6 = Graph.capture(lambda: (w.scale(1.0), w.offset(0.0)))
+    g6.launch()
+    # a chirp-z plan cannot be BUILT inside a capture (it synchronises the stream): a clean error, not a broken capture
+    prime = DspVec(orc.fill_uniform(2 * 10007, 8, -10, 10, np.float32), is_complex=True)
+    with pytest.raises(bd.BackendError, match="warm the plan"):
+        Graph.capture(lambda: bd._lib.check(prime.plain_fft()), warmup=False)
+    g7 = Graph.capture(lambda: (bd._lib.check(prime.plain_ifft()), bd._lib.check(prime.plain_fft())))   # warmed: fine
+    g7.launch()
+    del g, g2, g3, g4, g5, g6, g7   # releases the workspace blocks and plans the graphs pinned
     w2 = DspVec(x)
     assert w2.scale(2.0) == 0 and np.array_equal(w2.data(), orc.real_scale(x, 2.0))
     del ref3

@@ -13,7 +13,7 @@ sp = bd._lib.torch_stream_arg()
 flag = C.c_int(0)
 PEAK = 8000.0
 
-QUICK = "--quick" in sys.argv  # a few launches per config only: for the rocprofv3 --pmc passes (tools/profile_r02.sh)
+QUICK = "--quick" in sys.argv  # a few launches per config only: for the rocprofv3 --pmc passes (tools/profile_r03.sh)
 
 def timeit(fn, iters=20):
     # untimed pre-warm: the clock needs tens of milliseconds of load to settle (see bench.py)

@@ -1,9 +1,9 @@
 #!/bin/bash
-# Round-2 profiles (run on the GPU box through gpurun): rocprofv3 kernel stats and PMC counters for the bench step
-# and for every BASELINE config (tools/bench_configs.py).  Outputs under gpurun_out/r02prof/, copied to profiles/.
+# Round-3 profiles (run on the GPU box through gpurun): rocprofv3 kernel stats and PMC counters for the bench step
+# and for every BASELINE config (tools/bench_configs.py).  Outputs under gpurun_out/r03prof/, copied to profiles/.
 set -u
 ROOT=$GRAFT_REPO_ROOT
-OUT=$ROOT/gpurun_out/r02prof
+OUT=$ROOT/gpurun_out/r03prof
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 # --- the bench step: kernel trace + stats
@@ -33,3 +33,24 @@ python3 tools/pmc_traffic.py $OUT/bench_pmc $OUT/hbm_traffic.json > /dev/null 2>
 python3 tools/pmc_summary.py $OUT/configs_pmc > $OUT/configs_pmc_summary.txt 2>&1
 python3 tools/pmc_traffic.py $OUT/configs_pmc $OUT/configs_hbm_traffic.json > /dev/null 2>&1
 find $OUT -name "*kernel_stats.csv" | head; ls $OUT
+# --- what the figures were collected on: bench.py quotes them only while the kernel sources still hash to this value
+python3 - <<PY
+import json, sys, time
+sys.path.insert(0, "$ROOT")
+import bench
+json.dump({"source_sha16": bench.kernel_source_sha16(), "collected": time.strftime("%Y-%m-%d %H:%M:%S"),
+           "command": "tools/profile_r03.sh (rocprofv3 --kernel-trace --stats, then separate --pmc passes)"},
+          open("$OUT/profile_meta.json", "w"), indent=1)
+PY
+# --- the per-round names under profiles/ (copy these into the repository)
+mkdir -p $OUT/for_profiles
+cp $OUT/profile_meta.json $OUT/for_profiles/r03_profile_meta.json
+cp $OUT/hbm_traffic.json $OUT/for_profiles/r03_hbm_traffic.json
+cp $OUT/configs_hbm_traffic.json $OUT/for_profiles/r03_configs_hbm_traffic.json
+cp $OUT/bench_pmc_summary.txt $OUT/for_profiles/r03_bench_pmc_summary.txt
+cp $OUT/configs_pmc_summary.txt $OUT/for_profiles/r03_configs_pmc_summary.txt
+cp $OUT/bench_line_under_rocprof.json $OUT/for_profiles/r03_bench_line_under_rocprof.json
+cp $OUT/config_table.jsonl $OUT/for_profiles/r03_config_table.jsonl
+cp $(find $OUT/bench_stats -name "*kernel_stats.csv" | head -1) $OUT/for_profiles/r03_bench_kernel_stats.csv
+cp $(find $OUT/configs_stats -name "*kernel_stats.csv" | head -1) $OUT/for_profiles/r03_configs_kernel_stats.csv
+ls -la $OUT/for_profiles
