@@ -286,7 +286,13 @@ __global__ __launch_bounds__(256, sizeof(T) == 4 ? 3 : 2) void k_overlap_save_v2
         for (int r = R0; r < 16; ++r) {
             // (non-temporal stores measured 7 us slower on the FFT that follows: the result would leave the caches;
             // non-temporal loads of x made no difference)
+            // (round 3, -DBDSP_CONV_NT in the lab build: streaming stores pay only when the result exceeds the cache --
+            // 16M f64 points (256 MB) 129 -> 123 us, 64 x 1M f32 (512 MB) 232 -> 228 -- and cost the headline step 8 us)
+#if defined(BDSP_LAB) && defined(BDSP_CONV_NT)
+            nt_store(&yb[ut + 256u * r], v[r]);
+#else
             yb[ut + 256u * r] = v[r];
+#endif
         }
     }
 }

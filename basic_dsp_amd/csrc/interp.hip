@@ -135,7 +135,7 @@ template <typename T, bool CPLX, int FACTOR, int QB>
 __global__ __launch_bounds__(256) void k_interp_inner(const T* __restrict__ x, T* __restrict__ y,
                                                       const T* __restrict__ taps, long long q_lo,
                                                       long long q_hi, int conv_len, long long points,
-                                                      long long new_points, unsigned inner_blocks)
+                                                      long long new_points, unsigned inner_blocks, int stream_out)
 {
     constexpr int E = CPLX ? 2 : 1;
     constexpr int TILE = 256 * QB;
@@ -261,9 +261,18 @@ __global__ __launch_bounds__(256) void k_interp_inner(const T* __restrict__ x, T
         }
         __syncthreads();
         vecT* yv = reinterpret_cast<vecT*>(y + out0);
-        for (long long k = t; k < nout / VN; k += 256) {
-            const int q = (int)(k / PP), part = (int)(k % PP);
-            yv[k] = lov[PP * q + (POW2 ? ((part + rot(q)) & (PP - 1)) : part)];
+        // A result too large for the 256 MB Infinity Cache to hold until its reader comes is STREAMED (non-temporal
+        // stores): config C4b's 256 MB ran 82 -> 69 us that way; a result that fits (128 MB: 46 -> 48 us) is not.
+        if (stream_out) {
+            for (long long k = t; k < nout / VN; k += 256) {
+                const int q = (int)(k / PP), part = (int)(k % PP);
+                __builtin_nontemporal_store(lov[PP * q + (POW2 ? ((part + rot(q)) & (PP - 1)) : part)], &yv[k]);
+            }
+        } else {
+            for (long long k = t; k < nout / VN; k += 256) {
+                const int q = (int)(k / PP), part = (int)(k % PP);
+                yv[k] = lov[PP * q + (POW2 ? ((part + rot(q)) & (PP - 1)) : part)];
+            }
         }
     } else {
 #pragma unroll
@@ -479,13 +488,14 @@ int interpolatef_dev(const T* in, T* out, size_t len, bool is_complex, int fid, 
             size_t lds2 = sizeof(T) * ((((size_t)f * (ntaps + 1) + 3) & ~(size_t)3) + (((tile + 2 * conv_len + 2) * e + 3) & ~(size_t)3) + tile * (size_t)f * e);
             if (lds2 < lds) lds2 = lds;
             const unsigned g = (unsigned)((q_hi - q_lo + (long long)tile - 1) / (long long)tile);
+            const int stream_out = sizeof(T) * new_len > (size_t(192) << 20) ? 1 : 0; // (see the store loop of k_interp_inner)
 #define BDSP_INNER2(FV, CP, QV)                                                                    \
     do {                                                                                           \
         auto kk = k_interp_inner<T, CP, FV, QV>;                                                   \
         if (lds2 > 64 * 1024)                                                                      \
             BDSP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2)); \
         hipLaunchKernelGGL(kk, dim3(g + (unsigned)eblocks), dim3(256), lds2, s, in, out, taps_dev, q_lo, q_hi, (int)conv_len, \
-                           (long long)points, (long long)new_points, g);                           \
+                           (long long)points, (long long)new_points, g, stream_out);               \
     } while (0)
 #define BDSP_INNER(FV)                                                                             \
     do {                                                                                           \
