@@ -256,6 +256,13 @@ __global__ __launch_bounds__(256, sizeof(T) == 4 ? 3 : 2) void k_overlap_save_v2
     if (grp >= a.groups) return;
     const unsigned lo = grp == 0 ? 0u : (grp == 1 ? a.na : a.na + a.nbb);
     const unsigned hi = grp == 0 ? a.na : ((grp == 1 && a.groups == 3) ? a.na + a.nbb : total);
+    // (Round 3, measured and NOT adopted: RUNS of consecutive blocks per workgroup.  Block b + 1's first R0 rows are block
+    // b's last R0 input rows -- the same registers of the same threads -- so a workgroup that walks consecutive blocks
+    // can keep them: 12 instead of 16 loads per block at 1024 taps.  Lab kernel k_v5 (tools/lab/conv_lab.hip): 60.1 ->
+    // 58.7 us on two boxes, 60.6 -> 60.2 on a third; in the library the kernel alone measured equal (60.3 vs 60.6 us) and
+    // the step convolution -> FFT 7 us SLOWER (185.5 -> 192.5 us, three A/B rounds): with 768 runs the freshly written
+    // lines are spread over the whole result when the kernel ends and their write-back lands in the transform's first
+    // pass, whereas the strided sweep below leaves one compact window.)
     const unsigned w2 = xcd_contiguous(blockIdx.x - grp * gs, gs);
     for (unsigned id = lo + w2; id < hi; id += gs) {
         unsigned vec = 0, b = a.nb_lo + id;

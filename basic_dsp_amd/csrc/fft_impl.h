@@ -644,7 +644,7 @@ __global__ __launch_bounds__(W * (RP / 16), (pass_min_waves<T, RP, W, GEN>())) v
             for (int r = 0; r < RL; ++r)
                 // (non-temporal stores here, -DBDSP_FFT_NT in the lab build: 16M f32 points 127 -> 181 us, C2 x 64 379 -> 427
                 // -- a pass's output is the next pass's input and the Infinity Cache holds it; 2^25 / 2^26 points and 16M f64,
-                // whose buffers exceed the cache: +-1 %.  Not adopted.)
+                // whose buffers exceed the cache: +-1 %; streaming only the LAST pass's result: no difference.  Not adopted.)
 #if defined(BDSP_LAB) && defined(BDSP_FFT_NT)
                 nt_store(&out[(size_t)F::template out_index<RL, NSL>(t2, b, r ^ sx) * nsg], v[b * RL + r]);
 #else

@@ -1077,6 +1077,113 @@ __global__ __launch_bounds__(256, WPC) void k_v4(Args a, unsigned nb_lo, unsigne
     }
 }
 
+
+// ------------------------------------------------------------------------------------------- v5 (round 3): consecutive blocks
+// A workgroup takes a RUN of consecutive blocks instead of every gs-th one: block b + 1 starts V = 4096 - 256 R0 samples
+// after block b, so its first R0 rows ARE block b's last R0 input rows -- the same registers of the same threads.  They
+// are kept (2 R0 VGPRs) instead of loaded again: 12 instead of 16 loads per block at 1024 taps, a quarter less L2 -> CU
+// traffic.  (The overlap used to be an L2 hit of a neighbouring workgroup's load; now only a run's FIRST block reads
+// its overlap from memory.)  Shares as before: group g's workgroups get RA / RB / the rest "rounds" = blocks per run.
+// ABL as in k_v3 (1 loads off, 2 stores off, 28 = memory only).
+template <int R0, int ABL, int WPC, int RA, int RB>
+__global__ __launch_bounds__(256, WPC) void k_v5(Args a, unsigned nb_lo, unsigned nb_hi)
+{
+    using F = WgFft<float, L, 256>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    C* lds = reinterpret_cast<C*>(smem_raw);
+    const int t = threadIdx.x;
+    const unsigned ut = t;
+    const unsigned V = a.V;
+    const float hscale = 1.0f / L;
+    auto tww = [&](int mm) { return a.wtab[mm]; };
+    C hreg[16], tw2f[8], tw3f[8];
+    F::template load_twiddles16_fma<16>(tw2f, t, tww);
+    F::template load_twiddles16_fma<256>(tw3f, t, tww);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        C hv = a.hs[ut + 256u * r];
+        hreg[r] = C{hv.x * hscale, hv.y * hscale};
+    }
+    auto bar = [&]() { if constexpr (!(ABL & 16)) __syncthreads(); };
+    auto half = [&](C (&v)[16], auto D) {
+        constexpr int DIR = decltype(D)::value;
+        if constexpr (!(ABL & 8)) F::template compute<16, 1, DIR>(v, t, tww);
+        bar();
+        if constexpr (!(ABL & 4)) F::scatter_a3(v, t, lds);
+        bar();
+        if constexpr (!(ABL & 4)) F::gather_a3(v, t, lds);
+        if constexpr (!(ABL & 8)) dft16_tw<DIR>(&v[0], tw2f);
+        bar();
+        if constexpr (!(ABL & 4)) F::scatter_b3(v, t, lds);
+        bar();
+        if constexpr (!(ABL & 4)) F::gather_b(v, t, lds);
+        if constexpr (!(ABL & 8)) dft16_tw<DIR, (DIR > 0 && R0 <= 8) ? R0 : 0>(&v[0], tw3f);
+    };
+    auto transform = [&](C (&v)[16]) {
+        half(v, std::integral_constant<int, -1>{});
+        if constexpr (!(ABL & 8)) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = cmul(v[r], hreg[r]);
+        }
+        half(v, std::integral_constant<int, 1>{});
+    };
+    const unsigned G = gridDim.x;
+    {
+        const unsigned nwrap = nb_lo + (a.blocks - nb_hi);
+        for (unsigned w = blockIdx.x; w < nwrap; w += G) {
+            const unsigned b = w < nb_lo ? w : nb_hi + (w - nb_lo);
+            C v[16];
+            load_block(a, b, V, ut, v);
+            transform(v);
+            store_block<false>(a, b, V, ut, v);
+        }
+    }
+    const unsigned total = nb_hi - nb_lo, gs = G / WPC;
+    unsigned na = RA * gs, nbb = WPC >= 3 ? RB * gs : 0;
+    if (na > total) na = total;
+    if (na + nbb > total) nbb = total - na;
+    const unsigned grp = blockIdx.x / gs;
+    if (grp >= (unsigned)WPC) return;
+    const unsigned lo = grp == 0 ? nb_lo : ((grp == 1 && WPC == 3) ? nb_lo + na : nb_lo + na + nbb);
+    const unsigned hi = grp == 0 ? nb_lo + na : ((grp == 1 && WPC == 3) ? nb_lo + na + nbb : nb_hi);
+    // this workgroup's run: a balanced partition of [lo, hi) over the gs workgroups of the group
+    const unsigned w = blockIdx.x - grp * gs, n = hi - lo;
+    const unsigned b0 = lo + (unsigned)((unsigned long long)w * n / gs), b1 = lo + (unsigned)((unsigned long long)(w + 1) * n / gs);
+    if (b0 >= b1) return;
+    C keep[R0];
+    {
+        const C* xb = a.x + ((long long)b0 * V + a.in_off);
+#pragma unroll
+        for (int r = 0; r < R0; ++r) {
+            if constexpr (!(ABL & 1)) keep[r] = xb[ut + 256u * r]; else asm volatile("" : "=v"(keep[r]));
+        }
+    }
+    for (unsigned b = b0; b < b1; ++b) {
+        C v[16];
+#pragma unroll
+        for (int r = 0; r < R0; ++r) v[r] = keep[r];
+        if constexpr (!(ABL & 1)) {
+            const C* xb = a.x + ((long long)b * V + a.in_off);
+#pragma unroll
+            for (int r = R0; r < 16; ++r) v[r] = xb[ut + 256u * r];
+        } else {
+#pragma unroll
+            for (int r = R0; r < 16; ++r) asm volatile("" : "=v"(v[r]));
+        }
+#pragma unroll
+        for (int r = 0; r < R0; ++r) keep[r] = v[16 - R0 + r];
+        transform(v);
+        if constexpr (!(ABL & 2)) {
+            C* yb = a.y + ((long long)b * V - 256 * R0);
+#pragma unroll
+            for (int r = R0; r < 16; ++r) yb[ut + 256u * r] = v[r];
+        } else {
+#pragma unroll
+            for (int r = R0; r < 16; ++r) asm volatile("" : : "v"(v[r]));
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------- wave-per-block
 // ONE WAVE per 4096-point block, 64 points per lane: 4096 = 64 x 64, each 64-point transform entirely in the lane's
 // registers (4 x 16), ONE twiddle layer (w4096^(lane k)) and ONE transposition through LDS per transform -- two
@@ -1443,6 +1550,19 @@ int main(int argc, char** argv)
         {"k4 2wg 12", (const void*)k_v4<4, 2, 12, 0>, true, 2, lds_l3, 4},
         {"k4 2wg 11", (const void*)k_v4<4, 2, 11, 0>, true, 2, lds_l3, 4},
         {"k4 1wg", (const void*)k_v4<4, 1, 30, 0>, true, 1, lds_l3, 4},
+        {"k5 9/8", (const void*)k_v5<4, 0, 3, 9, 8>, true, 3, lds_l3, 4},
+        {"k5 8/7", (const void*)k_v5<4, 0, 3, 8, 7>, true, 3, lds_l3, 4},
+        {"k5 10/8", (const void*)k_v5<4, 0, 3, 10, 8>, true, 3, lds_l3, 4},
+        {"k5 9/7", (const void*)k_v5<4, 0, 3, 9, 7>, true, 3, lds_l3, 4},
+        {"k5 7/7", (const void*)k_v5<4, 0, 3, 7, 7>, true, 3, lds_l3, 4},
+        {"k5 10/7", (const void*)k_v5<4, 0, 3, 10, 7>, true, 3, lds_l3, 4},
+        {"k5 10/9", (const void*)k_v5<4, 0, 3, 10, 9>, true, 3, lds_l3, 4},
+        {"k5 11/8", (const void*)k_v5<4, 0, 3, 11, 8>, true, 3, lds_l3, 4},
+        {"k5 11/7", (const void*)k_v5<4, 0, 3, 11, 7>, true, 3, lds_l3, 4},
+        {"k5 11/9", (const void*)k_v5<4, 0, 3, 11, 9>, true, 3, lds_l3, 4},
+        {"k5 12/8", (const void*)k_v5<4, 0, 3, 12, 8>, true, 3, lds_l3, 4},
+        {"k5 memonly", (const void*)k_v5<4, 28, 3, 9, 8>, true, 3, lds_l3, 4},
+        {"k5 nomem", (const void*)k_v5<4, 3, 3, 9, 8>, true, 3, lds_l3, 4},
         {"k3 1wg full", (const void*)k_v3<4, 0, 1, 30, 0>, true, 1, lds_l3, 4},
         {"k3 1wg nomem", (const void*)k_v3<4, 3, 1, 30, 0>, true, 1, lds_l3, 4},
         {"k3 1wg memonly", (const void*)k_v3<4, 28, 1, 30, 0>, true, 1, lds_l3, 4},
