@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Times and CHECKS alternative super-radix plans (BDSP_FFT_PLAN) for one length and precision.
-usage: BDSP_FFT_PLAN=2048x4,2048x4 python tools/plan_probe.py <log2 n> <f32|f64>"""
+usage: BDSP_HIP_LIBRARY=basic_dsp_amd/lib/libbasic_dsp_hip_lab.so BDSP_FFT_PLAN=2048x4,2048x4 python tools/plan_probe.py <log2 n> <f32|f64>
+(the plan switch exists only in the LAB build of the library: make -C basic_dsp_amd/csrc lab)"""
 import ctypes as C, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
