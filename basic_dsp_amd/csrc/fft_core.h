@@ -396,6 +396,8 @@ BDSP_HD bdsp_f32x2 bf_tw_d(bdsp_f32x2 a, bdsp_f32x2 b, bdsp_f32x2 T)
 BDSP_HD bdsp_f32x2 bf_2a_minus_s(bdsp_f32x2 a, bdsp_f32x2 s)
 {
     bdsp_f32x2 d;
+    // (d = a - (s - a) as two packed adds, no multiplier: 60.6 -> 64.3 us on the block kernel -- an instruction is an
+    // instruction, whatever it computes)
     asm("v_pk_fma_f32 %0, %1, 2.0, %2 op_sel_hi:[1,0,1] neg_lo:[0,0,1] neg_hi:[0,0,1]" : "=v"(d) : "v"(a), "v"(s));
     return d;
 }
