@@ -482,8 +482,12 @@ int interpolatef_dev(const T* in, T* out, size_t len, bool is_complex, int fid, 
             if (eblocks < 1) eblocks = 1;
             const int e = is_complex ? 2 : 1;
             // positions per thread: as many as keep the output staging buffer at 32 KB
-            constexpr int QB = 1;
-            const int qb = is_complex ? QB : (sizeof(T) == 4 ? 4 : 1);
+            // *measured* (round 3, tools/c4b_bench.py, 4M -> 16M): real f64 with 1 / 2 / 3 / 4 positions per thread 45.4 / 35.9 /
+            // 34.9 / 37.4 us; complex f32 with 1 / 2 / 4: 40.6 / 40.0 / 45.5; complex f64 stays at 1 (round 2: 2 halves the
+            // occupancy through its 32 KB staging buffer)
+            constexpr int QB = sizeof(T) == 4 ? 2 : 1;   // complex
+            constexpr int QBR = sizeof(T) == 4 ? 4 : 2;  // real
+            const int qb = is_complex ? QB : QBR;
             const size_t tile = 256 * (size_t)qb;
             size_t lds2 = sizeof(T) * ((((size_t)f * (ntaps + 1) + 3) & ~(size_t)3) + (((tile + 2 * conv_len + 2) * e + 3) & ~(size_t)3) + tile * (size_t)f * e);
             if (lds2 < lds) lds2 = lds;
@@ -500,7 +504,7 @@ int interpolatef_dev(const T* in, T* out, size_t len, bool is_complex, int fid, 
 #define BDSP_INNER(FV)                                                                             \
     do {                                                                                           \
         if (is_complex) BDSP_INNER2(FV, true, QB);                                                 \
-        else BDSP_INNER2(FV, false, (sizeof(T) == 4 ? 4 : 1));                                     \
+        else BDSP_INNER2(FV, false, QBR);                                                          \
     } while (0)
             if (f == 2) BDSP_INNER(2); else if (f == 3) BDSP_INNER(3); else if (f == 4) BDSP_INNER(4); else BDSP_INNER(8);
 #undef BDSP_INNER2
