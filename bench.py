@@ -496,6 +496,10 @@ def run_rank(args):
                 "algorithmic_bytes_per_launch": algo_bytes,
                 "avg_launch_ms": conv_avg,
                 "event_delta_ms": conv_raw, "event_pair_overhead_ms": event_overhead,
+                # what keeps the kernel from the roofline (measured, DESIGN.md 4.3 / profiles/r03_conv_lab_variants.txt): with packed-f32
+                # arithmetic AND a saturated memory system the socket sits at its 1400 W cap and the core clock at 1.9 of 2.4 GHz;
+                # the kernel's memory traffic alone takes 41 us, its arithmetic + LDS exchanges alone 37 us
+                "limited_by": "socket power cap: 1400 W reached, sclk 1.9 GHz instead of 2.4 (memory skeleton alone 41 us, arithmetic + exchanges alone 37 us)",
                 "dominant_per_launch": bool(conv_avg >= fft_avg / passes),
                 "share_of_step": conv_avg / (conv_avg + fft_avg),
                 # the whole step and the transform, in the same terms (algorithmic bytes: 32 B per sample for the step,
