@@ -65,6 +65,20 @@ def test_is_supported_fft_len_contract():
     assert f(1, 2) == 1 and f(1, 2 * 4096) == 1 and f(1, 2 * 1000) == 1 and f(1, 2 * 12289) == 1
 
 
+def test_fft_passes_and_block_share_knob_without_a_gpu():
+    """Plan queries and tuning knobs answer without a device: trips through memory of a power-of-two transform
+    (1 resident, 2 / 3 global passes, 0 = not a power-of-two plan), the block-share knob's argument check."""
+    import basic_dsp_amd as b
+    f = b.lib.bdsp_hip_fft_passes
+    for elem in (0, 1):
+        assert f(elem, 16) == 1 and f(elem, 4096) == 1
+        assert f(elem, 1 << 13) == 2 and f(elem, 1 << 20) == 2 and f(elem, 1 << 22) == 2
+        assert f(elem, 1 << 23) == 3 and f(elem, 1 << 24) == 3 and f(elem, 1 << 30) == 3
+        assert f(elem, 0) == 0 and f(elem, 1000) == 0 and f(elem, 1 << 31) == 0
+    s = b.lib.bdsp_hip_conv_block_shares
+    assert s(60, 45) == -1 and s(0, 10) == -1 and s(43, 37) == 0 and s(33, 33) == 0 and s(-1, -1) == 0
+
+
 def test_host_sim_of_workgroup_fft(tmp_path):
     """The kernels' index math, butterflies and twiddle conventions (fft_core.h) run on the CPU."""
     import subprocess
