@@ -894,8 +894,11 @@ __global__ __launch_bounds__(256, WPC) void k_v3(Args a, unsigned nb_lo, unsigne
     };
     const unsigned G = gridDim.x;
     {
+        // ABL bit 128: the wrap-around blocks go to the LAST workgroups of the grid (the last dispatch group, whose
+        // highest-numbered workgroups have one block fewer than the others) instead of the first ones
         const unsigned nwrap = nb_lo + (a.blocks - nb_hi);
-        for (unsigned w = blockIdx.x; w < nwrap; w += G) {
+        const unsigned me = (ABL & 128) ? G - 1 - blockIdx.x : blockIdx.x;
+        for (unsigned w = me; w < nwrap; w += G) {
             const unsigned b = w < nb_lo ? w : nb_hi + (w - nb_lo);
             C v[16];
             load_block(a, b, V, ut, v);
@@ -904,7 +907,9 @@ __global__ __launch_bounds__(256, WPC) void k_v3(Args a, unsigned nb_lo, unsigne
         }
     }
     const unsigned total = nb_hi - nb_lo, gs = G / WPC;
-    unsigned na = RA * gs, nbb = WPC >= 3 ? RB * gs : 0;
+    // RA / RB: whole rounds of gs blocks, or (values >= 64) sixteenths of a round -- shares need not be whole rounds: the
+    // first (share mod gs) workgroups of a group then take one block more than the others
+    unsigned na = RA >= 64 ? RA * gs / 16 : RA * gs, nbb = WPC >= 3 ? (RB >= 64 ? RB * gs / 16 : RB * gs) : 0;
     if (na > total) na = total;
     if (na + nbb > total) nbb = total - na;
     const unsigned grp = blockIdx.x / gs;
@@ -1730,6 +1735,27 @@ int main(int argc, char** argv)
         {"k3 wide ldst", (const void*)k_v3<4, 96, 3, 9, 8>, true, 3, lds_l3, 4},
         {"k3 wide ldst memonly", (const void*)k_v3<4, 96 + 28, 3, 9, 8>, true, 3, lds_l3, 4},
         {"k3 wide ldst nolds", (const void*)k_v3<4, 96 + 4, 3, 9, 8>, true, 3, lds_l3, 4},
+        {"k3f 144/104", (const void*)k_v3<4, 0, 3, 144, 104>, true, 3, lds_l3, 4},
+        {"k3f 144/108", (const void*)k_v3<4, 0, 3, 144, 108>, true, 3, lds_l3, 4},
+        {"k3f 144/112", (const void*)k_v3<4, 0, 3, 144, 112>, true, 3, lds_l3, 4},
+        {"k3f 144/116", (const void*)k_v3<4, 0, 3, 144, 116>, true, 3, lds_l3, 4},
+        {"k3f 144/120", (const void*)k_v3<4, 0, 3, 144, 120>, true, 3, lds_l3, 4},
+        {"k3f 149/104", (const void*)k_v3<4, 0, 3, 149, 104>, true, 3, lds_l3, 4},
+        {"k3f 149/108", (const void*)k_v3<4, 0, 3, 149, 108>, true, 3, lds_l3, 4},
+        {"k3f 149/112", (const void*)k_v3<4, 0, 3, 149, 112>, true, 3, lds_l3, 4},
+        {"k3f 149/116", (const void*)k_v3<4, 0, 3, 149, 116>, true, 3, lds_l3, 4},
+        {"k3f 149/120", (const void*)k_v3<4, 0, 3, 149, 120>, true, 3, lds_l3, 4},
+        {"k3f 152/104", (const void*)k_v3<4, 0, 3, 152, 104>, true, 3, lds_l3, 4},
+        {"k3f 152/108", (const void*)k_v3<4, 0, 3, 152, 108>, true, 3, lds_l3, 4},
+        {"k3f 152/112", (const void*)k_v3<4, 0, 3, 152, 112>, true, 3, lds_l3, 4},
+        {"k3f 152/116", (const void*)k_v3<4, 0, 3, 152, 116>, true, 3, lds_l3, 4},
+        {"k3f 152/120", (const void*)k_v3<4, 0, 3, 152, 120>, true, 3, lds_l3, 4},
+        {"k3f 156/104", (const void*)k_v3<4, 0, 3, 156, 104>, true, 3, lds_l3, 4},
+        {"k3f 156/108", (const void*)k_v3<4, 0, 3, 156, 108>, true, 3, lds_l3, 4},
+        {"k3f 156/112", (const void*)k_v3<4, 0, 3, 156, 112>, true, 3, lds_l3, 4},
+        {"k3f 156/116", (const void*)k_v3<4, 0, 3, 156, 116>, true, 3, lds_l3, 4},
+        {"k3f 156/120", (const void*)k_v3<4, 0, 3, 156, 120>, true, 3, lds_l3, 4},
+        {"k3 wraplast", (const void*)k_v3<4, 128, 3, 9, 8>, true, 3, lds_l3, 4},
         {"k3 abl noload", (const void*)k_v3<4, 1, 3, 9, 8>, true, 3, lds_l3, 4},
         {"k3 abl nostore", (const void*)k_v3<4, 2, 3, 9, 8>, true, 3, lds_l3, 4},
         {"k3 abl nomem", (const void*)k_v3<4, 3, 3, 9, 8>, true, 3, lds_l3, 4},
