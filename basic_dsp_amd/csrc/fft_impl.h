@@ -634,6 +634,8 @@ __global__ __launch_bounds__(W * (RP / 16), (pass_min_waves<T, RP, W, GEN>())) v
 #pragma unroll
                 for (int r = 0; r < RL; ++r) {
                     const cpx<T> z = v[b * RL + r];
+                    // (streamed with non-temporal stores: C2 x 64 377 -> 422 us -- 4-byte pieces of a line arrive from different
+                    // lanes and instructions and need the cache to be merged)
                     outr[(size_t)F::template out_index<RL, NSL>(t2, b, r ^ sx) * nsg] = mag ? dev_hypot<T>(z.x, z.y) : z.x;
                 }
             return;
