@@ -1,7 +1,7 @@
 #!/bin/bash
-# A/B of two builds of the library on the same box: round-2 library (tools/lab/old_lib) against the tree's.
+# A/B of two builds of the library on the same box: baseline library (tools/build_baseline.sh -> tools/lab/old_lib) against the tree's.
 # usage: tools/ab_r03.sh   (on the GPU box)
-OLD=tools/lab/old_lib/libbasic_dsp_hip_r02.so
+OLD=tools/lab/old_lib/libbasic_dsp_hip_B.so
 for rep in 1 2; do
   for lib in "$OLD" ""; do
     echo "== lib: ${lib:-tree}"
