@@ -49,7 +49,7 @@ template <typename T> __device__ __forceinline__ Cx<T> cx_sqrt(Cx<T> z)
     return cx_from_polar<T>(sqrt(hypot(z.re, z.im)), atan2(z.im, z.re) / T(2));
 }
 
-template <typename T> __device__ Cx<T> cx_apply(Cx<T> z, int fn, T arg)
+template <typename T> __device__ __forceinline__ Cx<T> cx_apply(Cx<T> z, int fn, T arg)
 {
     const Cx<T> one{T(1), T(0)}, two{T(2), T(0)}, i{T(0), T(1)}, mi{T(0), T(-1)};
     switch (fn) {
@@ -91,7 +91,7 @@ template <typename T> __device__ Cx<T> cx_apply(Cx<T> z, int fn, T arg)
     }
 }
 
-template <typename T> __device__ T re_apply(T x, int fn, T arg)
+template <typename T> __device__ __forceinline__ T re_apply(T x, int fn, T arg)
 {
     switch (fn) {
     case MATH_SQRT: return sqrt(x);
@@ -123,6 +123,34 @@ template <typename T> __device__ T re_apply(T x, int fn, T arg)
 
 template <typename T> struct OpMath {
     struct Params { int fn; int cplx; T arg; };
+    // One 16-byte packet held in REGISTERS: the 25-way switch is far too large to unroll per element, and a rolled loop
+    // that indexes the packet with its counter would push the packet to scratch -- so the element is picked and put back
+    // with compare-selects on the counter (VN <= 4).
+    template <int VN>
+    static __device__ __forceinline__ void apply_packet(T (&el)[VN], Params p)
+    {
+        const int step = p.cplx ? 2 : 1;
+#pragma unroll 1
+        for (int k = 0; k < VN; k += step) {
+            T a = el[0], b = VN > 1 ? el[1] : T(0);
+#pragma unroll
+            for (int j = 1; j < VN; ++j) {
+                a = (k == j) ? el[j] : a;
+                if (j + 1 < VN) b = (k == j) ? el[j + 1] : b;
+            }
+            if (p.cplx) {
+                const Cx<T> r = cx_apply<T>(Cx<T>{a, b}, p.fn, p.arg);
+                a = r.re; b = r.im;
+            } else {
+                a = re_apply<T>(a, p.fn, p.arg);
+            }
+#pragma unroll
+            for (int j = 0; j < VN; ++j) {
+                el[j] = (k == j) ? a : el[j];
+                if (p.cplx && j > 0) el[j] = (k == j - 1) ? b : el[j];
+            }
+        }
+    }
     static __device__ __forceinline__ void apply(T* e, int n, size_t, Params p)
     {
         if (p.cplx) {
@@ -136,9 +164,48 @@ template <typename T> struct OpMath {
     }
 };
 
+// The math family is bound by its transcendental functions, not by memory: ONE packet per loop iteration (k_map_simple) with
+// the 25-way switch inlined once, instead of k_map_inplace's four packets in flight -- as out-of-line calls the switch
+// functions needed a stack frame (80 bytes of scratch per lane in the f64 instantiation, the last kernel of the library
+// that used any).
+template <typename T, typename OP>
+__global__ __launch_bounds__(256) void k_map_simple(T* __restrict__ x, size_t len, typename OP::Params p)
+{
+    using V = typename Vec16<T>::type;
+    constexpr int VN = Vec16<T>::N;
+    const size_t nvec = len / VN;
+    V* xv = reinterpret_cast<V*>(x);
+    // contiguous runs per workgroup, like k_map_inplace (far-apart concurrent streams thrash DRAM pages)
+    size_t per = (nvec + gridDim.x - 1) / gridDim.x;
+    per = (per + 255) / 256 * 256;
+    const size_t p0 = (size_t)blockIdx.x * per, p1 = p0 + per < nvec ? p0 + per : nvec;
+    for (size_t i = p0 + threadIdx.x; i < p1; i += 256) {
+        V pk = xv[i];
+        T el[VN];
+#pragma unroll
+        for (int j = 0; j < VN; ++j) el[j] = reinterpret_cast<T*>(&pk)[j];
+        OP::template apply_packet<VN>(el, p);
+#pragma unroll
+        for (int j = 0; j < VN; ++j) reinterpret_cast<T*>(&pk)[j] = el[j];
+        xv[i] = pk;
+    }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+        const size_t done = nvec * VN;
+        if (done < len) OP::apply(x + done, (int)(len - done), done, p); // (fewer than VN scalars, in place)
+    }
+}
+
 template <typename T> int ew_math(T* x, size_t len, bool is_complex, int fn, T arg, hipStream_t s)
 {
-    return launch_map<T, OpMath<T>>(x, len, {fn, is_complex ? 1 : 0, arg}, s);
+    if (len == 0) return BDSP_OK;
+    if (reinterpret_cast<uintptr_t>(x) % 16 != 0) {
+        set_last_error("elementwise: buffer must be 16-byte aligned");
+        return BDSP_ERR_UNSUPPORTED;
+    }
+    hipLaunchKernelGGL((k_map_simple<T, OpMath<T>>), dim3(ew_grid(len / Vec16<T>::N + 1)), dim3(256), 0, s, x, len,
+                       typename OpMath<T>::Params{fn, is_complex ? 1 : 0, arg});
+    BDSP_LAUNCH_CHECK();
+    return BDSP_OK;
 }
 
 // ---- diff / diff_with_start: out-of-place into the trade buffer ------------------------------------------------
