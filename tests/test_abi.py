@@ -65,6 +65,17 @@ def test_is_supported_fft_len_contract():
     assert f(1, 2) == 1 and f(1, 2 * 4096) == 1 and f(1, 2 * 1000) == 1 and f(1, 2 * 12289) == 1
 
 
+def test_the_product_library_reads_no_environment_variable():
+    """Experiment switches live in the LAB build only (make -C basic_dsp_amd/csrc lab): the shipped library does not even
+    import getenv."""
+    import subprocess
+    import basic_dsp_amd._lib as L
+    if os.path.basename(L.LIB_PATH) != "libbasic_dsp_hip.so":
+        pytest.skip("a library override is loaded")
+    out = subprocess.run(["nm", "-D", "--undefined-only", L.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    assert "getenv" not in out
+
+
 def test_fft_passes_and_block_share_knob_without_a_gpu():
     """Plan queries and tuning knobs answer without a device: trips through memory of a power-of-two transform
     (1 resident, 2 / 3 global passes, 0 = not a power-of-two plan), the block-share knob's argument check."""
