@@ -281,11 +281,11 @@ REAL_FN64 = C.CFUNCTYPE(_D, _P, _D)
 
 _proto("bdsp_hip_dev_fft", _I, _I, _P, _P, _SZ, _SZ, _U, _D, _I, _D, C.POINTER(_I), _P)
 _proto("bdsp_hip_dev_convolve", _I, _I, _P, _P, _SZ, _SZ, _P, _SZ, _P)
+_proto("bdsp_hip_dev_convolve_ex", _I, _I, _P, _P, _SZ, _SZ, _P, _SZ, _I, _I, _P)
 _proto("bdsp_hip_conv_spectrum_points", _SZ)
 _proto("bdsp_hip_fft_passes", _I, _I, _SZ)
 _proto("bdsp_hip_capture_abort", _I, _P)
 _proto("bdsp_hip_compute_units", _I)
-_proto("bdsp_hip_conv_block_shares", _I, _I, _I)
 _proto("bdsp_hip_dev_conv_prepare", _I, _I, _P, _SZ, _P, _P)
 _proto("bdsp_hip_dev_convolve_prepared", _I, _I, _P, _P, _SZ, _SZ, _P, _SZ, _P)
 _proto("bdsp_hip_dev_real_scale", _I, _I, _P, _SZ, _D, _P)

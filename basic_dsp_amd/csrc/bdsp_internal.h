@@ -128,7 +128,8 @@ template <typename T> size_t conv_block_step(size_t points, size_t taps, bool re
 // conv_v2.hip: the second-generation block kernel (complex f32 and f64)
 size_t conv_v2_block_step(size_t taps);
 bool conv_v2_applies(size_t points, size_t taps);
-// shares of the block kernel's dispatch groups in percent (-1: the measured defaults), bdsp_hip_conv_block_shares
+// shares of the block kernel's dispatch groups in percent (-1: the measured defaults) for the CALLING THREAD's next launches
+// (bdsp_hip_dev_convolve_ex sets them around one call)
 void conv_v2_set_shares(int first_pct, int second_pct);
 template <typename T>
 int conv_v2_run(const T* in, T* out, size_t points, size_t batch, const T* hs, size_t taps,

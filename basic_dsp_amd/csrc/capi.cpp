@@ -548,7 +548,13 @@ size_t b1_overlap_discard(T* x_time, size_t x_len, T* tmp, size_t tmp_len, const
         set_last_error("overlap_discard: unsupported argument combination");
         return 0;
     }
-    if (check_device() != BDSP_OK) return 0;
+    // (the return value is a position: a failure is only visible through last_error, so every failing path leaves a
+    // message there -- also the ones whose callee returned a bare code)
+    auto failed = [](int code) -> size_t {
+        if (bdsp_hip_last_error()[0] == '\0') set_last_error("overlap_discard: backend failure, code " + std::to_string(code));
+        return 0;
+    };
+    if (const int c = check_device(); c != BDSP_OK) return failed(c);
     // blocks at positions 0, step, 2*step, ... : the first one always, then while pos + l < xp
     size_t nb = 1;
     while (nb * step + l < xp) ++nb;
@@ -587,7 +593,7 @@ size_t b1_overlap_discard(T* x_time, size_t x_len, T* tmp, size_t tmp_len, const
         BDSP_HIP_TRY(hipStreamSynchronize(s));
         return BDSP_OK;
     };
-    if (run() != BDSP_OK) return 0;
+    if (const int c = run(); c != BDSP_OK) return failed(c);
     return nb * step_size;
 }
 
@@ -2408,11 +2414,29 @@ int bdsp_hip_dev_convolve(int elem, const void* in, void* out, size_t points, si
     return conv_complex_dev<double>((const double*)in, (double*)out, points, batch, (const double*)taps_dev, taps, s);
 }
 
+int bdsp_hip_dev_convolve_ex(int elem, const void* in, void* out, size_t points, size_t batch, const void* taps_dev,
+                             size_t taps, int first_pct, int second_pct, void* stream)
+{
+    const bool defaults = first_pct < 0 && second_pct < 0;
+    if (!defaults && (first_pct < 1 || second_pct < 0 || first_pct + second_pct > 99)) {
+        set_last_error("dev_convolve_ex: the shares leave the last dispatch group nothing to do");
+        return BDSP_ERR_ARG_LENGTH;
+    }
+    struct Scope { // the override lives for this call on this thread only
+        Scope(int a, int b) { conv_v2_set_shares(a, b); }
+        ~Scope() { conv_v2_set_shares(-1, -1); }
+    } scope(defaults ? -1 : first_pct, defaults ? -1 : second_pct);
+    return bdsp_hip_dev_convolve(elem, in, out, points, batch, taps_dev, taps, stream);
+}
+
 size_t bdsp_hip_conv_spectrum_points(void) { return conv_fft_len(0); }
 
 int bdsp_hip_fft_passes(int elem, size_t points)
 {
     if (points == 0 || (points & (points - 1)) != 0 || points > (size_t(1) << 30)) return 0;
+    // a PLAIN 8192-point f32 transform -- what bdsp_hip_dev_fft launches without flags, scale or window -- is one
+    // workgroup-resident trip (fft_pow2 -> launch_wg4); with fused options it takes the two passes of the plan
+    if (elem == 0 && points == 8192) return 1;
     return elem == 0 ? fft_pow2_passes<float>(points) : fft_pow2_passes<double>(points);
 }
 
@@ -2490,13 +2514,6 @@ int bdsp_hip_compute_units(void)
     return num_cus();
 }
 
-int bdsp_hip_conv_block_shares(int first_pct, int second_pct)
-{
-    if (first_pct < 0 && second_pct < 0) { conv_v2_set_shares(-1, -1); return 0; }
-    if (first_pct < 1 || second_pct < 0 || first_pct + second_pct > 99) return -1;
-    conv_v2_set_shares(first_pct, second_pct);
-    return 0;
-}
 
 void* bdsp_hip_event_create(void)
 {
@@ -2563,6 +2580,12 @@ int bdsp_hip_capture_abort(void* stream)
         std::lock_guard<std::mutex> lk(g_bs_mu);
         if (!g_capture_open) return BDSP_OK;
         if (g_capture_stream != st) { set_last_error("capture_abort: the open capture is on another stream"); return BDSP_ERR_UNSUPPORTED; }
+        // a capture belongs to the thread that opened it (capture_end enforces the same): another thread must not tear it
+        // down, and unpin its plans and blocks, while the owner is still recording
+        if (g_capture_thread != std::this_thread::get_id()) {
+            set_last_error("capture_abort: the open capture belongs to another thread");
+            return BDSP_ERR_UNSUPPORTED;
+        }
         ws_capture_end(st, &blocks);
         plans.swap(g_capture_plans);
         for (void* c : plans)

@@ -331,11 +331,13 @@ size_t conv_v2_block_step(size_t taps)
     return (size_t)L2 - 256 * r0;
 }
 
-static std::atomic<int> g_share_a{-1}, g_share_b{-1};
+// Per-CALL override of the dispatch-group shares (bdsp_hip_dev_convolve_ex sets it around its own launch): the
+// calling thread's, so that no other thread's launches see it and the pair can never be read torn.
+static thread_local int t_share_a = -1, t_share_b = -1;
 void conv_v2_set_shares(int first_pct, int second_pct)
 {
-    g_share_a.store(first_pct);
-    g_share_b.store(second_pct);
+    t_share_a = first_pct;
+    t_share_b = second_pct;
 }
 
 bool conv_v2_applies(size_t points, size_t taps)
@@ -397,8 +399,8 @@ int conv_v2_run(const T* in, T* out, size_t points, size_t batch, const T* hs, s
     // shares in whole rounds of gs blocks.  Three groups: ~43 % / ~37 % / rest (measured optimum 9 / 8 / 4.3 rounds of
     // 21.3); two groups: ~55 % / rest (12 of 21.3 rounds measured best for two workgroups per CU)
     const unsigned long long rounds = (interior + gs - 1) / gs;
-    // (bdsp_hip_conv_block_shares overrides the percentages: the guard test times equal shares against these)
-    const int sa = g_share_a.load(), sb = g_share_b.load();
+    // (bdsp_hip_dev_convolve_ex overrides the percentages for its own call: the guard test times equal shares against these)
+    const int sa = t_share_a, sb = t_share_b;
     const unsigned long long pa = sa > 0 ? (unsigned long long)sa : (GROUPS == 3 ? 43 : 55);
     const unsigned long long pb = GROUPS == 3 ? (sa > 0 ? (unsigned long long)sb : 37) : 0;
     unsigned long long ra = (rounds * pa + 50) / 100, rb = (rounds * pb + 50) / 100;

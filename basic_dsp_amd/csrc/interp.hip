@@ -407,15 +407,22 @@ static int interp_tap_table(int fid, T rolloff, int conv_len, int f, T delay, hi
     auto it = g_tap_cache.find(key);
     if (it != g_tap_cache.end()) { *table = static_cast<const T*>(it->second); return BDSP_OK; }
     T* dst = nullptr;
-    const bool cache = g_tap_cache.size() < 32;
+    // A table is cached only when this call may synchronise the stream: a cache miss while the stream is being captured
+    // into a HIP graph takes the uncached workspace route (the table kernel is then part of the graph), because
+    // hipStreamSynchronize on a capturing stream invalidates the capture.
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusNone; }
+    const bool cache = g_tap_cache.size() < 32 && cap == hipStreamCaptureStatusNone;
     if (cache) BDSP_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dst), bytes));
     else { BDSP_TRY(fallback->alloc(bytes, s)); dst = fallback->as<T>(); }
     hipLaunchKernelGGL((k_interp_taps<T>), dim3((f * ntaps + 63) / 64), dim3(64), 0, s, dst, fid, rolloff, conv_len, f, delay);
-    BDSP_LAUNCH_CHECK();
-    if (cache) {
-        BDSP_HIP_TRY(hipStreamSynchronize(s));
-        g_tap_cache[key] = dst;
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess && cache) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) {
+        if (cache) (void)hipFree(dst); // never entered into the cache: give it back
+        return hip_fail(e, "interp_tap_table", __FILE__, __LINE__);
     }
+    if (cache) g_tap_cache[key] = dst;
     *table = dst;
     return BDSP_OK;
 }

@@ -44,14 +44,19 @@ struct DeviceCtx {
 std::mutex g_mu;
 std::map<int, DeviceCtx> g_ctx;
 int g_probe = -2; // -2 unknown, BDSP_OK, or error
+std::string g_probe_msg; // why the probe failed: repeated to EVERY later caller (last_error is per thread and per call)
 
 int probe_locked()
 {
-    if (g_probe != -2) return g_probe;
+    if (g_probe != -2) {
+        if (g_probe != BDSP_OK) g_last_error = g_probe_msg;
+        return g_probe;
+    }
     int count = 0;
     hipError_t e = hipGetDeviceCount(&count);
     if (e != hipSuccess || count <= 0) {
-        g_last_error = std::string("no HIP device: ") + hipGetErrorString(e);
+        g_probe_msg = std::string("no HIP device: ") + hipGetErrorString(e);
+        g_last_error = g_probe_msg;
         (void)hipGetLastError();
         g_probe = BDSP_ERR_NO_DEVICE;
         return g_probe;

@@ -743,7 +743,8 @@ int bdsp_hip_dev_fft(int elem, void *data, void *scratch, size_t points, size_t 
                      unsigned flags, double in_scale, int window_id, double window_alpha,
                      int *result_in_scratch, void *stream);
 /* Trips through device memory a power-of-two transform of `points` complex points makes (1: one workgroup-resident
- * kernel, 2 or 3: global Stockham passes) -- what bdsp_hip_dev_fft will launch; 0 for lengths that are not a power
+ * kernel, 2 or 3: global Stockham passes) -- what bdsp_hip_dev_fft will launch for a PLAIN transform (no flags, scale or
+ * window: f32 8192 points = 1, two passes once an option is fused); 0 for lengths that are not a power
  * of two (mixed-radix / chirp-z plans) or out of range.  The benchmark's per-pass figures read it from here. */
 int bdsp_hip_fft_passes(int elem, size_t points);
 
@@ -752,6 +753,16 @@ int bdsp_hip_fft_passes(int elem, size_t points);
  * out must not alias in.  */
 int bdsp_hip_dev_convolve(int elem, const void *in, void *out, size_t points, size_t batch,
                           const void *taps_dev, size_t taps, void *stream);
+
+/* bdsp_hip_dev_convolve with the fused block kernel's dispatch-group shares given FOR THIS CALL: its persistent
+ * workgroups are dispatched in groups (three for f32) and the groups dispatched first get a larger share of the blocks,
+ * because the hardware issues the oldest wave first.  first_pct / second_pct = percent of the blocks for
+ * the first / second group (defaults f32 43 / 37, f64 55 / -); (33, 33) = equal shares; (-1, -1) = the defaults, i.e.
+ * bdsp_hip_dev_convolve.  The shares only move blocks between workgroups (bit-identical output); nothing outlives the
+ * call and no other thread's launches see it -- the dispatch-order guard test times equal shares against the defaults
+ * through this entry point.  BDSP_ERR_ARG_LENGTH for shares that leave the last group nothing to do. */
+int bdsp_hip_dev_convolve_ex(int elem, const void *in, void *out, size_t points, size_t batch,
+                             const void *taps_dev, size_t taps, int first_pct, int second_pct, void *stream);
 
 /* The same convolution split in two, so a caller that reuses one filter (the batch driver, the
  * benchmark) builds its spectrum once: prepare writes bdsp_hip_conv_spectrum_points() complex
@@ -782,13 +793,6 @@ int bdsp_hip_synchronize(void *stream);
 int bdsp_hip_set_device(int ordinal);
 /* Compute units of the bound device (256 on MI355X: 8 XCDs of 32); 0 without a device. */
 int bdsp_hip_compute_units(void);
-/* Tuning knob of the fused overlap-save block kernel, also what its guard test turns: the persistent workgroups of
- * a CU are dispatched in groups (three for f32), and the groups dispatched first get a larger share of the blocks
- * because the hardware issues the oldest wave first.  first_pct / second_pct = percent of the blocks
- * for the first / second dispatch group (f32 default 43 / 37, f64 55 / -); (33, 33) = equal shares; (-1, -1)
- * restores the defaults.  Process-wide, takes effect from the next launch.  Returns 0, or -1 for shares that do not
- * leave the last group anything to do. */
-int bdsp_hip_conv_block_shares(int first_pct, int second_pct);
 
 /* Timing hooks for bench.py: HIP events recorded on `stream`; elapsed milliseconds between
  * two recorded events.  (torch.cuda.Event only sees torch's current stream.) */

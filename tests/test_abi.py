@@ -76,18 +76,52 @@ def test_the_product_library_reads_no_environment_variable():
     assert "getenv" not in out
 
 
-def test_fft_passes_and_block_share_knob_without_a_gpu():
-    """Plan queries and tuning knobs answer without a device: trips through memory of a power-of-two transform
-    (1 resident, 2 / 3 global passes, 0 = not a power-of-two plan), the block-share knob's argument check."""
+def test_fft_passes_and_block_share_argument_check_without_a_gpu():
+    """Plan queries answer without a device: trips through memory of a power-of-two transform (1 resident, 2 / 3 global
+    passes, 0 = not a power-of-two plan).  The per-call block shares of bdsp_hip_dev_convolve_ex are checked before
+    anything touches a device, and the old process-wide knob is gone from the ABI."""
     import basic_dsp_amd as b
     f = b.lib.bdsp_hip_fft_passes
     for elem in (0, 1):
         assert f(elem, 16) == 1 and f(elem, 4096) == 1
-        assert f(elem, 1 << 13) == 2 and f(elem, 1 << 20) == 2 and f(elem, 1 << 22) == 2
+        assert f(elem, 1 << 13) == (1 if elem == 0 else 2)  # f32: the one-workgroup 8192-point kernel (fft_pow2 -> launch_wg4)
+        assert f(elem, 1 << 14) == 2 and f(elem, 1 << 20) == 2 and f(elem, 1 << 22) == 2
         assert f(elem, 1 << 23) == 3 and f(elem, 1 << 24) == 3 and f(elem, 1 << 30) == 3
         assert f(elem, 0) == 0 and f(elem, 1000) == 0 and f(elem, 1 << 31) == 0
-    s = b.lib.bdsp_hip_conv_block_shares
-    assert s(60, 45) == -1 and s(0, 10) == -1 and s(43, 37) == 0 and s(33, 33) == 0 and s(-1, -1) == 0
+    assert not hasattr(b.lib, "bdsp_hip_conv_block_shares")
+    ex = b.lib.bdsp_hip_dev_convolve_ex
+    for bad in ((60, 45), (0, 10), (-1, 5)):
+        assert ex(0, None, None, 0, 0, None, 0, bad[0], bad[1], None) == 7  # BDSP_ERR_ARG_LENGTH, before any device call
+        assert b"shares" in b.lib.bdsp_hip_last_error()
+
+
+def test_overlap_discard_reports_failure_out_of_band_without_a_gpu():
+    """The B1 return value is a position, so a failure must leave a message in last_error on EVERY failing path -- also
+    when the device probe failed on an earlier call or another thread: without a device every call raises."""
+    import numpy as np
+    import threading
+    import basic_dsp_amd as b
+    import basic_dsp_amd.vector as V
+    if b.lib.bdsp_hip_has_gpu_support_f32():
+        pytest.skip("a GPU is present")
+    x = np.zeros(2 * 64, dtype=np.float32)
+    tmp = np.zeros(2 * 16, dtype=np.float32)
+    h = np.zeros(2 * 16, dtype=np.float32)
+    for _ in range(3):
+        with pytest.raises(b.BackendError):
+            V.gpu_overlap_discard(x, tmp, h, 2 * 4, 2 * 8)
+    seen = []
+
+    def other_thread():
+        try:
+            V.gpu_overlap_discard(x, tmp, h, 2 * 4, 2 * 8)
+            seen.append("returned")
+        except b.BackendError as e:
+            seen.append(str(e))
+    t = threading.Thread(target=other_thread)
+    t.start()
+    t.join()
+    assert seen and seen[0] != "returned" and "no HIP device" in seen[0], seen
 
 
 def test_host_sim_of_workgroup_fft(tmp_path):
