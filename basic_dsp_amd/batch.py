@@ -37,8 +37,10 @@ def process_shard_gpu(shard, taps, points, stream=None):
     """convolve_signal(shared taps) then plain_fft on every vector of `shard`.
 
     shard: [n_vec, 2*points] f32/f64 CUDA tensor (interleaved complex); taps: [2*M] CUDA tensor.
-    Returns a tensor of the same shape holding the spectra.  Two batched launches for the
-    convolution (spectrum of the taps + fused overlap-save over all vectors) and the batched FFT.
+    Returns a NEW tensor of the same shape holding the spectra; `shard` is left untouched (the drivers below hand
+    over views of the caller's batch on rank 0).  Two batched launches for the convolution (spectrum of the taps +
+    fused overlap-save over all vectors) and the batched FFT, which ping-pongs between the convolution's result and
+    a scratch buffer of its own -- round 3 used `shard` as that partner and so overwrote the caller's rows.
     """
     from . import _lib
     lib = _lib.lib
@@ -51,18 +53,20 @@ def process_shard_gpu(shard, taps, points, stream=None):
     sp = _lib.stream_arg(stream if stream is not None else torch.cuda.current_stream().cuda_stream)
     spec = torch.empty(2 * lib.bdsp_hip_conv_spectrum_points(), device=shard.device, dtype=shard.dtype)
     out = torch.empty_like(shard)
+    scratch = torch.empty_like(shard)
     _lib.check(lib.bdsp_hip_dev_conv_prepare(elem, taps.data_ptr(), m, spec.data_ptr(), sp), "conv_prepare")
     _lib.check(lib.bdsp_hip_dev_convolve_prepared(elem, shard.data_ptr(), out.data_ptr(), points, nvec,
                                                   spec.data_ptr(), m, sp), "convolve")
     flag = C.c_int(0)
-    _lib.check(lib.bdsp_hip_dev_fft(elem, out.data_ptr(), shard.data_ptr(), points, nvec, 0, 1.0, -1, 0.0,
+    _lib.check(lib.bdsp_hip_dev_fft(elem, out.data_ptr(), scratch.data_ptr(), points, nvec, 0, 1.0, -1, 0.0,
                                     C.byref(flag), sp), "fft")
-    return shard if flag.value else out
+    return scratch if flag.value else out
 
 
 def scatter_process_gather(batch, taps, points, process_fn, group=None, device=None):
     """Scatter `batch` ([V, 2*points], meaningful on rank 0 only) from rank 0, run
     process_fn(shard, taps, points) on every rank, gather the results back to rank 0.
+    `batch` is only read: process_fn must not modify its input (rank 0 hands it views of `batch`).
 
     Point-to-point batched sends (one message per peer, all in flight together) rather than a ring:
     xGMI is point-to-point, so each of the 7 links carries exactly one peer's shard.
@@ -128,6 +132,7 @@ def scatter_process_gather_chunked(batch, taps, points, process_fn, chunk_vector
     and the peer transforms chunk r on a SIDE stream while round r + 1 is in flight (on CUDA; the CPU/gloo path
     of the unit tests computes in line).  The two-round lag of the results keeps a round's issue from waiting for
     the transform that has just been queued.  Rank 0 transforms its own shard chunk by chunk between rounds.
+    `batch` is only read: process_fn must not modify its input (rank 0 hands it views of `batch`).
     Returns the gathered [V, 2*points] tensor on rank 0, None elsewhere.
     """
     single = not dist.is_initialized()  # one process, one GPU: the same pipeline without any communication

@@ -112,6 +112,66 @@ def test_scatter_process_gather_chunked_gloo(tmp_path, world, nvec, chunk):
     assert float(open(result).read()) == 0.0
 
 
+def _fast_process(shard, taps, points):
+    """A cheap stand-in for the compute step with the same data dependencies (every output row depends on every
+    sample of its input row and on the taps): exact integer-valued arithmetic in f64, so results are bit-identical
+    however the rows are grouped."""
+    w = torch.arange(1, shard.shape[1] + 1, dtype=shard.dtype)
+    return torch.flip(shard, dims=[1]) * 2.0 + (shard * w).sum(dim=1, keepdim=True) + taps.sum()
+
+
+def _worker_c5_shape(rank, world, port, nvec, points, chunk, result_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from basic_dsp_amd.batch import scatter_process_gather, scatter_process_gather_chunked, shard_bounds
+    batch = taps = keep = None
+    if rank == 0:
+        g = torch.Generator().manual_seed(512)
+        batch = torch.randint(-8, 9, (nvec, 2 * points), generator=g).to(torch.float64)
+        taps = torch.randint(-3, 4, (2 * 9,), generator=g).to(torch.float64)
+        keep = batch.clone()
+    f, l = shard_bounds(nvec, world, rank)
+    errs = []
+    for driver in ("chunked", "whole"):
+        seen = []
+
+        def process(shard, t, p):
+            seen.append(shard.shape[0])
+            return _fast_process(shard, t, p)
+        if driver == "chunked":
+            out = scatter_process_gather_chunked(batch, taps, points, process, chunk_vectors=chunk, device=torch.device("cpu"))
+            # 64 vectors per rank in chunks of 8: eight compute calls of 8 vectors on EVERY rank (8 rounds + 2 of lag)
+            assert seen == [chunk] * ((l - f) // chunk), (rank, seen)
+        else:
+            out = scatter_process_gather(batch, taps, points, process, device=torch.device("cpu"))
+            assert seen == [l - f], (rank, seen)
+        assert (f, l) == (rank * (nvec // world), (rank + 1) * (nvec // world))  # v -> rank v // 64
+        if rank == 0:
+            assert torch.equal(batch, keep), "the drivers only read the caller's batch"
+            errs.append(float((out - _fast_process(keep, taps, points)).abs().max()))
+        else:
+            assert out is None
+    if rank == 0:
+        with open(result_path, "w") as fh:
+            fh.write(" ".join("%g" % e for e in errs))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_c5_shape_at_world_size_8_gloo(tmp_path):
+    """BASELINE config C5's SHAPE without hardware: 8 ranks, 512 vectors, 64 per rank, chunks of 8 vectors = 8 rounds
+    + 2 of lag with 7 peers per round, for both drivers (the 1 048 576-point vectors shrunk to 256 points: the sharding,
+    the round structure and the message pattern do not depend on the length).  Asserts the 64-per-rank map, the number
+    and size of the compute calls on every rank, bit-identity with the single-process result, and that rank 0's batch
+    is left untouched.  Counterpart of the reference's sequential row loop, matrix/src/lib.rs:195-208."""
+    port = _free_port()
+    result = str(tmp_path / "err.txt")
+    mp.spawn(_worker_c5_shape, args=(8, port, 512, 256, 8, result), nprocs=8, join=True)
+    assert [float(x) for x in open(result).read().split()] == [0.0, 0.0]
+
+
 def test_shard_bounds_contiguous_cover():
     from basic_dsp_amd.batch import shard_bounds
     for nvec in (1, 7, 64, 512, 513):

@@ -29,6 +29,26 @@ def test_gpus_n_launches_n_children_dry_run():
     assert launches[0]["env"]["MASTER_PORT"] == launches[1]["env"]["MASTER_PORT"]
 
 
+def test_c5_on_eight_gpus_dry_run_launch():
+    """`bench.py --mode c5 --gpus 8`: eight children, RANK = LOCAL_RANK = 0..7, WORLD_SIZE 8, one rendezvous on
+    127.0.0.1, every child told --mode c5 --gpus 8 (config C5: 64 vectors per GPU, 512 in all)."""
+    p = subprocess.run([sys.executable, BENCH, "--mode", "c5", "--gpus", "8", "--steps", "3", "--warmup", "1", "--dry-run-launch"],
+                       env=_env(), capture_output=True, text=True, timeout=60)
+    assert p.returncode == 0, p.stderr
+    launches = [json.loads(l)["launch"] for l in p.stdout.splitlines() if l.strip()]
+    assert len(launches) == 8
+    ports = set()
+    for r, l in enumerate(launches):
+        e = l["env"]
+        assert (e["RANK"], e["LOCAL_RANK"], e["WORLD_SIZE"], e["LOCAL_WORLD_SIZE"]) == (str(r), str(r), "8", "8")
+        assert e["MASTER_ADDR"] == "127.0.0.1" and int(e["MASTER_PORT"]) > 0
+        ports.add(e["MASTER_PORT"])
+        c = l["cmd"]
+        assert c[1] == BENCH and "--dry-run-launch" not in c
+        assert c[c.index("--mode") + 1] == "c5" and c[c.index("--gpus") + 1] == "8"
+    assert len(ports) == 1
+
+
 def test_gpus_must_match_world_size_under_a_launcher():
     p = subprocess.run([sys.executable, BENCH, "--gpus", "2"], env=_env(WORLD_SIZE="4", RANK="0", LOCAL_RANK="0"),
                        capture_output=True, text=True, timeout=60)

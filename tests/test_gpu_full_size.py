@@ -142,7 +142,9 @@ def test_c5_shard_of_64_1m_vectors_against_the_oracle():
     rows = np.stack([orc.fill_uniform(2 * n, SEED_C2 + r, -10, 10, np.float32) for r in range(nvec)])
     taps = (orc.fill_uniform(2 * m, SEED_C3_H, -1, 1, np.float32) / np.float32(m)).astype(np.float32)
     dev_rows, dev_taps = torch.from_numpy(rows).cuda(), torch.from_numpy(taps).cuda()
-    out = process_shard_gpu(dev_rows.clone(), dev_taps, n)
+    out = process_shard_gpu(dev_rows, dev_taps, n)
+    assert out.data_ptr() != dev_rows.data_ptr()
+    assert np.array_equal(dev_rows.cpu().numpy(), rows)  # the compute step leaves its input alone (round 3 overwrote it)
     # no device-wide synchronize here: .cpu() on torch's stream must already be ordered behind the kernels (they run
     # on the stream process_shard_gpu was given, torch's current one)
     out = out.cpu().numpy()
