@@ -61,6 +61,7 @@ def parse(argv=None):
     ap.add_argument("--vectors-per-gpu", type=int, default=C5_VECTORS_PER_GPU, help="--mode c5")
     ap.add_argument("--chunk-vectors", type=int, default=8, help="--mode c5: vectors per pipelined scatter/gather chunk")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-first-call", action="store_true", help="skip the fresh-process first-call measurement (config.first_call_ms)")
     ap.add_argument("--cpu-sample-points", type=int, default=1 << 23)
     ap.add_argument("--dry-run-launch", action="store_true", help="print the per-rank child launches of --gpus N and exit")
     ap.add_argument("--launch-timeout", type=float, default=900.0, help="own launcher: seconds before the ranks are ended")
@@ -291,6 +292,138 @@ def profile_figures():
     return out
 
 
+
+# ------------------------------------------------------------------------------------------ clock / power samples
+HBM_ACHIEVABLE_GBS = 6290.0  # measured float4 copy on MI355X, /opt/skills/guides/MI355X_MICROARCH.md (secondary fraction)
+
+
+class GpuSampler:
+    """Host-side samples of the GPU's core clock and socket power while the benchmark runs: a thread polls
+    librocm_smi64 (sysfs reads, nothing is launched on the GPU) every few milliseconds; `window(a, b)` summarises the
+    samples taken between two perf_counter times.  Absent library / device / permission: every figure is None --
+    the bench line then says nothing about clocks instead of repeating an old measurement."""
+
+    def __init__(self, pci_bus=None, pci_device=None, period_s=0.002):
+        self.samples = []  # (t, sclk_mhz or None, power_w or None)
+        self.cap_w = None
+        self.sclk_max_mhz = None
+        self.source = None
+        self._stop = False
+        self._thread = None
+        self._period = period_s
+        try:
+            lib = C.CDLL("librocm_smi64.so")
+
+            class Freqs(C.Structure):
+                _fields_ = [("has_deep_sleep", C.c_bool), ("num_supported", C.c_uint32), ("current", C.c_uint32),
+                            ("frequency", C.c_uint64 * 33)]
+            self._Freqs = Freqs
+            if lib.rsmi_init(C.c_uint64(0)) != 0:
+                return
+            n = C.c_uint32(0)
+            if lib.rsmi_num_monitor_devices(C.byref(n)) != 0 or n.value == 0:
+                return
+            dv = 0
+            if n.value > 1 and pci_bus is not None:
+                for i in range(n.value):
+                    bdf = C.c_uint64(0)
+                    if lib.rsmi_dev_pci_id_get(C.c_uint32(i), C.byref(bdf)) == 0 and ((bdf.value >> 8) & 0xff) == pci_bus and \
+                            (pci_device is None or ((bdf.value >> 3) & 0x1f) == pci_device):
+                        dv = i
+                        break
+            self._lib, self._dv = lib, C.c_uint32(dv)
+            cap = C.c_uint64(0)
+            if lib.rsmi_dev_power_cap_get(self._dv, C.c_uint32(0), C.byref(cap)) == 0 and cap.value:
+                self.cap_w = cap.value / 1e6
+            f = Freqs()
+            if lib.rsmi_dev_gpu_clk_freq_get(self._dv, C.c_int(0), C.byref(f)) == 0 and 0 < f.num_supported <= 33:
+                self.sclk_max_mhz = max(f.frequency[i] for i in range(f.num_supported)) / 1e6
+            self.source = "librocm_smi64 (rsmi_dev_gpu_clk_freq_get SYS, rsmi_dev_power_get), device %d of %d" % (dv, n.value)
+        except (OSError, AttributeError):
+            self.source = None
+
+    def _read(self):
+        sclk = power = None
+        f = self._Freqs()
+        if self._lib.rsmi_dev_gpu_clk_freq_get(self._dv, C.c_int(0), C.byref(f)) == 0 and f.current < 33:
+            sclk = f.frequency[f.current] / 1e6
+        pw, ty = C.c_uint64(0), C.c_int(0)
+        try:
+            if self._lib.rsmi_dev_power_get(self._dv, C.byref(pw), C.byref(ty)) == 0:
+                power = pw.value / 1e6
+        except AttributeError:
+            if self._lib.rsmi_dev_current_socket_power_get(self._dv, C.byref(pw)) == 0:
+                power = pw.value / 1e6
+        return sclk, power
+
+    def start(self):
+        if self.source is None:
+            return self
+        import threading
+
+        def loop():
+            while not self._stop:
+                t = time.perf_counter()
+                try:
+                    sclk, power = self._read()
+                except Exception:  # noqa: BLE001  (a sampler must never take the benchmark down)
+                    break
+                self.samples.append((t, sclk, power))
+                time.sleep(self._period)
+        self._thread = threading.Thread(target=loop, daemon=True)
+        self._thread.start()
+        return self
+
+    def stop(self):
+        self._stop = True
+        if self._thread:
+            self._thread.join(timeout=1)
+
+    def window(self, a, b):
+        """Median clock / power of the samples with a <= t <= b (None when there are none)."""
+        def med(v):
+            v = sorted(x for x in v if x is not None)
+            return v[len(v) // 2] if v else None
+        w = [x for x in self.samples if a <= x[0] <= b]
+        return {"samples": len(w), "sclk_mhz": med([x[1] for x in w]), "socket_power_w": med([x[2] for x in w])}
+
+
+FIRST_CALL_CHILD = r"""
+import sys, time
+sys.path.insert(0, sys.argv[1])
+import numpy as np
+import basic_dsp_amd as bd
+from basic_dsp_amd import DspVec
+n, m = int(sys.argv[2]), int(sys.argv[3])
+rng = np.random.default_rng(1)
+x = (rng.random(2 * n, dtype=np.float32) * 20 - 10)
+h = ((rng.random(2 * m, dtype=np.float32) * 2 - 1) / m).astype(np.float32)
+t = time.perf_counter(); bd.require_gpu(); v = DspVec(x, is_complex=True); hv = DspVec(h, is_complex=True); w = DspVec(x, is_complex=True)
+bd.lib.bdsp_hip_synchronize(None); up = time.perf_counter() - t
+out = {"device_init_and_upload_ms": up * 1e3}
+for name, vec, call in (("plain_fft", v, lambda q: q.plain_fft()), ("convolve_signal", w, lambda q: q.convolve_signal(hv))):
+    for rep in ("first", "second", "third"):
+        t = time.perf_counter(); assert call(vec) == 0; bd.lib.bdsp_hip_synchronize(None)
+        out[name + "_" + rep + "_ms"] = (time.perf_counter() - t) * 1e3
+        if name == "plain_fft": vec.plain_ifft()  # back to the time domain (untimed); its own first call loads nothing new but tables
+        bd.lib.bdsp_hip_synchronize(None)
+import json; print("FIRSTCALL " + json.dumps(out))
+"""
+
+
+def first_call_cost(points, taps):
+    """What a caller's very FIRST plain_fft / convolve_signal cost in a fresh process (code-object load of the 570-kernel
+    library, twiddle tables, workspace allocation) next to the second and third call of the same process.  Runs in a
+    child process (numpy + ctypes, no torch) after the timed region; None when it fails."""
+    try:
+        p = subprocess.run([sys.executable, "-c", FIRST_CALL_CHILD, ROOT, str(points), str(taps)], capture_output=True, text=True, timeout=300)
+        for line in p.stdout.splitlines():
+            if line.startswith("FIRSTCALL "):
+                return json.loads(line[len("FIRSTCALL "):])
+        return {"error": (p.stderr or p.stdout)[-300:]}
+    except (OSError, subprocess.SubprocessError, ValueError) as e:
+        return {"error": str(e)[-300:]}
+
 # ------------------------------------------------------------------------------------------ one rank
 def run_rank(args):
     rank = int(os.environ.get("RANK", "0"))
@@ -340,6 +473,9 @@ def run_rank(args):
     bd._lib.check(lib.bdsp_hip_set_device(local_rank), "set_device")
     bd.require_gpu()
 
+    props = torch.cuda.get_device_properties(local_rank)
+    smi = GpuSampler(getattr(props, "pci_bus_id", None), getattr(props, "pci_device_id", None)).start() if rank == 0 else None
+
     c5 = args.mode == "c5"
     n = args.points or (C5_POINTS if c5 else POINTS)
     m = args.taps
@@ -372,8 +508,8 @@ def run_rank(args):
             lib.bdsp_hip_event_record(ev[2], sp)
 
     # per-kernel durations come from HIP events inside the timed region; an event record costs about 2 us of stream
-    # time, so only every `ev_stride`-th step carries the three events (at least eight steps do)
-    ev_stride = max(1, min(8, args.steps // 8))
+    # time, so only every `ev_stride`-th step carries the three events (at least five steps do)
+    ev_stride = max(1, min(8, args.steps // 5))
     events = {i: [lib.bdsp_hip_event_create() for _ in range(3)] for i in range(0, args.steps, ev_stride)}
     # Untimed clock pre-warm: the GPU idles at a few hundred MHz and needs tens of milliseconds of load to reach its
     # sustained clock (*measured*: the same step runs 233 us right after start-up and 216 us once the clock has
@@ -396,6 +532,7 @@ def run_rank(args):
             step(pre)
             pre += 1
         torch.cuda.synchronize()
+    t_pre_end = time.perf_counter()
     for i in range(args.warmup):
         step(i)
     torch.cuda.synchronize()
@@ -410,6 +547,7 @@ def run_rank(args):
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    t_end = t0 + elapsed
     if use_dist:
         t = torch.tensor([elapsed], device=cdev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -455,6 +593,34 @@ def run_rank(args):
         prof = profile_figures() if headline else {}
         fft_algo_gbs = 16.0 * n * nvec / (fft_avg * 1e-3) / 1e9
         step_algo_gbs = 32.0 * n * nvec / ((conv_avg + fft_avg) * 1e-3) / 1e9
+        if smi is not None:
+            smi.stop()
+            w_pre, w_timed = smi.window(t_pre, t_pre_end), smi.window(t0, t_end)
+            clk = {"source": smi.source, "prewarm": w_pre, "timed": w_timed, "power_cap_w": smi.cap_w, "sclk_max_mhz": smi.sclk_max_mhz,
+                   "limited_by": None}
+            pw = w_timed["socket_power_w"] if w_timed["socket_power_w"] is not None else w_pre["socket_power_w"]
+            ck = w_timed["sclk_mhz"] if w_timed["sclk_mhz"] is not None else w_pre["sclk_mhz"]
+            if pw is not None and ck is not None and smi.cap_w and smi.sclk_max_mhz:
+                if pw >= 0.95 * smi.cap_w and ck <= 0.92 * smi.sclk_max_mhz:
+                    clk["limited_by"] = "socket power cap: %.0f of %.0f W, sclk %.0f of %.0f MHz (sampled in this run)" % (pw, smi.cap_w, ck, smi.sclk_max_mhz)
+                elif ck <= 0.92 * smi.sclk_max_mhz:
+                    clk["limited_by"] = "sclk %.0f of %.0f MHz at %.0f of %.0f W (sampled in this run)" % (ck, smi.sclk_max_mhz, pw, smi.cap_w)
+        else:
+            clk = {"source": None, "prewarm": {"samples": 0, "sclk_mhz": None, "socket_power_w": None},
+                   "timed": {"samples": 0, "sclk_mhz": None, "socket_power_w": None}, "power_cap_w": None, "sclk_max_mhz": None, "limited_by": None}
+        if fft_avg >= conv_avg:
+            dominant_by_time = {"kernel": "k_fft_pass<float,256,16> x %d passes (plain_fft)" % passes if not c5 else "k_fft_pass x %d passes (plain_fft)" % passes,
+                                "share_of_step": fft_avg / (conv_avg + fft_avg), "ms": fft_avg,
+                                "frac": fft_algo_gbs / HBM_PEAK_GBS, "frac_vs_achievable": fft_algo_gbs / HBM_ACHIEVABLE_GBS,
+                                "frac_pass_adjusted": fft_algo_gbs * passes / HBM_PEAK_GBS,
+                                "traffic_ratio": (prof["fft_traffic"] / (16.0 * n * nvec)) if prof.get("fft_traffic") else None}
+        else:
+            dominant_by_time = {"kernel": "k_overlap_save_v2 (convolve_signal)", "share_of_step": conv_avg / (conv_avg + fft_avg), "ms": conv_avg,
+                                "frac": achieved / HBM_PEAK_GBS, "frac_vs_achievable": achieved / HBM_ACHIEVABLE_GBS,
+                                "frac_pass_adjusted": achieved / HBM_PEAK_GBS, "traffic_ratio": None}
+        first_call = None
+        if world == 1 and not c5 and not args.no_first_call:
+            first_call = first_call_cost(n, m)
         if c5:
             workload = ("c5: %d vectors of %d complex f32 points per GPU (%d in all), batched convolve_signal(%d taps, fused "
                         "overlap-save) -> plain_fft; value = compute only, shards resident" % (nvec, n, nvec * world, m))
@@ -481,6 +647,8 @@ def run_rank(args):
                 "points": n, "taps": m, "vectors_per_gpu": nvec, "input_buffers_rotated": len(xs),
                 "untimed_clock_prewarm_s": args.prewarm, "untimed_prewarm_steps": pre,
                 "cold_ms_per_step_first_20_steps_after_idle": cold_ms,
+                # a fresh process's first plain_fft / convolve_signal against its second and third
+                "first_call_ms": first_call,
                 "steps_with_kernel_events": len(events),
                 "parallelism": "independent vectors per GPU, no data-path collective" + (
                     " -- TEST HOOK BDSP_BENCH_SHARE_GPU: all ranks on GPU 0, control collectives over gloo" if share_gpu else ""),
@@ -496,15 +664,25 @@ def run_rank(args):
                 "algorithmic_bytes_per_launch": algo_bytes,
                 "avg_launch_ms": conv_avg,
                 "event_delta_ms": conv_raw, "event_pair_overhead_ms": event_overhead,
-                # what keeps the kernel from the roofline (measured, DESIGN.md 4.3 / profiles/r03_conv_lab_variants.txt): with packed-f32
-                # arithmetic AND a saturated memory system the socket sits at its 1400 W cap and the core clock at 1.9 of 2.4 GHz;
-                # the kernel's memory traffic alone takes 41 us, its arithmetic + LDS exchanges alone 37 us
-                "limited_by": "socket power cap: 1400 W reached, sclk 1.9 GHz instead of 2.4 (memory skeleton alone 41 us, arithmetic + exchanges alone 37 us)",
+                # clock and socket power of THIS run (host thread polling librocm_smi64 during the untimed pre-warm -- the
+                # same load as the timed steps, tens of samples -- and during the timed region itself); `limited_by` is a
+                # sentence DERIVED from them or null, never a remembered measurement
+                "sclk_mhz": clk["timed"]["sclk_mhz"] if clk["timed"]["sclk_mhz"] is not None else clk["prewarm"]["sclk_mhz"],
+                "socket_power_w": clk["timed"]["socket_power_w"] if clk["timed"]["socket_power_w"] is not None else clk["prewarm"]["socket_power_w"],
+                "power_cap_w": clk["power_cap_w"], "sclk_max_mhz": clk["sclk_max_mhz"],
+                "clock_power_samples": clk,
+                "limited_by": clk["limited_by"],
+                # the same achieved rate against the 6.29 TB/s a float4 copy reaches on this chip
+                "frac_vs_achievable": achieved / HBM_ACHIEVABLE_GBS,
                 "dominant_per_launch": bool(conv_avg >= fft_avg / passes),
                 "share_of_step": conv_avg / (conv_avg + fft_avg),
+                # the kernel with the largest share of the STEP and ITS fraction, so that `frac` above (the fused block
+                # kernel, the dominant kernel per launch) cannot be read as the step's
+                "dominant_by_time": dominant_by_time,
                 # the whole step and the transform, in the same terms (algorithmic bytes: 32 B per sample for the step,
                 # 16 B per sample for the transform whatever its number of passes) -- the block kernel is a third of the step
                 "step_frac": step_algo_gbs / HBM_PEAK_GBS,
+                "step_frac_vs_achievable": step_algo_gbs / HBM_ACHIEVABLE_GBS,
                 "fft_frac_algorithmic": fft_algo_gbs / HBM_PEAK_GBS,
                 "fft_passes": passes,
                 # HBM bytes the transform's passes moved per algorithmic byte (PMC, profiles/) -- 3.0 = three full trips

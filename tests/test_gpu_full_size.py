@@ -292,6 +292,23 @@ def test_bench_py_runs_both_modes_and_prints_the_contract_fields():
         assert k in r, k
     assert 0.02 < r["step_frac"] < r["frac"] and 0.02 < r["fft_frac_algorithmic"] < 1.0 and r["fft_passes"] == 3
     assert r["traffic"] is None or r["traffic"] > 0.9 * r["algorithmic_bytes_per_launch"]
+    # round-4 verdict: clock and power sampled IN the run (or null), never a remembered sentence; the fraction against the
+    # achievable 6.29 TB/s; the kernel that dominates the step BY TIME with its own fraction; the first-call cost
+    for k in ("sclk_mhz", "socket_power_w", "power_cap_w", "limited_by", "clock_power_samples", "frac_vs_achievable", "dominant_by_time"):
+        assert k in r, k
+    assert abs(r["frac_vs_achievable"] - r["frac"] * 8000.0 / 6290.0) < 1e-9
+    dom = r["dominant_by_time"]
+    assert "k_fft_pass" in dom["kernel"] and 0.5 < dom["share_of_step"] < 0.9 and abs(dom["frac"] - r["fft_frac_algorithmic"]) < 1e-12
+    assert dom["frac"] < r["frac"]  # the transform, not the block kernel, is what holds the step back
+    cps = r["clock_power_samples"]
+    if cps["source"] is not None:
+        assert cps["prewarm"]["samples"] >= 3 and 300 < r["sclk_mhz"] < 3000 and 50 < r["socket_power_w"] < 2000
+        assert r["limited_by"] is None or "sampled in this run" in r["limited_by"]
+    else:
+        assert r["sclk_mhz"] is None and r["limited_by"] is None
+    fc = d["config"]["first_call_ms"]
+    assert fc and "error" not in fc, fc
+    assert fc["plain_fft_first_ms"] > fc["plain_fft_third_ms"] > 0 and fc["convolve_signal_first_ms"] >= fc["convolve_signal_third_ms"] > 0
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["fair_allcores_Msamples_s"] > 0
     p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--mode", "c5", "--steps", "4", "--warmup", "1",
                         "--prewarm", "0.02", "--vectors-per-gpu", "16", "--no-cpu-baseline"], env=env, capture_output=True,
