@@ -57,6 +57,10 @@ struct ConvV2Args {
     unsigned groups;         // dispatch groups = workgroups per CU: 3 (f32), 2 (f64)
 };
 
+// (ablations: a value the compiler must treat as defined / as used, without an instruction)
+template <typename C> static __device__ __forceinline__ void abl_def(C& v) { asm volatile("" : "=v"(v.x), "=v"(v.y)); }
+template <typename C> static __device__ __forceinline__ void abl_use(const C& v) { asm volatile("" : : "v"(v.x), "v"(v.y)); }
+
 static __device__ __forceinline__ unsigned xcd_contiguous(unsigned bid, unsigned g)
 {
     // workgroup w runs on XCD w % 8 (observed; only speed depends on it): give every XCD a contiguous run of the
@@ -69,7 +73,10 @@ static __device__ __forceinline__ unsigned xcd_contiguous(unsigned bid, unsigned
 // REAL: the vector holds n REAL samples and the taps are real: the real blocks 2p and 2p+1 travel through the complex
 // transform pair as real and imaginary part (convolution with a real filter is real-linear, so they come out
 // separated).  "Block" then means such a PAIR; x, y and hs are read as arrays of T.
-template <typename T, int R0, bool BATCHED, bool REAL = false>
+// ABL (LAB build only, BDSP_CONV_ABL=<bits>, R0 = 4): timing-only ablations of the interior loop -- 1 no global loads,
+// 2 no global stores, 8 no transform (3 = arithmetic + exchanges alone, 8 = the memory skeleton alone); the output is
+// garbage.  They put a measured bound next to the f64 and real-data kernels' roofline fractions.
+template <typename T, int R0, bool BATCHED, bool REAL = false, int ABL = 0>
 __global__ __launch_bounds__(256, sizeof(T) == 4 ? 3 : 2) void k_overlap_save_v2(ConvV2Args<T> a)
 {
     constexpr int L = L2;
@@ -271,24 +278,44 @@ __global__ __launch_bounds__(256, sizeof(T) == 4 ? 3 : 2) void k_overlap_save_v2
             const T* x0 = reinterpret_cast<const T*>(a.x) + ((size_t)vec * a.n + ((long long)(2 * b) * V + in_off));
             T* y0 = reinterpret_cast<T*>(a.y) + ((size_t)vec * a.n + ((long long)(2 * b) * V - OV));
             C32 v[16];
+            if constexpr (ABL & 1) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) v[r] = C32{x0[ut + 256u * r], x0[V + ut + 256u * r]};
-            transform(v);
+                for (int r = 0; r < 16; ++r) abl_def(v[r]);
+            } else {
 #pragma unroll
-            for (int r = R0; r < 16; ++r) {
-                y0[ut + 256u * r] = v[r].x;
-                y0[V + ut + 256u * r] = v[r].y;
+                for (int r = 0; r < 16; ++r) v[r] = C32{x0[ut + 256u * r], x0[V + ut + 256u * r]};
+            }
+            if constexpr (!(ABL & 8)) transform(v);
+            if constexpr (ABL & 2) {
+#pragma unroll
+                for (int r = R0; r < 16; ++r) abl_use(v[r]);
+            } else {
+#pragma unroll
+                for (int r = R0; r < 16; ++r) {
+                    y0[ut + 256u * r] = v[r].x;
+                    y0[V + ut + 256u * r] = v[r].y;
+                }
             }
             continue;
         }
         const C32* xb = a.x + ((size_t)vec * a.n + ((long long)b * V + in_off));
         C32* yb = a.y + ((size_t)vec * a.n + ((long long)b * V - OV));
         C32 v[16];
+        if constexpr (ABL & 1) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            v[r] = xb[ut + 256u * r];
+            for (int r = 0; r < 16; ++r) abl_def(v[r]);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                v[r] = xb[ut + 256u * r];
+            }
         }
-        transform(v);
+        if constexpr (!(ABL & 8)) transform(v);
+        if constexpr (ABL & 2) {
+#pragma unroll
+            for (int r = R0; r < 16; ++r) abl_use(v[r]);
+            continue;
+        }
 #pragma unroll
         for (int r = R0; r < 16; ++r) {
             // (non-temporal stores measured 7 us slower on the FFT that follows: the result would leave the caches;
@@ -307,6 +334,23 @@ __global__ __launch_bounds__(256, sizeof(T) == 4 ? 3 : 2) void k_overlap_save_v2
 template <typename T, int R0>
 static int launch_v2(const ConvV2Args<T>& a, unsigned grid, size_t lds, hipStream_t s, bool real)
 {
+#ifdef BDSP_LAB
+    if constexpr (R0 == 4) {
+        if (const char* e = lab_env("BDSP_CONV_ABL")) {
+            const int abl = atoi(e);
+#define BDSP_ABL(N)                                                                                                     \
+    if (abl == N) {                                                                                                     \
+        auto kern = real ? k_overlap_save_v2<T, R0, true, true, N> : k_overlap_save_v2<T, R0, true, false, N>;          \
+        if (lds > 64 * 1024) BDSP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, a);                                                     \
+        BDSP_LAUNCH_CHECK();                                                                                            \
+        return BDSP_OK;                                                                                                 \
+    }
+            BDSP_ABL(3) BDSP_ABL(8)
+#undef BDSP_ABL
+        }
+    }
+#endif
     if (real) {
         auto kern = k_overlap_save_v2<T, R0, true, true>; // (the batched instantiation serves single vectors too)
         if (lds > 64 * 1024) BDSP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

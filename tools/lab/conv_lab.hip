@@ -817,6 +817,47 @@ __global__ __launch_bounds__(256, WPC) void k_v2(Args a, unsigned nb_lo, unsigne
 
 
 
+
+// Timing-only stand-in for a Linzer-Feig radix-4 form of dft16_tw: a twiddled radix-4 butterfly
+// needs 11 packed instructions instead of the 12 of two radix-2 layers (t0 = a + w2 c [2], t1 = 2a - t0 [1],
+// B = b + tau1 (i b) [1], u^ = B + W d [2], v^ = 2B - u^ [1], y0/y2 = t0 +- c1 u^ [2], y1/y3 = t1 -+ i c1 v^ [2]) --
+// eight groups per 16-point transform, 88 instead of 96.  This copy of dft16_tw simply DROPS one "2a - s" per group
+// (the result is garbage): what the block kernel would gain from the instruction count alone, before the 15 instead of
+// 8 twiddle registers per stage the real form needs.
+template <int DIR, int PRUNE = 0, typename CT>
+__device__ __forceinline__ void dft16_tw_lfcount(CT* v, const CT* T)
+{
+    auto bf = [&](CT& a, CT& b, CT tw, auto ROT, bool drop) {
+        const CT s = bf_tw_s<DIR, decltype(ROT)::value>(a, b, tw);
+        if (!drop) b = bf_2a_minus_s(a, s);
+        a = s;
+    };
+    using TR = std::integral_constant<bool, true>;
+    using FA = std::integral_constant<bool, false>;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) bf(v[r], v[r + 8], T[0], FA{}, r < 2);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bf(v[r], v[r + 4], T[1], FA{}, r < 1);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bf(v[8 + r], v[8 + r + 4], T[1], TR{}, r < 1);
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        bf(v[r], v[r + 2], T[2], FA{}, r < 1);
+        bf(v[4 + r], v[4 + r + 2], T[2], TR{}, r < 1);
+        bf(v[8 + r], v[8 + r + 2], T[3], FA{}, false);
+        bf(v[12 + r], v[12 + r + 2], T[3], TR{}, false);
+    }
+    // last layer as in dft16_tw (pruning included), two of its eight butterflies without their second output
+    bf_tw<DIR, false, (0 >= PRUNE)>(v[0], v[1], T[4]);
+    bf_tw<DIR, true, (4 >= PRUNE)>(v[2], v[3], T[4]);
+    bf_tw<DIR, false, (2 >= PRUNE)>(v[4], v[5], T[6]);
+    bf_tw<DIR, true, (6 >= PRUNE)>(v[6], v[7], T[6]);
+    bf_tw<DIR, false, (1 >= PRUNE)>(v[8], v[9], T[5]);
+    bf_tw<DIR, true, (5 >= PRUNE)>(v[10], v[11], T[5]);
+    bf(v[12], v[13], T[7], FA{}, true);
+    bf(v[14], v[15], T[7], TR{}, true);
+}
+
 // ------------------------------------------------------------------------------------------- v3 (round 3)
 // The round-3 block kernel on its own: L3 exchange layouts, stages 2 and 3 as FMA-form twiddled 16-point transforms
 // (dft16_tw), the inverse's last stage pruned by the R0 rows the block discards, WPC dispatch groups with the shares
@@ -869,7 +910,8 @@ __global__ __launch_bounds__(256, WPC) void k_v3(Args a, unsigned nb_lo, unsigne
 #pragma unroll
                 for (int j = 0; j < 8; ++j) tl[j] = tab2[16 * j];
                 dft16_tw<DIR>(&v[0], tl);
-            } else dft16_tw<DIR>(&v[0], tw2f);
+            } else if constexpr (ABL & 256) dft16_tw_lfcount<DIR>(&v[0], tw2f);
+            else dft16_tw<DIR>(&v[0], tw2f);
         }
         bar();
         if constexpr (!(ABL & 4)) F::scatter_b3(v, t, lds);
@@ -881,7 +923,8 @@ __global__ __launch_bounds__(256, WPC) void k_v3(Args a, unsigned nb_lo, unsigne
 #pragma unroll
                 for (int j = 0; j < 8; ++j) tl[j] = tab3[256 * j];
                 dft16_tw<DIR, (DIR > 0 && R0 <= 8) ? R0 : 0>(&v[0], tl);
-            } else dft16_tw<DIR, (DIR > 0 && R0 <= 8) ? R0 : 0>(&v[0], tw3f);
+            } else if constexpr (ABL & 256) dft16_tw_lfcount<DIR, (DIR > 0 && R0 <= 8) ? R0 : 0>(&v[0], tw3f);
+            else dft16_tw<DIR, (DIR > 0 && R0 <= 8) ? R0 : 0>(&v[0], tw3f);
         }
     };
     auto transform = [&](C (&v)[16]) {
@@ -1759,6 +1802,8 @@ int main(int argc, char** argv)
         {"k3 abl noload", (const void*)k_v3<4, 1, 3, 9, 8>, true, 3, lds_l3, 4},
         {"k3 abl nostore", (const void*)k_v3<4, 2, 3, 9, 8>, true, 3, lds_l3, 4},
         {"k3 abl nomem", (const void*)k_v3<4, 3, 3, 9, 8>, true, 3, lds_l3, 4},
+        {"k3 abl lfcount", (const void*)k_v3<4, 256, 3, 9, 8>, true, 3, lds_l3, 4},
+        {"k3 abl lfcount nomem", (const void*)k_v3<4, 256 + 3, 3, 9, 8>, true, 3, lds_l3, 4},
         {"k3 abl nolds", (const void*)k_v3<4, 4, 3, 9, 8>, true, 3, lds_l3, 4},
         {"k3 abl noldsbar", (const void*)k_v3<4, 20, 3, 9, 8>, true, 3, lds_l3, 4},
         {"k3 abl novalu", (const void*)k_v3<4, 8, 3, 9, 8>, true, 3, lds_l3, 4},
