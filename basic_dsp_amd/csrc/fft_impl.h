@@ -655,6 +655,135 @@ __global__ __launch_bounds__(W * (RP / 16), (pass_min_waves<T, RP, W, GEN>())) v
     }
 }
 
+
+// ------------------------------------------------------------------------------ one 2^20-point vector (round 4, LAB only)
+// *Measured and NOT adopted* (profiles/r04_c2_tile_geometry.txt): correct for every output option (rel-L2 2.1e-7) and
+// 19.15 us against 17.2 us for the 1024 x 4 tiles -- the chain of a tile is memory latency, barriers and the launch
+// boundary, not instruction issue, so twice the waves at half the instructions each buy nothing and the doubled L2 -> CU
+// traffic costs.  Kept in the LAB build (BDSP_FFT_H512=1) so that the measurement can be repeated.
+// A single 1M-point f32 transform (BASELINE config C2) is two dependent launches of 256 tiles of 1024 x 4 points: ONE wave
+// per SIMD, nothing to hide the load -> butterflies -> store chain behind (9.1 + 8.0 us, of which ~1.7 us each are the
+// launch boundary; 17 MB in 9 us = 1.8 TB/s).  Here every 1024-point column transform is split in two by one
+// decimation-in-frequency step done in registers on load,
+//     X[2k]   = FFT_512(a + b)[k]                 a[n] = x[n], b[n] = x[n + 512]
+//     X[2k+1] = FFT_512((a - b) w_1024^n)[k]
+// and the halves go to DIFFERENT workgroups: 512 workgroups of 256 threads x 8 points (512 = 8 x 8 x 8: two LDS
+// exchanges as before), two per CU = two waves per SIMD, about half the instructions per wave; both workgroups of a tile
+// load all 1024 rows (the second read is an L2 hit).  Pass 1 writes half h of column j to mid[j 1024 + 512 h + k] (whole
+// contiguous runs; the parity interleave would be 8-byte pieces), so pass 2 finds output column 2k + h of pass 1 at
+// column position 512 h + k: its 4-wide tile takes positions {2t, 2t+1, 512 + 2t, 512 + 2t + 1} = the four ADJACENT true
+// columns 4t + {0, 2, 1, 3}.  Pass 2's outputs are rows 2 k' + h', 8 KB apart anyway.
+#ifdef BDSP_LAB
+template <int DIR, bool FIRST>
+__global__ __launch_bounds__(256) void k_fft_half512(FftIo<float> io, const cpx<float>* __restrict__ src, cpx<float>* __restrict__ dst,
+                                                      const cpx<float>* __restrict__ wtab /* exp(-2 pi i m / 1024) */)
+{
+    using T = float;
+    using C_ = cpx<T>;
+    constexpr int RP = 1024, H = 512, W = 4, NT = 64;
+    constexpr int CS = col_stride(H, W);
+    constexpr size_t N = (size_t)RP * RP;
+    using F = WgFft<T, H, NT>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    C_* lds = reinterpret_cast<C_*>(smem_raw);
+    C_* ltw = lds + (size_t)W * CS; // the 1024-entry table
+    const int tid = threadIdx.x;
+    for (int i = tid; i < RP; i += 256) ltw[i] = wtab[i];
+    const unsigned tiles = RP / W; // 256
+    unsigned tile = blockIdx.x % tiles;
+    const unsigned h = blockIdx.x / tiles; // (blocks b and b + 256 sit on the same XCD: 256 % 8 == 0)
+    tile = (tile & 7) * (tiles >> 3) + (tile >> 3);
+    auto tw = [&](int m) { return ltw[2 * m]; }; // exp(-2 pi i m / 512)
+    const int c = tid % W, ti = tid / W;
+    C_ a[8], b[8];
+    unsigned kt = 0; // pass 2: the true column index of this lane's column
+    if (FIRST) {
+        const C_* in = src + (size_t)W * tile + c;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            a[r] = in[(size_t)(ti + 64 * r) * RP];
+            b[r] = in[(size_t)(ti + 64 * r + H) * RP];
+        }
+    } else {
+        const unsigned hh = c >> 1, kk = c & 1, pos = hh * H + 2 * tile + kk;
+        kt = 2 * (2 * tile + kk) + hh;
+        const C_* in = src + pos;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            a[r] = in[(size_t)(ti + 64 * r) * RP];
+            b[r] = in[(size_t)(ti + 64 * r + H) * RP];
+        }
+    }
+    __syncthreads(); // the table is in LDS
+    C_ v[8];
+    if (FIRST) {
+        if (h == 0) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) v[r] = cadd(a[r], b[r]);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) v[r] = twmul<DIR>(csub(a[r], b[r]), ltw[ti + 64 * r]);
+        }
+    } else {
+        // inter-pass twiddle w_N^(n kt) on row n = ti + 64 r (+ 512 for b): a_r P_r and b_r P_r Q with P_r = bs d^r,
+        // bs = w_N^(ti kt), d = w_N^(64 kt), Q = w_N^(512 kt); the odd half's w_1024^n = w_N^(1024 n) joins bs and d
+        const unsigned e1 = h ? 1024u : 0u;
+        const C_ bs = unit_root<T>(((size_t)ti * (kt + e1)) & (N - 1), N);
+        const C_ d1 = unit_root<T>(((size_t)64 * (kt + e1)) & (N - 1), N);
+        const C_ q = unit_root<T>(((size_t)512 * kt) & (N - 1), N);
+        const C_ d2 = cmul(d1, d1), d4 = cmul(d2, d2);
+        C_ pw[8];
+        pw[0] = bs; pw[1] = cmul(bs, d1); pw[2] = cmul(bs, d2); pw[3] = cmul(pw[1], d2);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pw[4 + r] = cmul(pw[r], d4);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const C_ tb = twmul<DIR>(b[r], q);
+            v[r] = twmul<DIR>(h ? csub(a[r], tb) : cadd(a[r], tb), pw[r]);
+        }
+    }
+    // ---- 512-point transform of every column: 8 x 8 x 8
+    F::template compute<8, 1, DIR>(v, ti, tw);
+    const int c2 = FIRST ? tid / NT : c, t2 = FIRST ? tid % NT : ti; // pass 1: lanes along rows for the contiguous store
+    C_* l1 = lds + (size_t)c * CS;
+    C_* l2 = lds + (size_t)c2 * CS;
+    F::template scatter<8, 1>(v, ti, l1);
+    __syncthreads();
+    F::template gather<8>(v, t2, l2);
+    F::template compute<8, 8, DIR>(v, t2, tw);
+    __syncthreads();
+    F::template scatter<8, 8>(v, t2, l2);
+    __syncthreads();
+    F::template gather<8>(v, t2, l2);
+    F::template compute<8, 64, DIR>(v, t2, tw);
+    // v[r] = Y_h[t2 + 64 r]
+    if (FIRST) {
+        C_* out = dst + ((size_t)W * tile + c2) * RP + (size_t)h * H + t2;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) out[64 * r] = v[r];
+    } else {
+        // true output row 2 k' + h; fft_shift = the row index's top bit flipped
+        const unsigned sx = (io.flags & BDSP_FFT_SHIFT_OUT) ? (unsigned)H : 0u;
+        if (io.flags & (BDSP_FFT_MAGNITUDE | FFT_OUT_REAL)) {
+            T* outr = reinterpret_cast<T*>(io.out) + kt;
+            const bool mag = (io.flags & BDSP_FFT_MAGNITUDE) != 0;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const unsigned row = (2u * (t2 + 64 * r) + h) ^ sx;
+                outr[(size_t)row * RP] = mag ? dev_hypot<T>(v[r].x, v[r].y) : v[r].x;
+            }
+        } else {
+            C_* out = dst + kt;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const unsigned row = (2u * (t2 + 64 * r) + h) ^ sx;
+                out[(size_t)row * RP] = v[r];
+            }
+        }
+    }
+}
+#endif // BDSP_LAB
+
 // ------------------------------------------------------------------------------ launchers
 // plain complex in/out with the natural batch stride and no fused option?  The input side and the
 // output side are judged separately so that e.g. fft->magnitude pays the staged path only in its
@@ -807,6 +936,30 @@ static int launch_pass(const FftIo<T>& io, const cpx<T>* src, cpx<T>* dst, size_
     return BDSP_OK;
 }
 
+// the two launches of k_fft_half512 for ONE plain 2^20-point f32 vector (io.in -> scratch_a -> io.out)
+#if defined(BDSP_FFT_F32_TU) && defined(BDSP_LAB)
+static int launch_half512(const FftIo<float>& io, cpx<float>* mid, bool inverse, hipStream_t s)
+{
+    const cpx<float>* wtab;
+    BDSP_TRY(twiddle_table<float>(1024, &wtab));
+    constexpr size_t lds = ((size_t)4 * col_stride(512, 4) + 1024) * sizeof(cpx<float>);
+    const cpx<float>* in = reinterpret_cast<const cpx<float>*>(io.in);
+    cpx<float>* out = reinterpret_cast<cpx<float>*>(io.out);
+    if (inverse) {
+        hipLaunchKernelGGL((k_fft_half512<1, true>), dim3(512), dim3(256), lds, s, io, in, mid, wtab);
+        hipLaunchKernelGGL((k_fft_half512<1, false>), dim3(512), dim3(256), lds, s, io, mid, out, wtab);
+    } else {
+        hipLaunchKernelGGL((k_fft_half512<-1, true>), dim3(512), dim3(256), lds, s, io, in, mid, wtab);
+        hipLaunchKernelGGL((k_fft_half512<-1, false>), dim3(512), dim3(256), lds, s, io, mid, out, wtab);
+    }
+    BDSP_LAUNCH_CHECK();
+    return BDSP_OK;
+}
+#else
+template <typename T>
+static int launch_half512(const FftIo<T>&, cpx<T>*, bool, hipStream_t) { return BDSP_ERR_UNSUPPORTED; } // (LAB build, f32 TU only)
+#endif
+
 // (super-radix, tile width) pairs that are instantiated.  Default tile: W = 4096/RP columns
 // (256 threads); the wider variants trade LDS for longer contiguous global segments.
 template <typename T>
@@ -822,7 +975,7 @@ static int launch_pass_rp(int rp, int w, const FftIo<T>& io, const cpx<T>* src, 
     BDSP_CASE(1024, 8) BDSP_CASE(2048, 4)
 #ifdef BDSP_LAB
     // ... and the ones only a BDSP_FFT_PLAN experiment reaches (the f64 4096 x 4 tiles spill 12-76 bytes per lane)
-    BDSP_CASE(2048, 2) BDSP_CASE(4096, 2) BDSP_CASE(4096, 4)
+    BDSP_CASE(2048, 2) BDSP_CASE(4096, 2) BDSP_CASE(4096, 4) BDSP_CASE(1024, 2)
 #endif
 #undef BDSP_CASE
     set_last_error("unsupported super-radix / tile width");
@@ -912,6 +1065,15 @@ int fft_pow2(const FftIo<T>& io, T* scratch_a, T* scratch_b, size_t batch, bool 
         static const bool no_wg4 = lab_flag("BDSP_FFT_NO_WG4");
         if (!no_wg4 && n == 8192 && !io_is_generic(io) && io.window_id < 0 &&
             !(io.flags & (BDSP_FFT_MAGNITUDE | FFT_OUT_REAL | FFT_IN_REAL))) return launch_wg4<T, 8192>(io, batch, inverse, s);
+    }
+    if constexpr (sizeof(T) == 4) {
+        // ONE plain 2^20-point vector (config C2) through the half-column plan: LAB experiment only (*measured* slower,
+        // round 4)
+        static const bool h512 = lab_flag("BDSP_FFT_H512");
+        if (h512 && n == (size_t(1) << 20) && batch == 1 && scratch_a && !io_is_generic(io) && io.window_id < 0 && io.in_scale == (T)1 &&
+            !(io.flags & (FFT_IN_REAL | BDSP_FFT_SHIFT_IN)) && io.in_valid == 0 &&
+            reinterpret_cast<const void*>(scratch_a) != io.in && reinterpret_cast<const void*>(scratch_a) != io.out)
+            return launch_half512(io, reinterpret_cast<cpx<T>*>(scratch_a), inverse, s);
     }
     int rp[3], w[3];
     int passes = plan_passes(n, batch, sizeof(T), rp, w);

@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""GPU box: the half-column plan for ONE 2^20-point f32 vector (k_fft_half512) against numpy in f64 for every output
+option it serves, and its time against the 1024 x 4 tiles (LAB library: BDSP_FFT_H512 unset).
+usage: BDSP_HIP_LIBRARY=basic_dsp_amd/lib/libbasic_dsp_hip_lab.so python tools/c2_half512_check.py"""
+import ctypes as C, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+import basic_dsp_amd as bd
+from basic_dsp_amd._lib import FFT_SHIFT_OUT, FFT_MAGNITUDE
+lib = bd.lib
+dev = torch.device("cuda", 0)
+sp = bd._lib.torch_stream_arg()
+flag = C.c_int(0)
+n = 1 << 20
+rng = np.random.default_rng(3)
+x = (rng.random(2 * n, dtype=np.float32) * 20 - 10)
+xc = x[0::2].astype(np.float64) + 1j * x[1::2].astype(np.float64)
+ref = np.fft.fft(xc)
+refi = np.fft.ifft(xc) * n
+
+
+def run(flags):
+    d = torch.from_numpy(x).to(dev)
+    s = torch.empty(2 * n, device=dev, dtype=torch.float32)
+    bd._lib.check(lib.bdsp_hip_dev_fft(0, d.data_ptr(), s.data_ptr(), n, 1, flags, 1.0, -1, 0.0, C.byref(flag), sp))
+    torch.cuda.synchronize()
+    return (s if flag.value else d).cpu().numpy()
+
+
+def rel(a, b): return float(np.linalg.norm(a - b) / np.linalg.norm(b))
+
+
+o = run(0); print("plain_fft        rel-L2 %.3e" % rel(o[0::2] + 1j * o[1::2], ref))
+o = run(1); print("inverse          rel-L2 %.3e" % rel(o[0::2] + 1j * o[1::2], refi))
+o = run(FFT_SHIFT_OUT); print("fft (shift)      rel-L2 %.3e" % rel(o[0::2] + 1j * o[1::2], np.fft.fftshift(ref)))
+o = run(FFT_MAGNITUDE); print("fft->magnitude   rel-L2 %.3e" % rel(o[:n], np.abs(ref)))
+o = run(FFT_MAGNITUDE | FFT_SHIFT_OUT); print("fft shift->magn. rel-L2 %.3e" % rel(o[:n], np.abs(np.fft.fftshift(ref))))
+
+
+def timeit(fn, iters=200):
+    import time
+    t0 = time.perf_counter(); k = 0
+    while time.perf_counter() - t0 < 0.2:
+        for _ in range(10): fn(k); k += 1
+        torch.cuda.synchronize()
+    e0, e1 = lib.bdsp_hip_event_create(), lib.bdsp_hip_event_create()
+    lib.bdsp_hip_event_record(e0, sp)
+    for i in range(iters): fn(i)
+    lib.bdsp_hip_event_record(e1, sp)
+    torch.cuda.synchronize()
+    ms = C.c_float(0); lib.bdsp_hip_event_elapsed_ms(e0, e1, C.byref(ms))
+    return ms.value / iters * 1e3
+
+
+xs = [torch.rand(2 * n, device=dev, dtype=torch.float32) * 20 - 10 for _ in range(3)]
+sc = torch.empty(2 * n, device=dev, dtype=torch.float32)
+us = timeit(lambda i: lib.bdsp_hip_dev_fft(0, xs[i % 3].data_ptr(), sc.data_ptr(), n, 1, FFT_MAGNITUDE, 1.0, -1, 0.0, C.byref(flag), sp))
+print("C2 plain_fft->magnitude: %.2f us   (%s%s)" % (us, os.path.basename(bd.LIB_PATH), ", BDSP_FFT_H512" if os.environ.get("BDSP_FFT_H512") else ""))
+us = timeit(lambda i: lib.bdsp_hip_dev_fft(0, xs[i % 3].data_ptr(), sc.data_ptr(), n, 1, 0, 1.0, -1, 0.0, C.byref(flag), sp))
+print("   plain_fft           : %.2f us" % us)
