@@ -228,11 +228,11 @@ def cpu_baseline(points, taps, sample_points, vectors=1):
     }
 
 
-PROFILE_TAG = "r03"  # profiles/<tag>_* are the files tools/profile_r03.sh writes
+PROFILE_TAG = "r04"  # profiles/<tag>_* are the files tools/profile_round.sh writes (TAG=r04)
 
 
 def kernel_source_sha16():
-    """Hash of the kernel sources the profiles were collected on (tools/profile_r03.sh stores it in
+    """Hash of the kernel sources the profiles were collected on (tools/profile_round.sh stores it in
     profiles/<tag>_profile_meta.json): figures from a profile of OTHER sources are not quoted."""
     import glob
     import hashlib
@@ -245,7 +245,7 @@ def kernel_source_sha16():
 
 
 def profile_figures():
-    """What the committed rocprofv3 runs of THIS command say (tools/profile_r03.sh): HBM bytes per launch from the PMC
+    """What the committed rocprofv3 runs of THIS command say (tools/profile_round.sh): HBM bytes per launch from the PMC
     passes (FETCH_SIZE and WRITE_SIZE in separate runs, gfx950 read-size correction applied) and the kernel-trace
     average durations.  The live run cannot collect counters itself.  Everything is None when the profile is missing
     or was collected on other kernel sources than the ones in this tree."""

@@ -13,7 +13,7 @@ sp = bd._lib.torch_stream_arg()
 flag = C.c_int(0)
 PEAK = 8000.0
 
-QUICK = "--quick" in sys.argv  # a few launches per config only: for the rocprofv3 --pmc passes (tools/profile_r03.sh)
+QUICK = "--quick" in sys.argv  # a few launches per config only: for the rocprofv3 --pmc passes (tools/profile_round.sh)
 
 def timeit(fn, iters=20):
     # untimed pre-warm: the clock needs tens of milliseconds of load to settle (see bench.py)
@@ -92,10 +92,12 @@ n = 1 << 22
 xs = rnd(2 * n, torch.float64); sc = torch.empty(2 * n, device=dev, dtype=torch.float64)
 us = timeit(lambda i: lib.bdsp_hip_dev_fft(1, xs[i % 3].data_ptr(), sc.data_ptr(), n, 1, FFT_SHIFT_OUT, 1.0, 4, 0.5, C.byref(flag), sp))
 report("C4a complex f64 4M: windowed_fft(Hann) fused window+fft+shift", us, n, 32, "points")
-out = torch.empty(8 * n, device=dev, dtype=torch.float64)
-us = timeit(lambda i: lib.bdsp_hip_dev_interpolatef(1, xs[i % 3].data_ptr(), out.data_ptr(), 2 * n, 1, 1, 0.35, 4.0, 0.0, 12, 1.0, sp), 10)
-report("C4b complex f64 4M: interpolatef(RC 0.35, x4, conv_len 12)", us, n, 80, "input_points")
-del xs, sc, out
+# ONE protocol for C4b (round 4): three rotating inputs (64 MB each) AND three rotating outputs (256 MB each), like the
+# headline's rotating inputs -- neither side of the operation finds its data in the 256 MB Infinity Cache; 30 calls
+outs = [torch.empty(8 * n, device=dev, dtype=torch.float64) for _ in range(3)]
+us = timeit(lambda i: lib.bdsp_hip_dev_interpolatef(1, xs[i % 3].data_ptr(), outs[i % 3].data_ptr(), 2 * n, 1, 1, 0.35, 4.0, 0.0, 12, 1.0, sp), 30)
+report("C4b complex f64 4M: interpolatef(RC 0.35, x4, conv_len 12), 3 rotating inputs and outputs", us, n, 80, "input_points")
+del xs, sc, outs
 
 n, b = 1 << 20, 64
 xs = rnd(2 * n * b, torch.float32, 2); y = torch.empty(2 * n * b, device=dev, dtype=torch.float32)
