@@ -129,3 +129,20 @@ def test_cpu_baseline_fields_are_numeric():
     # --mode c5: whole vectors, one after the other
     b = bench.cpu_baseline(1 << 13, 64, 1 << 15, vectors=64)
     assert "4 whole vectors of 8192 points" in b["sample"] and b["value"] > 0
+
+
+def test_clock_power_sampler_degrades_to_nulls_without_a_device():
+    """bench.py's clock / power figures come from a host thread polling librocm_smi64 during the run; without the library,
+    a device or permission every figure is None (the line then says nothing about clocks) -- never an exception and never
+    a remembered number."""
+    import time
+    sys.path.insert(0, ROOT)
+    import bench
+    s = bench.GpuSampler().start()
+    time.sleep(0.02)
+    s.stop()
+    w = s.window(0.0, 1e18)
+    if s.source is None:
+        assert w == {"samples": 0, "sclk_mhz": None, "socket_power_w": None} and s.cap_w is None
+    else:  # (a box with a GPU: real samples)
+        assert w["samples"] >= 1
