@@ -442,12 +442,20 @@ __device__ __forceinline__ cpx<double> unit_root<double>(size_t e, size_t n)
 // on a later one -- the instantiation the headline transforms take.  The run-time option checks around the loads and
 // stores are then compiled out: the branches themselves are free, but hipcc's code around their merge points is not
 // (the same lesson as in conv_v2.hip).
-template <typename T, int RP, int W, int DIR, bool ROWMAP, bool GEN, bool SIMPLE = false>
+// TL (round 4): the TILED intermediate of a two-pass plan.  The first pass's output layout is nobody's business but the
+// second pass's, which reads, per tile, W2 adjacent columns of it: W2 x 8 (16) bytes per row -- 32-64-byte runs wherever
+// the columns are long (1024 / 2048 points).  With mid'[k1 / W2][j][k1 % W2] (k1 = the first pass's output index = the
+// second pass's column, j = the first pass's column = the second pass's row) a second-pass tile is ONE contiguous
+// RP2 x W2 block, and the first pass still stores whole lines (W1 x W2 adjacent values per k1 group, lanes along the
+// columns).  TL = 1: first pass, tiled store (aux = log2 W2); TL = 2: last pass, tiled load.  The natural-order input of
+// the first pass and output of the last keep their W-wide runs.
+template <typename T, int RP, int W, int DIR, bool ROWMAP, bool GEN, bool SIMPLE = false, int TL = 0>
 __global__ __launch_bounds__(W * (RP / 16), (pass_min_waves<T, RP, W, GEN>())) void k_fft_pass(FftIo<T> io, const cpx<T>* src, // (src may equal dst: the in-place last pass)
                                                    cpx<T>* dst,
                                                    const cpx<T>* __restrict__ wtab, size_t n,
-                                                   size_t nsg, size_t tiles_per_vec, int last)
+                                                   size_t nsg, size_t tiles_per_vec, int last, int aux)
 {
+    static_assert(TL == 0 || (TL == 1 && ROWMAP) || (TL == 2 && !ROWMAP), "tiled store: first pass; tiled load: a later pass");
     constexpr int NT = RP / 16;
     constexpr int CS = col_stride(RP, W);
     using F = WgFft<T, RP, NT>;
@@ -496,6 +504,10 @@ __global__ __launch_bounds__(W * (RP / 16), (pass_min_waves<T, RP, W, GEN>())) v
             const T* inr = reinterpret_cast<const T*>(io.in) + vec * io.in_stride + j;
 #pragma unroll
             for (int r = 0; r < 16; ++r) v[r] = cpx<T>{inr[(size_t)(ti + (r ^ rx) * NT) * stride_in], (T)0};
+        } else if constexpr (TL == 2) {
+            const cpx<T>* in_t = src + vec * n + j0 * RP + c; // the tile's own RP x W block
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = in_t[(size_t)(ti + r * NT) * W];
         } else {
 #pragma unroll
             for (int r = 0; r < 16; ++r) v[r] = in[(size_t)(ti + (r ^ rx) * NT) * stride_in];
@@ -561,8 +573,8 @@ __global__ __launch_bounds__(W * (RP / 16), (pass_min_waves<T, RP, W, GEN>())) v
     }
 
     // ---- RP-point sub-FFT of every column
-    const int c2 = ROWMAP ? tid / NT : tid % W;
-    const int t2 = ROWMAP ? tid % NT : tid / W;
+    const int c2 = (ROWMAP && TL != 1) ? tid / NT : tid % W; // (a tiled store wants its lanes along the columns)
+    const int t2 = (ROWMAP && TL != 1) ? tid % NT : tid / W;
     LE* l1 = lds + (size_t)c * CS;
     LE* l2 = lds + (size_t)c2 * CS;
     if constexpr (SPLIT) {
@@ -602,6 +614,19 @@ __global__ __launch_bounds__(W * (RP / 16), (pass_min_waves<T, RP, W, GEN>())) v
     constexpr int RL = P::R3 > 1 ? P::R3 : P::R2;
     constexpr int NSL = RP / RL;
     const size_t jj = j0 + c2;
+    if constexpr (TL == 1) {
+        const int lw2 = aux;
+        const size_t ncols = n / RP;
+        cpx<T>* out = dst + vec * n;
+#pragma unroll
+        for (int b = 0; b < 16 / RL; ++b)
+#pragma unroll
+            for (int r = 0; r < RL; ++r) {
+                const unsigned k1 = (unsigned)F::template out_index<RL, NSL>(t2, b, r);
+                out[((((size_t)(k1 >> lw2)) * ncols + jj) << lw2) + (k1 & ((1u << lw2) - 1u))] = v[b * RL + r];
+            }
+        return;
+    }
     const size_t base = (jj / nsg) * nsg * RP + (jj % nsg);
     bool staged = false;
     if constexpr (GEN && !ROWMAP) {
@@ -900,9 +925,21 @@ static int launch_tiny(const FftIo<T>& io, size_t batch, bool inverse, hipStream
     return BDSP_OK;
 }
 
+// column lengths whose pass kernels also exist with the tiled intermediate (TL): the long ones, whose tiles are narrow --
+// in the LAB build only (*measured*, round 4: not faster, see fft_pow2)
+template <int RP>
+constexpr bool pass_tiled_pair()
+{
+#ifdef BDSP_LAB
+    return RP >= 512;
+#else
+    return false;
+#endif
+}
+
 template <typename T, int RP, int W>
 static int launch_pass(const FftIo<T>& io, const cpx<T>* src, cpx<T>* dst, size_t n, size_t nsg,
-                       size_t batch, bool inverse, bool first, bool last, hipStream_t s)
+                       size_t batch, bool inverse, bool first, bool last, hipStream_t s, int tl = 0, int aux = 0)
 {
     const cpx<T>* wtab;
     BDSP_TRY(twiddle_table<T>(RP, &wtab));
@@ -916,21 +953,31 @@ static int launch_pass(const FftIo<T>& io, const cpx<T>* src, cpx<T>* dst, size_
     // plain first / last pass?  (then no option is looked at inside the kernel)
     const bool simple = !gen && (rowmap ? ((io.flags & (FFT_IN_REAL | BDSP_FFT_SHIFT_IN)) == 0 && io.in_scale == (T)1 && io.window_id < 0)
                                         : (!last || (io.flags & (BDSP_FFT_SHIFT_OUT | BDSP_FFT_MAGNITUDE | FFT_OUT_REAL)) == 0));
-#define BDSP_PASS(DIRV, RM, GENV, SV)                                                              \
+    // (tiled instantiations exist for the long columns only: pass_tiled_pair)
+    if (tl != 0 && (!pass_tiled_pair<RP>() || (tl == 1) != rowmap)) { set_last_error("tiled intermediate: unsupported pass"); return BDSP_ERR_UNSUPPORTED; }
+#define BDSP_PASS(DIRV, RM, GENV, SV, TLV)                                                         \
     do {                                                                                           \
         constexpr size_t lds = pass_tile_lds_bytes<T, RP, W, GENV>() +                             \
                                (pass_lds_twiddles<T, RP, W, GENV>() ? (size_t)RP * sizeof(cpx<T>) : 0); \
-        BDSP_TRY(set_lds(k_fft_pass<T, RP, W, DIRV, RM, GENV, SV>, lds));                          \
-        hipLaunchKernelGGL((k_fft_pass<T, RP, W, DIRV, RM, GENV, SV>), grid, dim3(THREADS), lds, s, \
-                           io, src, dst, wtab, n, nsg, tiles, (int)last);                          \
+        BDSP_TRY(set_lds(k_fft_pass<T, RP, W, DIRV, RM, GENV, SV, TLV>, lds));                     \
+        hipLaunchKernelGGL((k_fft_pass<T, RP, W, DIRV, RM, GENV, SV, TLV>), grid, dim3(THREADS), lds, s, \
+                           io, src, dst, wtab, n, nsg, tiles, (int)last, aux);                     \
+    } while (0)
+#define BDSP_PASS_V(DIRV, RM, TLV)                                                                 \
+    do {                                                                                           \
+        if (gen) BDSP_PASS(DIRV, RM, true, false, TLV); else if (simple) BDSP_PASS(DIRV, RM, false, true, TLV); else BDSP_PASS(DIRV, RM, false, false, TLV); \
     } while (0)
 #define BDSP_PASS_D(DIRV)                                                                          \
     do {                                                                                           \
-        if (rowmap) { if (gen) BDSP_PASS(DIRV, true, true, false); else if (simple) BDSP_PASS(DIRV, true, false, true); else BDSP_PASS(DIRV, true, false, false); }   \
-        else { if (gen) BDSP_PASS(DIRV, false, true, false); else if (simple) BDSP_PASS(DIRV, false, false, true); else BDSP_PASS(DIRV, false, false, false); }        \
+        if constexpr (pass_tiled_pair<RP>()) {                                                     \
+            if (tl == 1) { BDSP_PASS_V(DIRV, true, 1); break; }                                    \
+            if (tl == 2) { BDSP_PASS_V(DIRV, false, 2); break; }                                   \
+        }                                                                                          \
+        if (rowmap) BDSP_PASS_V(DIRV, true, 0); else BDSP_PASS_V(DIRV, false, 0);                  \
     } while (0)
     if (inverse) BDSP_PASS_D(1); else BDSP_PASS_D(-1);
 #undef BDSP_PASS_D
+#undef BDSP_PASS_V
 #undef BDSP_PASS
     BDSP_LAUNCH_CHECK();
     return BDSP_OK;
@@ -965,11 +1012,11 @@ static int launch_half512(const FftIo<T>&, cpx<T>*, bool, hipStream_t) { return 
 template <typename T>
 static int launch_pass_rp(int rp, int w, const FftIo<T>& io, const cpx<T>* src, cpx<T>* dst,
                           size_t n, size_t nsg, size_t batch, bool inverse, bool first, bool last,
-                          hipStream_t s)
+                          hipStream_t s, int tl = 0, int aux = 0)
 {
 #define BDSP_CASE(RPV, WV)                                                                         \
     if (rp == RPV && w == WV)                                                                      \
-        return launch_pass<T, RPV, WV>(io, src, dst, n, nsg, batch, inverse, first, last, s);
+        return launch_pass<T, RPV, WV>(io, src, dst, n, nsg, batch, inverse, first, last, s, tl, aux);
     // every pair plan_passes can choose by itself ...
     BDSP_CASE(64, 64) BDSP_CASE(128, 32) BDSP_CASE(256, 16) BDSP_CASE(512, 8) BDSP_CASE(1024, 4)
     BDSP_CASE(1024, 8) BDSP_CASE(2048, 4)
@@ -1085,10 +1132,20 @@ int fft_pow2(const FftIo<T>& io, T* scratch_a, T* scratch_b, size_t batch, bool 
     cpx<T>* sa = reinterpret_cast<cpx<T>*>(scratch_a);
     cpx<T>* sb = reinterpret_cast<cpx<T>*>(scratch_b);
     size_t nsg = 1;
-    BDSP_TRY(launch_pass_rp<T>(rp[0], w[0], io, nullptr, sa, n, nsg, batch, inverse, true, false, s));
+    // two passes with narrow second-pass tiles: the intermediate through scratch_a in the TILED layout (k_fft_pass, TL) --
+    // LAB experiment (BDSP_FFT_TILED=1).  *Measured*, round 4 (tools/ab_tiled.sh, profiles/r04_fft_tiled_intermediate.txt):
+    // the second pass's reads become one contiguous block per tile, the first pass's stores 128-512-byte pieces instead of
+    // whole 4-8 KB columns, and nothing gets faster -- C2 17.1 -> 17.5 us, C2 x 64 384 -> 409, C4a 53.2 -> 54.0, C5 equal:
+    // the narrow READS were never the cost (32-byte sectors out of the Infinity Cache), and the scattered stores are one.
+    static const bool want_tiled = lab_flag("BDSP_FFT_TILED");
+    const bool tiled = passes == 2 && want_tiled && rp[0] >= 512 && rp[1] >= 512 && (size_t)w[1] * sizeof(cpx<T>) < 128 &&
+                       reinterpret_cast<const void*>(scratch_a) != io.out;
+    int lw2 = 0;
+    while ((1 << lw2) < w[1]) ++lw2;
+    BDSP_TRY(launch_pass_rp<T>(rp[0], w[0], io, nullptr, sa, n, nsg, batch, inverse, true, false, s, tiled ? 1 : 0, lw2));
     nsg *= rp[0];
     if (passes == 2) {
-        BDSP_TRY(launch_pass_rp<T>(rp[1], w[1], io, sa, nullptr, n, nsg, batch, inverse, false, true, s));
+        BDSP_TRY(launch_pass_rp<T>(rp[1], w[1], io, sa, nullptr, n, nsg, batch, inverse, false, true, s, tiled ? 2 : 0, 0));
     } else {
         BDSP_TRY(launch_pass_rp<T>(rp[1], w[1], io, sa, sb, n, nsg, batch, inverse, false, false, s));
         nsg *= rp[1];
