@@ -267,8 +267,8 @@ def profile_figures():
         if conv:
             out["conv_traffic"] = conv[0]
         if len(fft) == 2:  # the first-pass instantiation runs once per transform, the later-pass one twice (3 passes)
-            first = [v["hbm_bytes_per_launch"] for kn, v in k.items() if kn.startswith("k_fft_pass") and ", true, false, true>" in kn]
-            later = [v["hbm_bytes_per_launch"] for kn, v in k.items() if kn.startswith("k_fft_pass") and ", false, false, true>" in kn]
+            first = [v["hbm_bytes_per_launch"] for kn, v in k.items() if kn.startswith("k_fft_pass") and ", -1, true, false, true" in kn]
+            later = [v["hbm_bytes_per_launch"] for kn, v in k.items() if kn.startswith("k_fft_pass") and ", -1, false, false, true" in kn]
             if first and later:
                 out["fft_traffic"] = first[0] + 2 * later[0]
     except (OSError, KeyError, ValueError):
