@@ -61,6 +61,16 @@ __device__ __forceinline__ void nt_store(C* p, C v)
     __builtin_nontemporal_store(vec2{v.x, v.y}, reinterpret_cast<vec2*>(p));
 }
 
+// Streaming load (experiment, LAB builds with -DBDSP_FFT_NTLOAD: a pass's input is dead once read)
+template <typename C>
+__device__ __forceinline__ C nt_load(const C* p)
+{
+    using R = typename real_of<C>::type;
+    typedef R vec2 __attribute__((ext_vector_type(2)));
+    const vec2 v = __builtin_nontemporal_load(reinterpret_cast<const vec2*>(p));
+    return C{v.x, v.y};
+}
+
 int num_cus();
 
 // Experiment switches (tools/plan_probe.py, tools/chunk_probe.py, A/B runs) exist only in the LAB build of the library

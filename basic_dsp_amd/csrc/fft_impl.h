@@ -510,7 +510,13 @@ __global__ __launch_bounds__(W * (RP / 16), (pass_min_waves<T, RP, W, GEN>())) v
             for (int r = 0; r < 16; ++r) v[r] = in_t[(size_t)(ti + r * NT) * W];
         } else {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) v[r] = in[(size_t)(ti + (r ^ rx) * NT) * stride_in];
+            for (int r = 0; r < 16; ++r)
+                // (non-temporal loads, -DBDSP_FFT_NTLOAD in a LAB build: *measured* round 4)
+#if defined(BDSP_LAB) && defined(BDSP_FFT_NTLOAD)
+                v[r] = nt_load(&in[(size_t)(ti + (r ^ rx) * NT) * stride_in]);
+#else
+                v[r] = in[(size_t)(ti + (r ^ rx) * NT) * stride_in];
+#endif
         }
         if (!SIMPLE && ROWMAP && io.in_scale != (T)1) {
 #pragma unroll
