@@ -109,6 +109,9 @@ struct FftIo {
     int window_id;     // -1 none; else reference window id (4 = Hann)
     T window_alpha;
     size_t in_valid;   // 0 = all n points; else points >= in_valid read as zero (fused End zero-padding)
+    // cos / sin of q * 2 pi (n/16) / (n-1), q = 0..7: a pass thread's sixteen rows are n/16 points apart, so a generalised
+    // Hamming window costs it two sincospi and sixteen multiply-adds (filled by launch_pass; k_fft_pass, round 4)
+    T win_c[8], win_s[8];
 };
 constexpr unsigned FFT_IN_REAL = 1u << 8;        // input is a real vector (zero imaginary parts)
 constexpr unsigned FFT_WINDOW_OUT_DIV = 1u << 9; // divide OUTPUT by the window (windowed_ifft)

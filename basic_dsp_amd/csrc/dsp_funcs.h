@@ -20,6 +20,9 @@ template <typename T> __device__ __forceinline__ T dev_abs(T x) { return x < 0 ?
 template <typename T> __device__ __forceinline__ T dev_cospi(T x);
 template <> __device__ __forceinline__ float dev_cospi<float>(float x) { return cospif(x); }
 template <> __device__ __forceinline__ double dev_cospi<double>(double x) { return cospi(x); }
+template <typename T> __device__ __forceinline__ void dev_sincospi(T x, T* s, T* c);
+template <> __device__ __forceinline__ void dev_sincospi<float>(float x, float* s, float* c) { sincospif(x, s, c); }
+template <> __device__ __forceinline__ void dev_sincospi<double>(double x, double* s, double* c) { sincospi(x, s, c); }
 
 // window ids: 0 triangular, 1 Hamming(alpha), 2 Blackman-Harris, 3 rectangular
 // (interop/src/lib.rs:153-164); callers map the Hann addition (id 4) to (1, alpha = 0.5).

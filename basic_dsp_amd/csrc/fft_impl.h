@@ -523,39 +523,25 @@ __global__ __launch_bounds__(W * (RP / 16), (pass_min_waves<T, RP, W, GEN>())) v
             for (int r = 0; r < 16; ++r) v[r] = cpx<T>{v[r].x * io.in_scale, v[r].y * io.in_scale};
         }
         if (!SIMPLE && ROWMAP && io.window_id == 1 && !(io.flags & FFT_WINDOW_OUT_DIV)) {
-            // generalised Hamming (Hamming, Hann) on the input, in registers: w = alpha - beta cos(2 pi i/(n-1)),
-            // symmetric evaluation like the reference (vector_types/mod.rs:567-594)
+            // generalised Hamming (Hamming, Hann) on the input, in registers: w = alpha - beta cos(2 pi i/(n-1)), evaluated
+            // symmetrically like the reference (vector_types/mod.rs:567-594: w(i) = w(n-1-i)).  Register r holds row
+            // q = r ^ rx, i.e. point i = i0 + q n/16 with i0 = j + ti n/RP < n/16: the first-half rows q < 8 have angles
+            // theta0 + q D, the second-half rows their mirror images theta1 + (15 - q) D with i1 = n/16 - 1 - i0 -- two
+            // small base angles per thread and the eight constants cos / sin(q D) the launcher put into io
+            // (round 4; before: sixteen cospi per thread in f32 -- windowed_fft(Hann) at 16M points 146 us against 128
+            // plain -- and three sincospi + sixteen chained rotations in f64).
             const T beta = (T)1 - io.window_alpha, two_over = (T)2 / ((T)n - (T)1);
-            const size_t half = n - n / 2;
-            if constexpr (sizeof(T) == 8) {
-                // f64: sixteen cospi evaluations per thread were what made this pass 5 us slower than the others at
-                // 4M points.  The sixteen rows are n/16 apart, i.e. a constant angle step: two runs of eight rotations
-                // (registers 0..7 and 8..15 hold rows rx.. and (8^rx)..) from three sincospi; 8 rotations add < 1e-15.
-                double sd, cd;
-                sincospi((double)((size_t)NT * stride_in) * two_over, &sd, &cd);
-#pragma unroll
-                for (int run = 0; run < 2; ++run) {
-                    const size_t i0 = j + (size_t)(ti + ((8 * run) ^ rx) * NT) * stride_in;
-                    double s0, c0;
-                    sincospi((double)i0 * two_over, &s0, &c0);
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) {
-                        const int r = 8 * run + q;
-                        const T w = io.window_alpha - beta * c0;
-                        v[r] = cpx<T>{v[r].x * w, v[r].y * w};
-                        const double cn = c0 * cd - s0 * sd;
-                        s0 = s0 * cd + c0 * sd;
-                        c0 = cn;
-                    }
-                }
-            } else {
+            const size_t i0 = j + (size_t)ti * stride_in, i1 = n / 16 - 1 - i0;
+            T s0, c0, s1, c1;
+            dev_sincospi<T>((T)i0 * two_over, &s0, &c0);
+            dev_sincospi<T>((T)i1 * two_over, &s1, &c1);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                size_t i = j + (size_t)(ti + (r ^ rx) * NT) * stride_in;
-                i = i < half ? i : n - 1 - i;
-                const T w = io.window_alpha - beta * dev_cospi<T>((T)i * two_over);
+                const int q = r ^ rx; // (rx is 0 or 8: a compile-time pattern per branch after unrolling)
+                const int qq = q < 8 ? q : 15 - q;
+                const T cb = q < 8 ? c0 : c1, sb = q < 8 ? s0 : s1;
+                const T w = io.window_alpha - beta * (cb * io.win_c[qq] - sb * io.win_s[qq]);
                 v[r] = cpx<T>{v[r].x * w, v[r].y * w};
-            }
             }
         }
     }
@@ -944,9 +930,18 @@ constexpr bool pass_tiled_pair()
 }
 
 template <typename T, int RP, int W>
-static int launch_pass(const FftIo<T>& io, const cpx<T>* src, cpx<T>* dst, size_t n, size_t nsg,
+static int launch_pass(const FftIo<T>& io_in, const cpx<T>* src, cpx<T>* dst, size_t n, size_t nsg,
                        size_t batch, bool inverse, bool first, bool last, hipStream_t s, int tl = 0, int aux = 0)
 {
+    FftIo<T> io = io_in;
+    if (first && io.window_id == 1 && n > 1) {
+        // the window constants of k_fft_pass: cos / sin of q * 2 pi (n/16) / (n-1), q = 0..7, from double precision
+        const double step = 2.0 * (double)(n / 16) / ((double)n - 1.0); // in units of pi
+        for (int q = 0; q < 8; ++q) {
+            io.win_c[q] = (T)std::cos(M_PI * step * q);
+            io.win_s[q] = (T)std::sin(M_PI * step * q);
+        }
+    }
     const cpx<T>* wtab;
     BDSP_TRY(twiddle_table<T>(RP, &wtab));
     constexpr int THREADS = W * (RP / 16);
