@@ -522,26 +522,54 @@ __global__ __launch_bounds__(W * (RP / 16), (pass_min_waves<T, RP, W, GEN>())) v
 #pragma unroll
             for (int r = 0; r < 16; ++r) v[r] = cpx<T>{v[r].x * io.in_scale, v[r].y * io.in_scale};
         }
-        if (!SIMPLE && ROWMAP && io.window_id == 1 && !(io.flags & FFT_WINDOW_OUT_DIV)) {
-            // generalised Hamming (Hamming, Hann) on the input, in registers: w = alpha - beta cos(2 pi i/(n-1)), evaluated
-            // symmetrically like the reference (vector_types/mod.rs:567-594: w(i) = w(n-1-i)).  Register r holds row
-            // q = r ^ rx, i.e. point i = i0 + q n/16 with i0 = j + ti n/RP < n/16: the first-half rows q < 8 have angles
-            // theta0 + q D, the second-half rows their mirror images theta1 + (15 - q) D with i1 = n/16 - 1 - i0 -- two
-            // small base angles per thread and the eight constants cos / sin(q D) the launcher put into io
-            // (round 4; before: sixteen cospi per thread in f32 -- windowed_fft(Hann) at 16M points 146 us against 128
-            // plain -- and three sincospi + sixteen chained rotations in f64).
-            const T beta = (T)1 - io.window_alpha, two_over = (T)2 / ((T)n - (T)1);
+        if (!SIMPLE && ROWMAP && io.window_id >= 0 && io.window_id <= 2 && !(io.flags & FFT_WINDOW_OUT_DIV)) {
+            // The reference's windows on the input, in registers, evaluated symmetrically like the reference
+            // (vector_types/mod.rs:567-594: w(i) = w(n-1-i)).  Register r holds row q = r ^ rx, i.e. point i = i0 + q n/16
+            // with i0 = j + ti n/RP < n/16; a second-half row's mirror image is i1 + (15 - q) n/16, i1 = n/16 - 1 - i0.
+            //   Hamming / Hann (id 1) and Blackman-Harris (id 2): cos(2 pi i/(n-1)) = cos(theta_b + qq D) from TWO small base
+            //   angles per thread and the eight constants cos / sin(qq D) the launcher put into io (round 4; before:
+            //   sixteen cospi per thread in f32 -- windowed_fft(Hann) at 16M points 146 us against 128 plain -- and three
+            //   sincospi + sixteen chained rotations in f64; Blackman-Harris went through the staged generic loop with
+            //   three cospi per ELEMENT); the harmonics of Blackman-Harris by cos 2t = 2c^2 - 1, cos 3t = c (4c^2 - 3).
+            //   Triangular (id 0): the reference's formula on the mirrored index.
+            // (The f64 tiles with the split exchange live at a 128-register budget: with the triangular and Blackman-Harris
+            // code beside the Hamming loop they spilled 24-54 registers, so for THEM only the Hamming window is handled
+            // here and launch_pass sends the other two through the staged loop as before.)
             const size_t i0 = j + (size_t)ti * stride_in, i1 = n / 16 - 1 - i0;
-            T s0, c0, s1, c1;
-            dev_sincospi<T>((T)i0 * two_over, &s0, &c0);
-            dev_sincospi<T>((T)i1 * two_over, &s1, &c1);
+            if (!SPLIT && io.window_id == 0) {
+                // 1 - |(jm - (n-1)/2) / (n/2)| on the mirrored index jm = ib + qq n/16 (window_functions.rs:36-42)
+                const T b0 = ((T)i0 - ((T)n - (T)1) / (T)2) / ((T)n / (T)2), b1 = ((T)i1 - ((T)n - (T)1) / (T)2) / ((T)n / (T)2);
+                const T step = (T)0.125; // (n/16) / (n/2)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int q = r ^ rx; // (rx is 0 or 8: a compile-time pattern per branch after unrolling)
-                const int qq = q < 8 ? q : 15 - q;
-                const T cb = q < 8 ? c0 : c1, sb = q < 8 ? s0 : s1;
-                const T w = io.window_alpha - beta * (cb * io.win_c[qq] - sb * io.win_s[qq]);
-                v[r] = cpx<T>{v[r].x * w, v[r].y * w};
+                for (int r = 0; r < 16; ++r) {
+                    const int q = r ^ rx;
+                    const T w = (T)1 - dev_abs((q < 8 ? b0 : b1) + step * (T)(q < 8 ? q : 15 - q));
+                    v[r] = cpx<T>{v[r].x * w, v[r].y * w};
+                }
+            } else {
+                const T two_over = (T)2 / ((T)n - (T)1);
+                T s0, c0, s1, c1;
+                dev_sincospi<T>((T)i0 * two_over, &s0, &c0);
+                dev_sincospi<T>((T)i1 * two_over, &s1, &c1);
+                if (SPLIT || io.window_id == 1) {
+                    const T beta = (T)1 - io.window_alpha;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int q = r ^ rx, qq = q < 8 ? q : 15 - q; // (rx is 0 or 8)
+                        const T c = (q < 8 ? c0 : c1) * io.win_c[qq] - (q < 8 ? s0 : s1) * io.win_s[qq];
+                        const T w = io.window_alpha - beta * c;
+                        v[r] = cpx<T>{v[r].x * w, v[r].y * w};
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int q = r ^ rx, qq = q < 8 ? q : 15 - q;
+                        const T c = (q < 8 ? c0 : c1) * io.win_c[qq] - (q < 8 ? s0 : s1) * io.win_s[qq];
+                        const T c2 = c * c;
+                        const T w = (T)0.35875 - (T)0.48829 * c + (T)0.14128 * ((T)2 * c2 - (T)1) - (T)0.01168 * (c * ((T)4 * c2 - (T)3));
+                        v[r] = cpx<T>{v[r].x * w, v[r].y * w};
+                    }
+                }
             }
         }
     }
@@ -810,7 +838,8 @@ static bool io_in_generic(const FftIo<T>& io)
 {
     // ifft_shift (a register renaming for even n) and the input scale are handled by the plain path
     // ... and so is a generalised Hamming window on the first global pass (n > 4096)
-    const bool win = io.window_id >= 0 && !(io.flags & FFT_WINDOW_OUT_DIV) && !(io.window_id == 1 && io.n > 4096);
+    // (... and so are all four reference windows -- the rectangular one multiplies by one -- on the first global pass)
+    const bool win = io.window_id >= 0 && !(io.flags & FFT_WINDOW_OUT_DIV) && !(io.window_id <= 3 && io.n > 4096);
     // ... and real input (zero imaginary parts)
     return win || io.in_stride != io.n || (io.in_valid != 0 && io.n > 4096);
 }
@@ -934,7 +963,7 @@ static int launch_pass(const FftIo<T>& io_in, const cpx<T>* src, cpx<T>* dst, si
                        size_t batch, bool inverse, bool first, bool last, hipStream_t s, int tl = 0, int aux = 0)
 {
     FftIo<T> io = io_in;
-    if (first && io.window_id == 1 && n > 1) {
+    if (first && (io.window_id == 1 || io.window_id == 2) && n > 1) {
         // the window constants of k_fft_pass: cos / sin of q * 2 pi (n/16) / (n-1), q = 0..7, from double precision
         const double step = 2.0 * (double)(n / 16) / ((double)n - 1.0); // in units of pi
         for (int q = 0; q < 8; ++q) {
@@ -948,7 +977,10 @@ static int launch_pass(const FftIo<T>& io_in, const cpx<T>* src, cpx<T>* dst, si
     size_t tiles = (n / RP) / W;
     dim3 grid((unsigned)(tiles * batch));
     const bool rowmap = nsg == 1; // the first pass
-    const bool gen = (first && io_in_generic(io)) || (last && io_out_generic(io));
+    // (triangular / Blackman-Harris on a split-exchange f64 tile: the staged loop, see k_fft_pass)
+    const bool win_staged = first && (io.window_id == 0 || io.window_id == 2) && !(io.flags & FFT_WINDOW_OUT_DIV) &&
+                            pass_split_exchange<T, RP, W, false>();
+    const bool gen = (first && (io_in_generic(io) || win_staged)) || (last && io_out_generic(io));
     if (first && !gen) src = reinterpret_cast<const cpx<T>*>(io.in);
     if (last && !gen) dst = reinterpret_cast<cpx<T>*>(io.out);
     // plain first / last pass?  (then no option is looked at inside the kernel)

@@ -185,6 +185,29 @@ def test_two_pass_lengths_2m_and_4m_with_every_fused_option(bits, dtype):
     assert len(v) == n and rel_l2(v.data(), orc.magnitude(ref)) < tol
 
 
+@pytest.mark.parametrize("bits,dtype", [(13, np.float32), (20, np.float32), (23, np.float32), (14, np.float64), (21, np.float64)])
+def test_every_reference_window_fused_into_the_first_global_pass(bits, dtype):
+    """Above 4096 points all four reference windows (triangular, Hamming / Hann, Blackman-Harris, rectangular) are applied
+    in the registers of the first global pass (k_fft_pass: two sincospi per thread + host constants for the cosine
+    windows, the harmonics of Blackman-Harris by Chebyshev recurrences), with and without the fused ifft_shift that
+    renames the registers.  Against the oracle's window (window_functions.rs:26-132, evaluated symmetrically) and f64
+    transform."""
+    n = 1 << bits
+    tol = 1e-6 if dtype == np.float32 else 1e-12
+    x = orc.fill_uniform(2 * n, SEED_C2 + 7 * bits, -10, 10, dtype)
+    for wid, oid, alpha in ((V.WINDOW_TRIANGULAR, 0, 0.0), (V.WINDOW_HAMMING, 1, 0.54), (V.WINDOW_HANN, 1, 0.5),
+                            (V.WINDOW_BLACKMAN_HARRIS, 2, 0.0), (V.WINDOW_RECTANGULAR, 3, 0.0)):
+        v = DspVec(x, is_complex=True)
+        assert v.windowed_fft(wid) == 0
+        w = orc.apply_window(x.astype(np.float64), True, oid, alpha)
+        assert rel_l2(v.data(), orc.swap_halves(orc.fft(w), True, True)) < tol, wid
+        # windowed_ifft = ifft (scale + ifft_shift fused into the first pass) then the division by the window: the
+        # round trip restores the signal where the window is not ~0
+        if wid in (V.WINDOW_HAMMING, V.WINDOW_RECTANGULAR):
+            assert v.windowed_ifft(wid) == 0
+            assert rel_l2(v.data(), x) < (2e-5 if dtype == np.float32 else 1e-9), wid
+
+
 @pytest.mark.parametrize("n,dtype", [(1_000_003, np.float32), (2_000_003, np.float32), (1_000_003, np.float64)])
 def test_bluestein_lengths_over_two_pass_transforms(n, dtype):
     """Lengths with a large prime factor run Bluestein's chirp-z on power-of-two transforms of m >= 2n - 1 points:
