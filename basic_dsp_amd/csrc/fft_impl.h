@@ -442,6 +442,61 @@ __device__ __forceinline__ cpx<double> unit_root<double>(size_t e, size_t n)
 // on a later one -- the instantiation the headline transforms take.  The run-time option checks around the loads and
 // stores are then compiled out: the branches themselves are free, but hipcc's code around their merge points is not
 // (the same lesson as in conv_v2.hip).
+// The reference's windows on the sixteen values a pass thread holds, in registers (round 4).  In the first pass
+// (input side) and in the last one (output side) a thread's sixteen points form the lattice i0 + m n/16, m = 0..15, with
+// i0 < n/16 (rows are n/16 points apart); lattice(reg) says which m register `reg` holds.  Evaluated symmetrically like the
+// reference (vector_types/mod.rs:567-594: w(i) = w(n-1-i)): point m >= 8 takes the value of its mirror image
+// i1 + (15 - m) n/16, i1 = n/16 - 1 - i0.
+//   Hamming / Hann (id 1) and Blackman-Harris (id 2): cos(2 pi i/(n-1)) = cos(theta_b + mm D) from TWO small base angles
+//   per thread and the eight constants cos / sin(mm D) the launcher put into io (before: sixteen cospi per thread in f32,
+//   three sincospi + sixteen chained rotations in f64, and Blackman-Harris through the staged generic loop with three
+//   cospi per ELEMENT); Blackman-Harris's harmonics by cos 2t = 2c^2 - 1, cos 3t = c (4c^2 - 3).
+//   Triangular (id 0): the reference's formula, 1 - |(jm - (n-1)/2) / (n/2)|, on the mirrored index jm.
+// INV: divide by the window instead (windowed_ifft's un-windowing of the output, time.rs:50-66).
+// HAMMING_ONLY: the f64 tiles with the split exchange live at a 128-register budget -- with the triangular and
+// Blackman-Harris code beside the Hamming loop they spilled 24-54 registers -- so for them only the Hamming window is
+// handled here and launch_pass sends the other two through the staged loop.
+template <typename T, bool HAMMING_ONLY, bool INV, class LATTICE>
+__device__ __forceinline__ void pass_window16(const FftIo<T>& io, size_t i0, size_t n, cpx<T> (&v)[16], LATTICE lattice)
+{
+    const size_t i1 = n / 16 - 1 - i0;
+    auto put = [&](int reg, T w) {
+        if (INV) w = (T)1 / w;
+        v[reg] = cpx<T>{v[reg].x * w, v[reg].y * w};
+    };
+    if (!HAMMING_ONLY && io.window_id == 0) {
+        const T b0 = ((T)i0 - ((T)n - (T)1) / (T)2) / ((T)n / (T)2), b1 = ((T)i1 - ((T)n - (T)1) / (T)2) / ((T)n / (T)2);
+        const T step = (T)0.125; // (n/16) / (n/2)
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int m = lattice(reg);
+            put(reg, (T)1 - dev_abs((m < 8 ? b0 : b1) + step * (T)(m < 8 ? m : 15 - m)));
+        }
+        return;
+    }
+    const T two_over = (T)2 / ((T)n - (T)1);
+    T s0, c0, s1, c1;
+    dev_sincospi<T>((T)i0 * two_over, &s0, &c0);
+    dev_sincospi<T>((T)i1 * two_over, &s1, &c1);
+    if (HAMMING_ONLY || io.window_id == 1) {
+        const T beta = (T)1 - io.window_alpha;
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int m = lattice(reg), mm = m < 8 ? m : 15 - m;
+            const T c = (m < 8 ? c0 : c1) * io.win_c[mm] - (m < 8 ? s0 : s1) * io.win_s[mm];
+            put(reg, io.window_alpha - beta * c);
+        }
+    } else {
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int m = lattice(reg), mm = m < 8 ? m : 15 - m;
+            const T c = (m < 8 ? c0 : c1) * io.win_c[mm] - (m < 8 ? s0 : s1) * io.win_s[mm];
+            const T c2 = c * c;
+            put(reg, (T)0.35875 - (T)0.48829 * c + (T)0.14128 * ((T)2 * c2 - (T)1) - (T)0.01168 * (c * ((T)4 * c2 - (T)3)));
+        }
+    }
+}
+
 // TL (round 4): the TILED intermediate of a two-pass plan.  The first pass's output layout is nobody's business but the
 // second pass's, which reads, per tile, W2 adjacent columns of it: W2 x 8 (16) bytes per row -- 32-64-byte runs wherever
 // the columns are long (1024 / 2048 points).  With mid'[k1 / W2][j][k1 % W2] (k1 = the first pass's output index = the
@@ -523,54 +578,8 @@ __global__ __launch_bounds__(W * (RP / 16), (pass_min_waves<T, RP, W, GEN>())) v
             for (int r = 0; r < 16; ++r) v[r] = cpx<T>{v[r].x * io.in_scale, v[r].y * io.in_scale};
         }
         if (!SIMPLE && ROWMAP && io.window_id >= 0 && io.window_id <= 2 && !(io.flags & FFT_WINDOW_OUT_DIV)) {
-            // The reference's windows on the input, in registers, evaluated symmetrically like the reference
-            // (vector_types/mod.rs:567-594: w(i) = w(n-1-i)).  Register r holds row q = r ^ rx, i.e. point i = i0 + q n/16
-            // with i0 = j + ti n/RP < n/16; a second-half row's mirror image is i1 + (15 - q) n/16, i1 = n/16 - 1 - i0.
-            //   Hamming / Hann (id 1) and Blackman-Harris (id 2): cos(2 pi i/(n-1)) = cos(theta_b + qq D) from TWO small base
-            //   angles per thread and the eight constants cos / sin(qq D) the launcher put into io (round 4; before:
-            //   sixteen cospi per thread in f32 -- windowed_fft(Hann) at 16M points 146 us against 128 plain -- and three
-            //   sincospi + sixteen chained rotations in f64; Blackman-Harris went through the staged generic loop with
-            //   three cospi per ELEMENT); the harmonics of Blackman-Harris by cos 2t = 2c^2 - 1, cos 3t = c (4c^2 - 3).
-            //   Triangular (id 0): the reference's formula on the mirrored index.
-            // (The f64 tiles with the split exchange live at a 128-register budget: with the triangular and Blackman-Harris
-            // code beside the Hamming loop they spilled 24-54 registers, so for THEM only the Hamming window is handled
-            // here and launch_pass sends the other two through the staged loop as before.)
-            const size_t i0 = j + (size_t)ti * stride_in, i1 = n / 16 - 1 - i0;
-            if (!SPLIT && io.window_id == 0) {
-                // 1 - |(jm - (n-1)/2) / (n/2)| on the mirrored index jm = ib + qq n/16 (window_functions.rs:36-42)
-                const T b0 = ((T)i0 - ((T)n - (T)1) / (T)2) / ((T)n / (T)2), b1 = ((T)i1 - ((T)n - (T)1) / (T)2) / ((T)n / (T)2);
-                const T step = (T)0.125; // (n/16) / (n/2)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int q = r ^ rx;
-                    const T w = (T)1 - dev_abs((q < 8 ? b0 : b1) + step * (T)(q < 8 ? q : 15 - q));
-                    v[r] = cpx<T>{v[r].x * w, v[r].y * w};
-                }
-            } else {
-                const T two_over = (T)2 / ((T)n - (T)1);
-                T s0, c0, s1, c1;
-                dev_sincospi<T>((T)i0 * two_over, &s0, &c0);
-                dev_sincospi<T>((T)i1 * two_over, &s1, &c1);
-                if (SPLIT || io.window_id == 1) {
-                    const T beta = (T)1 - io.window_alpha;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int q = r ^ rx, qq = q < 8 ? q : 15 - q; // (rx is 0 or 8)
-                        const T c = (q < 8 ? c0 : c1) * io.win_c[qq] - (q < 8 ? s0 : s1) * io.win_s[qq];
-                        const T w = io.window_alpha - beta * c;
-                        v[r] = cpx<T>{v[r].x * w, v[r].y * w};
-                    }
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int q = r ^ rx, qq = q < 8 ? q : 15 - q;
-                        const T c = (q < 8 ? c0 : c1) * io.win_c[qq] - (q < 8 ? s0 : s1) * io.win_s[qq];
-                        const T c2 = c * c;
-                        const T w = (T)0.35875 - (T)0.48829 * c + (T)0.14128 * ((T)2 * c2 - (T)1) - (T)0.01168 * (c * ((T)4 * c2 - (T)3));
-                        v[r] = cpx<T>{v[r].x * w, v[r].y * w};
-                    }
-                }
-            }
+            // the window on the input, in registers: register r holds row q = r ^ rx (rx is 0 or 8), i.e. lattice point q
+            pass_window16<T, SPLIT, false>(io, j + (size_t)ti * stride_in, n, v, [&](int r) { return r ^ rx; });
         }
     }
     if (!ROWMAP) { // (nsg > 1 exactly on the later passes)
@@ -670,6 +679,12 @@ __global__ __launch_bounds__(W * (RP / 16), (pass_min_waves<T, RP, W, GEN>())) v
         cpx<T>* out = dst + vec * n + base;
         // last pass: fft_shift = the row index's top bit flipped; the last inner stage's digit r is that top digit
         const int sx = (!SIMPLE && last && !ROWMAP && (io.flags & BDSP_FFT_SHIFT_OUT)) ? RL / 2 : 0;
+        if (!SIMPLE && last && !ROWMAP && (io.flags & FFT_WINDOW_OUT_DIV) && io.window_id >= 0 && io.window_id <= 2) {
+            // windowed_ifft: the division by the window in the registers of the last pass (round 4; before: the staged
+            // loop, 16M points f32 150 us for Hamming and 181 for Blackman-Harris against 133 for ifft).  Register
+            // b RL + r goes to row t2 + (b + (r ^ sx) 16/RL) RP/16, i.e. lattice point b + (r ^ sx) 16/RL of jj + t2 n/RP
+            pass_window16<T, SPLIT, true>(io, jj + (size_t)t2 * nsg, n, v, [&](int reg) { return reg / RL + ((reg % RL) ^ sx) * (16 / RL); });
+        }
         if (!SIMPLE && last && !ROWMAP && (io.flags & (BDSP_FFT_MAGNITUDE | FFT_OUT_REAL))) {
             // magnitude / real part straight from the registers: `points` reals per vector
             T* outr = reinterpret_cast<T*>(io.out) + vec * io.out_stride + base;
@@ -848,7 +863,8 @@ static bool io_out_generic(const FftIo<T>& io)
 {
     // fft_shift is handled by the plain path
     // ... and magnitude / real-part outputs are written straight from the registers
-    return (io.flags & FFT_WINDOW_OUT_DIV) != 0 || io.out_stride != io.n;
+    // ... and so is the division by one of the reference's windows (windowed_ifft) on the last global pass
+    return ((io.flags & FFT_WINDOW_OUT_DIV) != 0 && !(io.window_id >= 0 && io.window_id <= 3 && io.n > 4096)) || io.out_stride != io.n;
 }
 template <typename T>
 static bool io_is_generic(const FftIo<T>& io) { return io_in_generic(io) || io_out_generic(io); }
@@ -963,7 +979,7 @@ static int launch_pass(const FftIo<T>& io_in, const cpx<T>* src, cpx<T>* dst, si
                        size_t batch, bool inverse, bool first, bool last, hipStream_t s, int tl = 0, int aux = 0)
 {
     FftIo<T> io = io_in;
-    if (first && (io.window_id == 1 || io.window_id == 2) && n > 1) {
+    if ((first || last) && (io.window_id == 1 || io.window_id == 2) && n > 1) {
         // the window constants of k_fft_pass: cos / sin of q * 2 pi (n/16) / (n-1), q = 0..7, from double precision
         const double step = 2.0 * (double)(n / 16) / ((double)n - 1.0); // in units of pi
         for (int q = 0; q < 8; ++q) {
@@ -978,14 +994,14 @@ static int launch_pass(const FftIo<T>& io_in, const cpx<T>* src, cpx<T>* dst, si
     dim3 grid((unsigned)(tiles * batch));
     const bool rowmap = nsg == 1; // the first pass
     // (triangular / Blackman-Harris on a split-exchange f64 tile: the staged loop, see k_fft_pass)
-    const bool win_staged = first && (io.window_id == 0 || io.window_id == 2) && !(io.flags & FFT_WINDOW_OUT_DIV) &&
-                            pass_split_exchange<T, RP, W, false>();
-    const bool gen = (first && (io_in_generic(io) || win_staged)) || (last && io_out_generic(io));
+    const bool win_staged = (io.window_id == 0 || io.window_id == 2) && pass_split_exchange<T, RP, W, false>() &&
+                            ((first && !(io.flags & FFT_WINDOW_OUT_DIV)) || (last && (io.flags & FFT_WINDOW_OUT_DIV)));
+    const bool gen = (first && io_in_generic(io)) || (last && io_out_generic(io)) || win_staged;
     if (first && !gen) src = reinterpret_cast<const cpx<T>*>(io.in);
     if (last && !gen) dst = reinterpret_cast<cpx<T>*>(io.out);
     // plain first / last pass?  (then no option is looked at inside the kernel)
     const bool simple = !gen && (rowmap ? ((io.flags & (FFT_IN_REAL | BDSP_FFT_SHIFT_IN)) == 0 && io.in_scale == (T)1 && io.window_id < 0)
-                                        : (!last || (io.flags & (BDSP_FFT_SHIFT_OUT | BDSP_FFT_MAGNITUDE | FFT_OUT_REAL)) == 0));
+                                        : (!last || (io.flags & (BDSP_FFT_SHIFT_OUT | BDSP_FFT_MAGNITUDE | FFT_OUT_REAL | FFT_WINDOW_OUT_DIV)) == 0));
     // (tiled instantiations exist for the long columns only: pass_tiled_pair)
     if (tl != 0 && (!pass_tiled_pair<RP>() || (tl == 1) != rowmap)) { set_last_error("tiled intermediate: unsupported pass"); return BDSP_ERR_UNSUPPORTED; }
 #define BDSP_PASS(DIRV, RM, GENV, SV, TLV)                                                         \

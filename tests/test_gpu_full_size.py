@@ -206,6 +206,17 @@ def test_every_reference_window_fused_into_the_first_global_pass(bits, dtype):
         if wid in (V.WINDOW_HAMMING, V.WINDOW_RECTANGULAR):
             assert v.windowed_ifft(wid) == 0
             assert rel_l2(v.data(), x) < (2e-5 if dtype == np.float32 else 1e-9), wid
+        # windowed_ifft by itself (the division by the window in the registers of the LAST global pass) against the
+        # oracle's ifft + unapply_window of the same spectrum.  A division amplifies the window's own rounding (1e-7 in
+        # f32, absolute) by 1 / w, and the triangular and Blackman-Harris windows are small towards the ends (2e-4 at
+        # n/64): compare the central half for those two, all but the first and last 1/64 for the others
+        spec = orc.fill_uniform(2 * n, SEED_C2 + 11 * bits + wid, -10, 10, dtype)
+        v = DspVec(spec, is_complex=True, domain=1)
+        assert v.windowed_ifft(wid) == 0
+        t = orc.fft(orc.swap_halves(spec.astype(np.float64), True, False), inverse=True) / n
+        t = orc.apply_window(t, True, oid, alpha, unapply=True)
+        cut = 2 * (n // 4) if wid in (V.WINDOW_TRIANGULAR, V.WINDOW_BLACKMAN_HARRIS) else 2 * (n // 64)
+        assert rel_l2(v.data()[cut:-cut], t[cut:-cut]) < 4 * tol, wid
 
 
 @pytest.mark.parametrize("n,dtype", [(1_000_003, np.float32), (2_000_003, np.float32), (1_000_003, np.float64)])

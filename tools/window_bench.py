@@ -16,3 +16,7 @@ for dtype, n in ((np.float32, 1 << 24), (np.float64, 1 << 22)):
     print("%s n=%d (%s): plain_fft %.1f us; windowed_fft triangular %.1f, Hamming %.1f, Blackman-Harris %.1f, Hann %.1f us" % (
         np.dtype(dtype).name, n, os.path.basename(bd.LIB_PATH), t(v.plain_fft, v.plain_ifft), t(lambda: v.windowed_fft(0), v.ifft),
         t(lambda: v.windowed_fft(1), v.ifft), t(lambda: v.windowed_fft(2), v.ifft), t(lambda: v.windowed_fft(4), v.ifft)))
+    v.fft()
+    print("      inverses: plain_ifft %.1f us, ifft %.1f; windowed_ifft triangular %.1f, Hamming %.1f, Blackman-Harris %.1f, Hann %.1f us" % (
+        t(v.plain_ifft, v.plain_fft), t(v.ifft, v.fft), t(lambda: v.windowed_ifft(0), v.fft), t(lambda: v.windowed_ifft(1), v.fft),
+        t(lambda: v.windowed_ifft(2), v.fft), t(lambda: v.windowed_ifft(4), v.fft)))
