@@ -176,6 +176,10 @@ template <typename T> int ew_window(T* x, size_t len, bool is_complex, int id, T
 template <typename T> int ew_fill(T* x, size_t len, T value, hipStream_t s);
 template <typename T> int ew_freq_response(T* x, size_t len, bool is_complex, int fid, T rolloff, T ratio, bool shifted, hipStream_t s);
 template <typename T> int ew_linear_phase(T* x, size_t len, T delay, hipStream_t s);
+// spectrum of N points -> dst_points, out of place, one trip (mode 0: periodic repetition = the transform of the
+// zero-interleaved vector; mode 1: zero_pad(Center) with the linear phase on the source bin), x the frequency response
+// on the destination axis (fid >= 0), x ratio (fid == -1) or nothing (fid == -2); elementwise.hip
+template <typename T> int ew_spectrum_resample(const T* in, T* out, size_t src_points, size_t dst_points, int mode, int fid, T rolloff, T ratio, double phase_inc, hipStream_t s);
 
 // reorg.hip
 template <typename T> int rg_rotate(const T* in, T* out, size_t points, size_t elem, size_t shift, hipStream_t s);

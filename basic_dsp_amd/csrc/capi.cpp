@@ -944,16 +944,18 @@ int op_interpolatei(DevVec<T>* v, int fid, T rolloff, int factor, const Sampler<
     const size_t points = v->points(), np = points * (size_t)factor;
     if (points == 0) return BDSP_OK;
     BDSP_TRY(v->reserve(2 * np));
-    // real input: interleave with 2*factor-1 zeros = complex with zero imaginary parts
-    BDSP_HIP_TRY(hipMemsetAsync(v->buf, 0, sizeof(T) * 2 * np, s));
-    BDSP_TRY(rg_zero_interleave<T>(v->data, v->buf, v->valid_len, was_complex ? 2 : 1,
-                                   was_complex ? (size_t)factor : 2 * (size_t)factor, s));
-    v->trade();
+    // Round 4: the transform of the vector interleaved with factor - 1 zeros is the factor-fold periodic repetition of
+    // the transform of the vector itself, so the reference's zero_interleave -> plain_fft of factor * N points
+    // (interpolation.rs:484-532) is an N-point transform (real input read directly: zero imaginary parts) whose
+    // spectrum is read `factor` times under the frequency response -- one resampling trip instead of memset +
+    // interleave + response, and the forward transform at 1/factor of the size (*measured*, 4M points f32, factor 2:
+    // 221 -> see DESIGN.md 4.4).
     bool in_b = false;
-    BDSP_TRY(fft_two_buffers<T>(v->data, v->buf, np, 1, false, 0, (T)1, -1, (T)0, &in_b, s));
+    BDSP_TRY(fft_two_buffers<T>(v->data, v->buf, points, 1, false, was_complex ? 0u : FFT_IN_REAL, (T)1, -1, (T)0, &in_b, s));
     if (in_b) v->trade();
+    BDSP_TRY(ew_spectrum_resample<T>(v->data, v->buf, points, np, 0, custom ? -2 : fid, rolloff, (T)factor, 0.0, s));
+    v->trade();
     if (custom) BDSP_TRY(apply_sampled_response<T>(v->data, 2 * np, true, *custom, (T)factor, true, s));
-    else BDSP_TRY(ew_freq_response<T>(v->data, 2 * np, true, fid, rolloff, (T)factor, true, s));
     // plain_ifft then scale(1/points): the scale rides on the inverse transform's input
     BDSP_TRY(fft_two_buffers<T>(v->data, v->buf, np, 1, true, 0, (T)1 / (T)np, -1, (T)0, &in_b, s));
     if (in_b) v->trade();
@@ -986,14 +988,17 @@ int op_interpolate(DevVec<T>* v, int fid, T rolloff, size_t dest_points, T delay
     bool in_b = false;
     BDSP_TRY(fft_two_buffers<T>(v->data, v->buf, points, 1, false, 0, (T)1, -1, (T)0, &in_b, s));
     if (in_b) v->trade();
-    if (delay != (T)0) BDSP_TRY(ew_linear_phase<T>(v->data, 2 * points, delay / delta_t, s));
     if (dest_points > points) {
-        BDSP_TRY(rg_zero_pad<T>(v->data, v->buf, 2 * points, true, dest_points, 2, s));
+        // linear phase (on the source bins) + zero_pad(Center) + frequency response / scale: ONE resampling trip
+        // (round 4; before: three, and the padding's own memset)
+        const T dly = delay / delta_t;
+        const T phase_inc = (T)2 * (T)3.14159265358979323846 * dly / (T)points; // as ew_linear_phase computes it
+        BDSP_TRY(ew_spectrum_resample<T>(v->data, v->buf, points, dest_points, 1, custom ? -2 : (fid < 0 ? -1 : fid), rolloff, factorf,
+                                         delay != (T)0 ? (double)phase_inc : 0.0, s));
         v->trade();
         if (custom) BDSP_TRY(apply_sampled_response<T>(v->data, 2 * dest_points, true, *custom, factorf, true, s));
-        else if (fid < 0) BDSP_TRY(ew_real_scale<T>(v->data, 2 * dest_points, factorf, s));
-        else BDSP_TRY(ew_freq_response<T>(v->data, 2 * dest_points, true, fid, rolloff, factorf, true, s));
     } else if (dest_points < points) {
+        if (delay != (T)0) BDSP_TRY(ew_linear_phase<T>(v->data, 2 * points, delay / delta_t, s));
         // interpolate_downsample (:362-376): keep the first pos and the last neg bins
         const size_t neg = dest_points / 2, pos = dest_points - neg;
         BDSP_HIP_TRY(hipMemcpyAsync(v->buf, v->data, sizeof(T) * 2 * pos, hipMemcpyDeviceToDevice, s));

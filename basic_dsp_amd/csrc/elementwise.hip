@@ -177,6 +177,76 @@ template <typename T> int ew_linear_phase(T* x, size_t len, T delay, hipStream_t
     return launch_map<T, OpLinearPhase<T>>(x, len, {(double)phase_inc, points, pos}, s);
 }
 
+// ---- spectrum resampling for the FFT-domain interpolation family (round 4) ------------------------
+// out[k], k < dst_points, from an N-point spectrum `in` (complex, out != in), in ONE trip instead of three or four:
+//   MODE 0 (interpolatei): out[k] = in[k mod N] -- the transform of a vector interleaved with factor - 1 zeros IS the
+//          factor-fold periodic repetition of the transform of the vector itself (sum_i x[i] e^{-2 pi i (i f) k / (f N)} =
+//          X[k mod N]), so the reference's zero_interleave -> plain_fft of f N points (interpolation.rs:484-532) is an
+//          N-point transform read f times;
+//   MODE 1 (interpolate / interpft, upsampling): zero_pad(Center) -- the first ceil(N/2) bins stay, the last floor(N/2)
+//          move to the end, zeros between (data_reorganization.rs:343-358) -- with apply_linear_phase (:319-339) on the
+//          SOURCE bin when delay != 0;
+// then x the frequency response on the destination axis (OpFreqResp: the same formula, so the multiplier is bit-identical
+// to the separate pass), or x `ratio` alone (fid < 0), or nothing (fid == -2: a host-sampled response follows).
+// Every product is rounded to T in the same order as the separate passes (this file is compiled without contraction).
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void k_spectrum_resample(const T* __restrict__ in, T* __restrict__ out, size_t src_points, size_t dst_points,
+                                                            int fid, T rolloff, T ratio, double phase_inc)
+{
+    const size_t offset = dst_points % 2;
+    const T maxv = (T)(dst_points - offset) / (T)2;
+    const size_t pos = src_points - src_points / 2, neg = src_points / 2; // bins that stay / move to the end
+    const size_t ph_pos = src_points / 2;                                  // OpLinearPhase's positive bins
+    typedef T vec2 __attribute__((ext_vector_type(2)));
+    const vec2* in2 = reinterpret_cast<const vec2*>(in);
+    vec2* out2 = reinterpret_cast<vec2*>(out);
+    for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < dst_points; k += (size_t)gridDim.x * blockDim.x) {
+        size_t sk;
+        bool zero = false;
+        if (MODE == 0) sk = k % src_points;
+        else {
+            if (k < pos) sk = k;
+            else if (k >= dst_points - neg) sk = k - (dst_points - src_points);
+            else { sk = 0; zero = true; }
+        }
+        T re = (T)0, im = (T)0;
+        if (!zero) {
+            const vec2 z = in2[sk];
+            re = z.x;
+            im = z.y;
+            if (MODE == 1 && phase_inc != 0.0) { // OpLinearPhase on the source bin
+                const double kk = sk < ph_pos ? (double)sk : (double)sk - (double)src_points;
+                double sn, cs;
+                sincos(phase_inc * kk, &sn, &cs);
+                const T wr = (T)cs, wi = (T)sn, zr = re, zi = im;
+                re = zr * wr - zi * wi;
+                im = zr * wi + zi * wr;
+            }
+        }
+        if (fid >= 0) { // OpFreqResp on the destination axis
+            T j = -maxv + (T)k;
+            if (j > (T)0) j = -j;
+            const T arg = ratio * conv_freq_value<T>(fid, rolloff, fft_swap_x<T>(true, j, maxv) * ratio);
+            const T r2 = re * arg - im * (T)0, i2 = re * (T)0 + im * arg;
+            re = r2; im = i2;
+        } else if (fid == -1) {
+            re = re * ratio; im = im * ratio;
+        }
+        out2[k] = vec2{re, im};
+    }
+}
+template <typename T>
+int ew_spectrum_resample(const T* in, T* out, size_t src_points, size_t dst_points, int mode, int fid, T rolloff, T ratio, double phase_inc, hipStream_t s)
+{
+    if (dst_points == 0) return BDSP_OK;
+    if (in == out || src_points == 0) return BDSP_ERR_UNSUPPORTED;
+    const unsigned grid = ew_grid(dst_points / 2 + 1);
+    if (mode == 0) hipLaunchKernelGGL((k_spectrum_resample<T, 0>), dim3(grid), dim3(256), 0, s, in, out, src_points, dst_points, fid, rolloff, ratio, phase_inc);
+    else hipLaunchKernelGGL((k_spectrum_resample<T, 1>), dim3(grid), dim3(256), 0, s, in, out, src_points, dst_points, fid, rolloff, ratio, phase_inc);
+    BDSP_LAUNCH_CHECK();
+    return BDSP_OK;
+}
+
 // ---- binary vector (.) vector, in place on x (elementary.rs:540-589) ------------------------------
 template <typename T, int OP, bool CPLX>
 __global__ __launch_bounds__(256) void k_binary(T* __restrict__ x, const T* __restrict__ y, size_t len)
@@ -364,7 +434,8 @@ template <typename T> int ew_complex_to_real(const T* x, T* out, size_t len, int
     template int ew_window<T>(T*, size_t, bool, int, T, bool, hipStream_t);                        \
     template int ew_fill<T>(T*, size_t, T, hipStream_t);                                            \
     template int ew_freq_response<T>(T*, size_t, bool, int, T, T, bool, hipStream_t);              \
-    template int ew_linear_phase<T>(T*, size_t, T, hipStream_t);
+    template int ew_linear_phase<T>(T*, size_t, T, hipStream_t);                                    \
+    template int ew_spectrum_resample<T>(const T*, T*, size_t, size_t, int, int, T, T, double, hipStream_t);
 BDSP_INST(float)
 BDSP_INST(double)
 #undef BDSP_INST

@@ -219,6 +219,35 @@ def test_every_reference_window_fused_into_the_first_global_pass(bits, dtype):
         assert rel_l2(v.data()[cut:-cut], t[cut:-cut]) < 4 * tol, wid
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_fft_domain_interpolation_family_at_1m_points(dtype):
+    """interpolatei / interpolate / interpft at sizes where every transform runs in global passes.  interpolatei takes the
+    N-point transform and reads its spectrum `factor` times under the frequency response (the transform of the
+    zero-interleaved vector IS that periodic repetition); interpolate / interpft put the linear phase, the centred
+    zero-padding and the response into one resampling trip (capi.cpp op_interpolatei / op_interpolate,
+    elementwise.hip k_spectrum_resample).  Against the oracle's literal restatement of interpolation.rs:484-605."""
+    n = 1 << 20
+    for cplx in (True, False):
+        e = 2 if cplx else 1
+        x = orc.fill_uniform(n * e, 4711 + e, -10, 10, dtype)
+        for fid, ro, factor in ((0, 0.0, 2), (1, 0.35, 3)):
+            v = DspVec(x, is_complex=cplx)
+            assert v.interpolatei(fid, factor, ro) == 0
+            code, ref = orc.interpolatei(x.astype(np.float64), cplx, fid, ro, factor)
+            assert code == 0 and len(v) == ref.size and v.is_complex() == cplx
+            assert rel_l2(v.data(), ref) < (5e-6 if dtype == np.float32 else 1e-11), (cplx, fid, factor)
+        for dest, delay in ((3 * n // 2, 0.0), (2 * n, 0.3), (2 * n + 1, 0.0)):
+            v = DspVec(x, is_complex=cplx, delta=0.5)
+            assert v.interpolate(V.CONV_SINC, dest, delay) == 0
+            code, ref, nd = orc.interpolate(x.astype(np.float64), cplx, 0, 0.0, dest, delay, 0.5)
+            assert len(v) == ref.size and v.delta() == pytest.approx(nd, rel=1e-6)
+            assert rel_l2(v.data(), ref) < (2e-5 if dtype == np.float32 else 1e-10), (cplx, dest, delay)
+        v = DspVec(x, is_complex=cplx)
+        assert v.interpft(2 * n) == 0
+        code, ref, _ = orc.interpolate(x.astype(np.float64), cplx, -1, 0.0, 2 * n, 0.0, 1.0)
+        assert rel_l2(v.data(), ref) < (2e-5 if dtype == np.float32 else 1e-10)
+
+
 @pytest.mark.parametrize("n,dtype", [(1_000_003, np.float32), (2_000_003, np.float32), (1_000_003, np.float64)])
 def test_bluestein_lengths_over_two_pass_transforms(n, dtype):
     """Lengths with a large prime factor run Bluestein's chirp-z on power-of-two transforms of m >= 2n - 1 points:
