@@ -957,15 +957,9 @@ int op_interpolatei(DevVec<T>* v, int fid, T rolloff, int factor, const Sampler<
     v->trade();
     if (custom) BDSP_TRY(apply_sampled_response<T>(v->data, 2 * np, true, *custom, (T)factor, true, s));
     // plain_ifft then scale(1/points): the scale rides on the inverse transform's input
-    BDSP_TRY(fft_two_buffers<T>(v->data, v->buf, np, 1, true, 0, (T)1 / (T)np, -1, (T)0, &in_b, s));
+    BDSP_TRY(fft_two_buffers<T>(v->data, v->buf, np, 1, true, was_complex ? 0u : FFT_OUT_REAL, (T)1 / (T)np, -1, (T)0, &in_b, s));
     if (in_b) v->trade();
-    if (was_complex) {
-        v->valid_len = 2 * np;
-    } else {
-        BDSP_TRY(ew_complex_to_real<T>(v->data, v->buf, 2 * np, 2, s));
-        v->trade();
-        v->valid_len = np;
-    }
+    v->valid_len = was_complex ? 2 * np : np; // (a real vector's result: the real parts straight from the last pass)
     return BDSP_OK; // the reference does not touch delta here (interpolation.rs:484-532)
 }
 
@@ -998,25 +992,21 @@ int op_interpolate(DevVec<T>* v, int fid, T rolloff, size_t dest_points, T delay
         v->trade();
         if (custom) BDSP_TRY(apply_sampled_response<T>(v->data, 2 * dest_points, true, *custom, factorf, true, s));
     } else if (dest_points < points) {
-        if (delay != (T)0) BDSP_TRY(ew_linear_phase<T>(v->data, 2 * points, delay / delta_t, s));
-        // interpolate_downsample (:362-376): keep the first pos and the last neg bins
-        const size_t neg = dest_points / 2, pos = dest_points - neg;
-        BDSP_HIP_TRY(hipMemcpyAsync(v->buf, v->data, sizeof(T) * 2 * pos, hipMemcpyDeviceToDevice, s));
-        BDSP_HIP_TRY(hipMemcpyAsync(v->buf + 2 * pos, v->data + 2 * (points - neg), sizeof(T) * 2 * neg,
-                                    hipMemcpyDeviceToDevice, s));
+        // interpolate_downsample (:362-376): linear phase + the crop to the first pos and the last neg bins + the
+        // scale in one resampling trip
+        const T dly = delay / delta_t;
+        const T phase_inc = (T)2 * (T)3.14159265358979323846 * dly / (T)points;
+        BDSP_TRY(ew_spectrum_resample<T>(v->data, v->buf, points, dest_points, 2, -1, (T)0, (T)(2 * dest_points) / (T)(2 * points),
+                                         delay != (T)0 ? (double)phase_inc : 0.0, s));
         v->trade();
-        BDSP_TRY(ew_real_scale<T>(v->data, 2 * dest_points, (T)(2 * dest_points) / (T)(2 * points), s));
+    } else if (delay != (T)0) {
+        BDSP_TRY(ew_linear_phase<T>(v->data, 2 * points, delay / delta_t, s));
     }
-    BDSP_TRY(fft_two_buffers<T>(v->data, v->buf, dest_points, 1, true, 0, (T)1 / (T)dest_points, -1, (T)0, &in_b, s));
+    // (a real vector's result: the real parts straight from the inverse transform's last pass, FFT_OUT_REAL)
+    BDSP_TRY(fft_two_buffers<T>(v->data, v->buf, dest_points, 1, true, was_complex ? 0u : FFT_OUT_REAL, (T)1 / (T)dest_points, -1, (T)0, &in_b, s));
     if (in_b) v->trade();
     v->delta = delta_t / factorf;
-    if (was_complex) {
-        v->valid_len = 2 * dest_points;
-    } else {
-        BDSP_TRY(ew_complex_to_real<T>(v->data, v->buf, 2 * dest_points, 2, s));
-        v->trade();
-        v->valid_len = dest_points;
-    }
+    v->valid_len = was_complex ? 2 * dest_points : dest_points;
     return BDSP_OK;
 }
 

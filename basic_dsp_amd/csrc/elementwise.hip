@@ -186,6 +186,7 @@ template <typename T> int ew_linear_phase(T* x, size_t len, T delay, hipStream_t
 //   MODE 1 (interpolate / interpft, upsampling): zero_pad(Center) -- the first ceil(N/2) bins stay, the last floor(N/2)
 //          move to the end, zeros between (data_reorganization.rs:343-358) -- with apply_linear_phase (:319-339) on the
 //          SOURCE bin when delay != 0;
+//   MODE 2 (interpolate, downsampling): the crop of interpolate_downsample with the same linear phase;
 // then x the frequency response on the destination axis (OpFreqResp: the same formula, so the multiplier is bit-identical
 // to the separate pass), or x `ratio` alone (fid < 0), or nothing (fid == -2: a host-sampled response follows).
 // Every product is rounded to T in the same order as the separate passes (this file is compiled without contraction).
@@ -204,7 +205,9 @@ __global__ __launch_bounds__(256) void k_spectrum_resample(const T* __restrict__
         size_t sk;
         bool zero = false;
         if (MODE == 0) sk = k % src_points;
-        else {
+        else if (MODE == 2) { // interpolate_downsample (interpolation.rs:362-376): the first ceil(D/2) and the last floor(D/2) bins
+            sk = k < dst_points - dst_points / 2 ? k : k + (src_points - dst_points);
+        } else {
             if (k < pos) sk = k;
             else if (k >= dst_points - neg) sk = k - (dst_points - src_points);
             else { sk = 0; zero = true; }
@@ -214,7 +217,7 @@ __global__ __launch_bounds__(256) void k_spectrum_resample(const T* __restrict__
             const vec2 z = in2[sk];
             re = z.x;
             im = z.y;
-            if (MODE == 1 && phase_inc != 0.0) { // OpLinearPhase on the source bin
+            if (MODE != 0 && phase_inc != 0.0) { // OpLinearPhase on the source bin
                 const double kk = sk < ph_pos ? (double)sk : (double)sk - (double)src_points;
                 double sn, cs;
                 sincos(phase_inc * kk, &sn, &cs);
@@ -242,6 +245,7 @@ int ew_spectrum_resample(const T* in, T* out, size_t src_points, size_t dst_poin
     if (in == out || src_points == 0) return BDSP_ERR_UNSUPPORTED;
     const unsigned grid = ew_grid(dst_points / 2 + 1);
     if (mode == 0) hipLaunchKernelGGL((k_spectrum_resample<T, 0>), dim3(grid), dim3(256), 0, s, in, out, src_points, dst_points, fid, rolloff, ratio, phase_inc);
+    else if (mode == 2) hipLaunchKernelGGL((k_spectrum_resample<T, 2>), dim3(grid), dim3(256), 0, s, in, out, src_points, dst_points, fid, rolloff, ratio, phase_inc);
     else hipLaunchKernelGGL((k_spectrum_resample<T, 1>), dim3(grid), dim3(256), 0, s, in, out, src_points, dst_points, fid, rolloff, ratio, phase_inc);
     BDSP_LAUNCH_CHECK();
     return BDSP_OK;
