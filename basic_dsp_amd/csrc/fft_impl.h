@@ -453,10 +453,10 @@ __device__ __forceinline__ cpx<double> unit_root<double>(size_t e, size_t n)
 //   cospi per ELEMENT); Blackman-Harris's harmonics by cos 2t = 2c^2 - 1, cos 3t = c (4c^2 - 3).
 //   Triangular (id 0): the reference's formula, 1 - |(jm - (n-1)/2) / (n/2)|, on the mirrored index jm.
 // INV: divide by the window instead (windowed_ifft's un-windowing of the output, time.rs:50-66).
-// HAMMING_ONLY: the f64 tiles with the split exchange live at a 128-register budget -- with the triangular and
-// Blackman-Harris code beside the Hamming loop they spilled 24-54 registers -- so for them only the Hamming window is
-// handled here and launch_pass sends the other two through the staged loop.
-template <typename T, bool HAMMING_ONLY, bool INV, class LATTICE>
+// FIXED >= 0: the window id is a compile-time constant.  The f64 tiles with the split exchange live at a 128-register
+// budget; with the code of all three windows in one kernel they spilled 24-54 registers, so THEIR kernels are instantiated
+// per window (k_fft_pass WIN) and each carries one loop.
+template <typename T, int FIXED, bool INV, class LATTICE>
 __device__ __forceinline__ void pass_window16(const FftIo<T>& io, size_t i0, size_t n, cpx<T> (&v)[16], LATTICE lattice)
 {
     const size_t i1 = n / 16 - 1 - i0;
@@ -464,7 +464,8 @@ __device__ __forceinline__ void pass_window16(const FftIo<T>& io, size_t i0, siz
         if (INV) w = (T)1 / w;
         v[reg] = cpx<T>{v[reg].x * w, v[reg].y * w};
     };
-    if (!HAMMING_ONLY && io.window_id == 0) {
+    const int wid = FIXED >= 0 ? FIXED : io.window_id;
+    if (wid == 0) {
         const T b0 = ((T)i0 - ((T)n - (T)1) / (T)2) / ((T)n / (T)2), b1 = ((T)i1 - ((T)n - (T)1) / (T)2) / ((T)n / (T)2);
         const T step = (T)0.125; // (n/16) / (n/2)
 #pragma unroll
@@ -478,7 +479,7 @@ __device__ __forceinline__ void pass_window16(const FftIo<T>& io, size_t i0, siz
     T s0, c0, s1, c1;
     dev_sincospi<T>((T)i0 * two_over, &s0, &c0);
     dev_sincospi<T>((T)i1 * two_over, &s1, &c1);
-    if (HAMMING_ONLY || io.window_id == 1) {
+    if (wid == 1) {
         const T beta = (T)1 - io.window_alpha;
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
@@ -504,7 +505,9 @@ __device__ __forceinline__ void pass_window16(const FftIo<T>& io, size_t i0, siz
 // RP2 x W2 block, and the first pass still stores whole lines (W1 x W2 adjacent values per k1 group, lanes along the
 // columns).  TL = 1: first pass, tiled store (aux = log2 W2); TL = 2: last pass, tiled load.  The natural-order input of
 // the first pass and output of the last keep their W-wide runs.
-template <typename T, int RP, int W, int DIR, bool ROWMAP, bool GEN, bool SIMPLE = false, int TL = 0>
+// WIN: -1 = the window id is read at run time (and is Hamming / Hann where the tile uses the split exchange); 0 / 2: the
+// split-exchange tiles' instantiations for the triangular and the Blackman-Harris window (pass_window16 FIXED).
+template <typename T, int RP, int W, int DIR, bool ROWMAP, bool GEN, bool SIMPLE = false, int TL = 0, int WIN = -1>
 __global__ __launch_bounds__(W * (RP / 16), (pass_min_waves<T, RP, W, GEN>())) void k_fft_pass(FftIo<T> io, const cpx<T>* src, // (src may equal dst: the in-place last pass)
                                                    cpx<T>* dst,
                                                    const cpx<T>* __restrict__ wtab, size_t n,
@@ -579,7 +582,7 @@ __global__ __launch_bounds__(W * (RP / 16), (pass_min_waves<T, RP, W, GEN>())) v
         }
         if (!SIMPLE && ROWMAP && io.window_id >= 0 && io.window_id <= 2 && !(io.flags & FFT_WINDOW_OUT_DIV)) {
             // the window on the input, in registers: register r holds row q = r ^ rx (rx is 0 or 8), i.e. lattice point q
-            pass_window16<T, SPLIT, false>(io, j + (size_t)ti * stride_in, n, v, [&](int r) { return r ^ rx; });
+            pass_window16<T, (SPLIT ? (WIN >= 0 ? WIN : 1) : -1), false>(io, j + (size_t)ti * stride_in, n, v, [&](int r) { return r ^ rx; });
         }
     }
     if (!ROWMAP) { // (nsg > 1 exactly on the later passes)
@@ -683,7 +686,7 @@ __global__ __launch_bounds__(W * (RP / 16), (pass_min_waves<T, RP, W, GEN>())) v
             // windowed_ifft: the division by the window in the registers of the last pass (round 4; before: the staged
             // loop, 16M points f32 150 us for Hamming and 181 for Blackman-Harris against 133 for ifft).  Register
             // b RL + r goes to row t2 + (b + (r ^ sx) 16/RL) RP/16, i.e. lattice point b + (r ^ sx) 16/RL of jj + t2 n/RP
-            pass_window16<T, SPLIT, true>(io, jj + (size_t)t2 * nsg, n, v, [&](int reg) { return reg / RL + ((reg % RL) ^ sx) * (16 / RL); });
+            pass_window16<T, (SPLIT ? (WIN >= 0 ? WIN : 1) : -1), true>(io, jj + (size_t)t2 * nsg, n, v, [&](int reg) { return reg / RL + ((reg % RL) ^ sx) * (16 / RL); });
         }
         if (!SIMPLE && last && !ROWMAP && (io.flags & (BDSP_FFT_MAGNITUDE | FFT_OUT_REAL))) {
             // magnitude / real part straight from the registers: `points` reals per vector
@@ -993,10 +996,10 @@ static int launch_pass(const FftIo<T>& io_in, const cpx<T>* src, cpx<T>* dst, si
     size_t tiles = (n / RP) / W;
     dim3 grid((unsigned)(tiles * batch));
     const bool rowmap = nsg == 1; // the first pass
-    // (triangular / Blackman-Harris on a split-exchange f64 tile: the staged loop, see k_fft_pass)
-    const bool win_staged = (io.window_id == 0 || io.window_id == 2) && pass_split_exchange<T, RP, W, false>() &&
-                            ((first && !(io.flags & FFT_WINDOW_OUT_DIV)) || (last && (io.flags & FFT_WINDOW_OUT_DIV)));
-    const bool gen = (first && io_in_generic(io)) || (last && io_out_generic(io)) || win_staged;
+    const bool gen = (first && io_in_generic(io)) || (last && io_out_generic(io));
+    // (triangular / Blackman-Harris on a split-exchange f64 tile: the kernel instantiated for that window, see k_fft_pass)
+    const bool win_here = io.window_id >= 0 && ((first && !(io.flags & FFT_WINDOW_OUT_DIV)) || (last && (io.flags & FFT_WINDOW_OUT_DIV)));
+    const int win_fixed = (!gen && win_here && pass_split_exchange<T, RP, W, false>() && (io.window_id == 0 || io.window_id == 2)) ? io.window_id : -1;
     if (first && !gen) src = reinterpret_cast<const cpx<T>*>(io.in);
     if (last && !gen) dst = reinterpret_cast<cpx<T>*>(io.out);
     // plain first / last pass?  (then no option is looked at inside the kernel)
@@ -1004,17 +1007,25 @@ static int launch_pass(const FftIo<T>& io_in, const cpx<T>* src, cpx<T>* dst, si
                                         : (!last || (io.flags & (BDSP_FFT_SHIFT_OUT | BDSP_FFT_MAGNITUDE | FFT_OUT_REAL | FFT_WINDOW_OUT_DIV)) == 0));
     // (tiled instantiations exist for the long columns only: pass_tiled_pair)
     if (tl != 0 && (!pass_tiled_pair<RP>() || (tl == 1) != rowmap)) { set_last_error("tiled intermediate: unsupported pass"); return BDSP_ERR_UNSUPPORTED; }
-#define BDSP_PASS(DIRV, RM, GENV, SV, TLV)                                                         \
+#define BDSP_PASS(DIRV, RM, GENV, SV, TLV, WINV)                                                   \
     do {                                                                                           \
         constexpr size_t lds = pass_tile_lds_bytes<T, RP, W, GENV>() +                             \
                                (pass_lds_twiddles<T, RP, W, GENV>() ? (size_t)RP * sizeof(cpx<T>) : 0); \
-        BDSP_TRY(set_lds(k_fft_pass<T, RP, W, DIRV, RM, GENV, SV, TLV>, lds));                     \
-        hipLaunchKernelGGL((k_fft_pass<T, RP, W, DIRV, RM, GENV, SV, TLV>), grid, dim3(THREADS), lds, s, \
+        BDSP_TRY(set_lds(k_fft_pass<T, RP, W, DIRV, RM, GENV, SV, TLV, WINV>, lds));               \
+        hipLaunchKernelGGL((k_fft_pass<T, RP, W, DIRV, RM, GENV, SV, TLV, WINV>), grid, dim3(THREADS), lds, s, \
                            io, src, dst, wtab, n, nsg, tiles, (int)last, aux);                     \
     } while (0)
 #define BDSP_PASS_V(DIRV, RM, TLV)                                                                 \
     do {                                                                                           \
-        if (gen) BDSP_PASS(DIRV, RM, true, false, TLV); else if (simple) BDSP_PASS(DIRV, RM, false, true, TLV); else BDSP_PASS(DIRV, RM, false, false, TLV); \
+        if (gen) BDSP_PASS(DIRV, RM, true, false, TLV, -1);                                        \
+        else if (simple) BDSP_PASS(DIRV, RM, false, true, TLV, -1);                                \
+        else {                                                                                     \
+            if constexpr (pass_split_exchange<T, RP, W, false>() && TLV == 0) {                    \
+                if (win_fixed == 0) { BDSP_PASS(DIRV, RM, false, false, TLV, 0); break; }          \
+                if (win_fixed == 2) { BDSP_PASS(DIRV, RM, false, false, TLV, 2); break; }          \
+            }                                                                                      \
+            BDSP_PASS(DIRV, RM, false, false, TLV, -1);                                            \
+        }                                                                                          \
     } while (0)
 #define BDSP_PASS_D(DIRV)                                                                          \
     do {                                                                                           \
