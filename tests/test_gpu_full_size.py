@@ -372,6 +372,10 @@ def test_bench_py_runs_both_modes_and_prints_the_contract_fields():
     fc = d["config"]["first_call_ms"]
     assert fc and "error" not in fc, fc
     assert fc["plain_fft_first_ms"] > fc["plain_fft_third_ms"] > 0 and fc["convolve_signal_first_ms"] >= fc["convolve_signal_third_ms"] > 0
+    # the two kernels' event-derived durations add up to (almost) the step: an over-subtracted event-pair overhead would
+    # inflate both fractions (seen at --steps 200 before the overhead became the smallest of its samples)
+    k = d["kernels"]
+    assert 0.85 * d["ms_per_step"] < k["conv_ms"] + k["fft_ms"] <= 1.02 * d["ms_per_step"], (k, d["ms_per_step"])
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["fair_allcores_Msamples_s"] > 0
     p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--mode", "c5", "--steps", "4", "--warmup", "1",
                         "--prewarm", "0.02", "--vectors-per-gpu", "16", "--no-cpu-baseline"], env=env, capture_output=True,
