@@ -30,6 +30,55 @@ def timeit(fn, iters=20):
     ms = C.c_float(0); lib.bdsp_hip_event_elapsed_ms(e0, e1, C.byref(ms))
     return ms.value / iters * 1e3
 
+_EV_OVERHEAD = None
+
+
+def event_overhead_us():
+    """what an event pair costs by itself on this stream (the smallest of twenty samples)"""
+    global _EV_OVERHEAD
+    if _EV_OVERHEAD is None:
+        v = []
+        ms = C.c_float(0)
+        for _ in range(20):
+            a, b = lib.bdsp_hip_event_create(), lib.bdsp_hip_event_create()
+            lib.bdsp_hip_event_record(a, sp); lib.bdsp_hip_event_record(b, sp)
+            lib.bdsp_hip_event_elapsed_ms(a, b, C.byref(ms)); v.append(ms.value * 1e3)
+            lib.bdsp_hip_event_destroy(a); lib.bdsp_hip_event_destroy(b)
+        _EV_OVERHEAD = min(v)
+    return _EV_OVERHEAD
+
+
+def timeit_restored(fn, restore, iters=20):
+    """For calls that CLOBBER their input (the in-place transforms): an untimed `restore(i)` puts valid data back before
+    call i, and every call carries its own event pair (median of the deltas minus the cost of an empty pair).  Round 4:
+    without the restore a loop of in-place transforms feeds each call the previous call's output -- the values grow by
+    sqrt(n) per call and are inf / NaN long before the timed region, and kernels run measurably faster on such constant
+    bit patterns than on data (config C4b, whose inputs config C4a had left that way: 54-56 us against 68-70)."""
+    import time as _t
+    if QUICK: iters = 2
+    # (the buffer of call i + 1 is restored before call i runs, so that a restored input has been pushed out of the 256 MB
+    # Infinity Cache by a whole call's traffic when its turn comes -- for the 64-128 MB inputs; the small ones stay warm)
+    restore(0)
+    t0 = _t.perf_counter(); k = 0
+    while _t.perf_counter() - t0 < (0.0 if QUICK else 0.15):
+        for _ in range(5): restore(k + 1); fn(k); k += 1
+        torch.cuda.synchronize()
+    restore(0)
+    pairs = []
+    for i in range(iters):
+        restore(i + 1)
+        a, b = lib.bdsp_hip_event_create(), lib.bdsp_hip_event_create()
+        lib.bdsp_hip_event_record(a, sp); fn(i); lib.bdsp_hip_event_record(b, sp)
+        pairs.append((a, b))
+    torch.cuda.synchronize()
+    ms = C.c_float(0); d = []
+    for a, b in pairs:
+        lib.bdsp_hip_event_elapsed_ms(a, b, C.byref(ms)); d.append(ms.value * 1e3)
+        lib.bdsp_hip_event_destroy(a); lib.bdsp_hip_event_destroy(b)
+    d.sort()
+    return d[len(d) // 2] - event_overhead_us()
+
+
 def report(name, us, units, bytes_per_unit, unit_name):
     gbs = units * bytes_per_unit / us / 1e3
     print(json.dumps({"config": name, "us": round(us, 2), "M%s_per_s" % unit_name: round(units / us, 1),
@@ -38,8 +87,9 @@ def report(name, us, units, bytes_per_unit, unit_name):
 def rnd(n, dt, k=3):
     return [torch.rand(n, device=dev, dtype=dt) * 20 - 10 for _ in range(k)]
 
-x = rnd(65536, torch.float32, 1)[0]
-us = timeit(lambda i: (lib.bdsp_hip_dev_real_scale(0, x.data_ptr(), 65536, 2.5, sp), lib.bdsp_hip_dev_real_offset(0, x.data_ptr(), 65536, 0, -1.25, sp)))
+x = rnd(65536, torch.float32, 1)[0]; x0 = x.clone()
+us = timeit_restored(lambda i: (lib.bdsp_hip_dev_real_scale(0, x.data_ptr(), 65536, 2.5, sp), lib.bdsp_hip_dev_real_offset(0, x.data_ptr(), 65536, 0, -1.25, sp)),
+                     lambda i: x.copy_(x0), 50)
 report("C1 real f32 65536: scale+offset (2 launches, launch-bound)", us, 65536, 16, "samples")
 n = 1 << 26
 xb = rnd(n, torch.float32, 2)
@@ -48,14 +98,16 @@ report("C1' real f32 64M: scale (bandwidth regime)", us, n, 8, "samples")
 del xb
 
 n = 1 << 20
-xs = rnd(2 * n, torch.float32); sc = torch.empty(2 * n, device=dev, dtype=torch.float32)
-us = timeit(lambda i: lib.bdsp_hip_dev_fft(0, xs[i % 3].data_ptr(), sc.data_ptr(), n, 1, FFT_MAGNITUDE, 1.0, -1, 0.0, C.byref(flag), sp))
+xs = rnd(2 * n, torch.float32); sc = torch.empty(2 * n, device=dev, dtype=torch.float32); pristine = rnd(2 * n, torch.float32, 1)[0]
+us = timeit_restored(lambda i: lib.bdsp_hip_dev_fft(0, xs[i % 3].data_ptr(), sc.data_ptr(), n, 1, FFT_MAGNITUDE, 1.0, -1, 0.0, C.byref(flag), sp),
+                     lambda i: xs[i % 3].copy_(pristine), 40)
 report("C2 complex f32 1M: plain_fft->magnitude fused (2 passes, latency-bound)", us, n, 12, "points")
 b = 64
-xs = rnd(2 * n * b, torch.float32, 2); sc = torch.empty(2 * n * b, device=dev, dtype=torch.float32)
-us = timeit(lambda i: lib.bdsp_hip_dev_fft(0, xs[i % 2].data_ptr(), sc.data_ptr(), n, b, FFT_MAGNITUDE, 1.0, -1, 0.0, C.byref(flag), sp), 10)
+xs = rnd(2 * n * b, torch.float32, 2); sc = torch.empty(2 * n * b, device=dev, dtype=torch.float32); pristine = rnd(2 * n * b, torch.float32, 1)[0]
+us = timeit_restored(lambda i: lib.bdsp_hip_dev_fft(0, xs[i % 2].data_ptr(), sc.data_ptr(), n, b, FFT_MAGNITUDE, 1.0, -1, 0.0, C.byref(flag), sp),
+                     lambda i: xs[i % 2].copy_(pristine), 10)
 report("C2x64 64 x complex f32 1M: plain_fft->magnitude fused", us, n * b, 12, "points")
-del xs, sc
+del xs, sc, pristine
 
 n, m = 1 << 24, 1024
 xs = rnd(2 * n, torch.float32); y = torch.empty(2 * n, device=dev, dtype=torch.float32)
@@ -70,28 +122,37 @@ xd = rnd(2 * n, torch.float64, 2); yd = torch.empty(2 * n, device=dev, dtype=tor
 us = timeit(lambda i: lib.bdsp_hip_dev_convolve(1, xd[i % 2].data_ptr(), yd.data_ptr(), n, 1, td.data_ptr(), m, sp), 10)
 report("C3 in f64: complex f64 16M (*) 1024 taps", us, n, 32, "samples")
 del xd, yd
-us = timeit(lambda i: lib.bdsp_hip_dev_fft(0, xs[i % 3].data_ptr(), y.data_ptr(), n, 1, 0, 1.0, -1, 0.0, C.byref(flag), sp))
+xf = [t.clone() for t in xs]  # (the transform clobbers its input: restored from xs before every call)
+us = timeit_restored(lambda i: lib.bdsp_hip_dev_fft(0, xf[i % 3].data_ptr(), y.data_ptr(), n, 1, 0, 1.0, -1, 0.0, C.byref(flag), sp),
+                     lambda i: xf[i % 3].copy_(xs[i % 3]))
 report("FFT complex f32 16M: plain_fft (3 passes)", us, n, 16, "points")
+del xf
 # real signal, real taps through the facade (B2): two real blocks per complex transform pair
 import numpy as np
 from basic_dsp_amd import DspVec
 rv = [DspVec(np.random.rand(n).astype(np.float32) * 20 - 10) for _ in range(3)]
 rh = DspVec((np.random.rand(m).astype(np.float32) * 2 - 1) / m)
-def real_conv(i): rv[i % 3].convolve_signal(rh)
 import time as _tm
-for i in range(30): real_conv(i)
-lib.bdsp_hip_synchronize(None)
-_t0 = _tm.perf_counter()
-for i in range(200): real_conv(i)
-lib.bdsp_hip_synchronize(None)
-report("C3 on REAL data: real f32 16M (*) 1024 real taps, through the facade (incl. host call)", (_tm.perf_counter() - _t0) / 200 * 1e6, n, 8, "samples")
+_tot = 0.0
+for i in range(-20, 100):  # (the facade's convolve_signal works in place: every call gets a fresh clone of its input, untimed)
+    w = rv[i % 3].clone()
+    lib.bdsp_hip_synchronize(None)
+    _t0 = _tm.perf_counter()
+    w.convolve_signal(rh)
+    lib.bdsp_hip_synchronize(None)
+    if i >= 0: _tot += _tm.perf_counter() - _t0
+    del w
+report("C3 on REAL data: real f32 16M (*) 1024 real taps, through the facade (host call + synchronise included)", _tot / 100 * 1e6, n, 8, "samples")
 del rv
 del xs, y
 
 n = 1 << 22
 xs = rnd(2 * n, torch.float64); sc = torch.empty(2 * n, device=dev, dtype=torch.float64)
-us = timeit(lambda i: lib.bdsp_hip_dev_fft(1, xs[i % 3].data_ptr(), sc.data_ptr(), n, 1, FFT_SHIFT_OUT, 1.0, 4, 0.5, C.byref(flag), sp))
+xf = [t.clone() for t in xs]  # (clobbered by the transform: restored from xs before every call)
+us = timeit_restored(lambda i: lib.bdsp_hip_dev_fft(1, xf[i % 3].data_ptr(), sc.data_ptr(), n, 1, FFT_SHIFT_OUT, 1.0, 4, 0.5, C.byref(flag), sp),
+                     lambda i: xf[i % 3].copy_(xs[i % 3]), 30)
 report("C4a complex f64 4M: windowed_fft(Hann) fused window+fft+shift", us, n, 32, "points")
+del xf
 # ONE protocol for C4b (round 4): three rotating inputs (64 MB each) AND three rotating outputs (256 MB each), like the
 # headline's rotating inputs -- neither side of the operation finds its data in the 256 MB Infinity Cache; 30 calls
 outs = [torch.empty(8 * n, device=dev, dtype=torch.float64) for _ in range(3)]
@@ -101,8 +162,9 @@ del xs, sc, outs
 
 n, b = 1 << 20, 64
 xs = rnd(2 * n * b, torch.float32, 2); y = torch.empty(2 * n * b, device=dev, dtype=torch.float32)
-def c5(i):
+sc5 = torch.empty(2 * n * b, device=dev, dtype=torch.float32)
+def c5(i):  # (the transform ping-pongs between the convolution's result and its OWN scratch: the inputs stay valid)
     lib.bdsp_hip_dev_convolve(0, xs[i % 2].data_ptr(), y.data_ptr(), n, b, taps.data_ptr(), m, sp)
-    lib.bdsp_hip_dev_fft(0, y.data_ptr(), xs[i % 2].data_ptr(), n, b, 0, 1.0, -1, 0.0, C.byref(flag), sp)
+    lib.bdsp_hip_dev_fft(0, y.data_ptr(), sc5.data_ptr(), n, b, 0, 1.0, -1, 0.0, C.byref(flag), sp)
 us = timeit(c5, 10)
 report("C5/GPU 64 x complex f32 1M: convolve_signal -> fft (compute only)", us, n * b, 32, "samples")

@@ -39,21 +39,34 @@ o = run(FFT_MAGNITUDE | FFT_SHIFT_OUT); print("fft shift->magn. rel-L2 %.3e" % r
 
 
 def timeit(fn, iters=200):
+    """Every call gets its input restored first (untimed copy; the transform clobbers it -- a loop of in-place transforms
+    otherwise runs on inf / NaN after a few dozen calls) and carries its own event pair."""
     import time
-    t0 = time.perf_counter(); k = 0
-    while time.perf_counter() - t0 < 0.2:
-        for _ in range(10): fn(k); k += 1
-        torch.cuda.synchronize()
-    e0, e1 = lib.bdsp_hip_event_create(), lib.bdsp_hip_event_create()
-    lib.bdsp_hip_event_record(e0, sp)
-    for i in range(iters): fn(i)
-    lib.bdsp_hip_event_record(e1, sp)
+    for k in range(300):
+        xs[(k + 1) % 3].copy_(pristine); fn(k)
     torch.cuda.synchronize()
-    ms = C.c_float(0); lib.bdsp_hip_event_elapsed_ms(e0, e1, C.byref(ms))
-    return ms.value / iters * 1e3
+    ov = []
+    ms = C.c_float(0)
+    for _ in range(20):
+        a, b = lib.bdsp_hip_event_create(), lib.bdsp_hip_event_create()
+        lib.bdsp_hip_event_record(a, sp); lib.bdsp_hip_event_record(b, sp)
+        lib.bdsp_hip_event_elapsed_ms(a, b, C.byref(ms)); ov.append(ms.value * 1e3)
+    pairs = []
+    for i in range(iters):
+        xs[(i + 1) % 3].copy_(pristine)
+        a, b = lib.bdsp_hip_event_create(), lib.bdsp_hip_event_create()
+        lib.bdsp_hip_event_record(a, sp); fn(i); lib.bdsp_hip_event_record(b, sp)
+        pairs.append((a, b))
+    torch.cuda.synchronize()
+    d = []
+    for a, b in pairs:
+        lib.bdsp_hip_event_elapsed_ms(a, b, C.byref(ms)); d.append(ms.value * 1e3)
+    d.sort()
+    return d[len(d) // 2] - min(ov)
 
 
-xs = [torch.rand(2 * n, device=dev, dtype=torch.float32) * 20 - 10 for _ in range(3)]
+pristine = torch.rand(2 * n, device=dev, dtype=torch.float32) * 20 - 10
+xs = [pristine.clone() for _ in range(3)]
 sc = torch.empty(2 * n, device=dev, dtype=torch.float32)
 us = timeit(lambda i: lib.bdsp_hip_dev_fft(0, xs[i % 3].data_ptr(), sc.data_ptr(), n, 1, FFT_MAGNITUDE, 1.0, -1, 0.0, C.byref(flag), sp))
 print("C2 plain_fft->magnitude: %.2f us   (%s%s)" % (us, os.path.basename(bd.LIB_PATH), ", BDSP_FFT_H512" if os.environ.get("BDSP_FFT_H512") else ""))
