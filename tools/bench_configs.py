@@ -48,27 +48,45 @@ def event_overhead_us():
     return _EV_OVERHEAD
 
 
-def timeit_restored(fn, restore, iters=20):
-    """For calls that CLOBBER their input (the in-place transforms): an untimed `restore(i)` puts valid data back before
-    call i, and every call carries its own event pair (median of the deltas minus the cost of an empty pair).  Round 4:
-    without the restore a loop of in-place transforms feeds each call the previous call's output -- the values grow by
-    sqrt(n) per call and are inf / NaN long before the timed region, and kernels run measurably faster on such constant
-    bit patterns than on data (config C4b, whose inputs config C4a had left that way: 54-56 us against 68-70)."""
+def timeit_fresh(call, pristine, iters=20):
+    """For calls that CLOBBER their input (the in-place transforms): `call(buf)` runs on a buffer that holds valid data and
+    is used exactly ONCE in the timed loop -- `iters` copies of `pristine` are made beforehand (288 GB of HBM: room is not
+    the problem), so every call reads a cold, valid input and nothing untimed runs between the calls; the pre-warm runs on
+    three more buffers that are restored before each use.  One event pair around the loop.
+    Round 4: a loop of in-place transforms on the same buffers feeds each call the previous call's output -- the values
+    grow by sqrt(n) per call and are inf / NaN long before the timed region, and kernels run measurably faster on such
+    constant bit patterns than on data (config C4b, whose inputs config C4a had left that way: 54-56 us against 68-74)."""
     import time as _t
     if QUICK: iters = 2
-    # (the buffer of call i + 1 is restored before call i runs, so that a restored input has been pushed out of the 256 MB
-    # Infinity Cache by a whole call's traffic when its turn comes -- for the 64-128 MB inputs; the small ones stay warm)
-    restore(0)
+    warm = [pristine.clone() for _ in range(3)]
+    bufs = [pristine.clone() for _ in range(iters)]
     t0 = _t.perf_counter(); k = 0
     while _t.perf_counter() - t0 < (0.0 if QUICK else 0.15):
-        for _ in range(5): restore(k + 1); fn(k); k += 1
+        for _ in range(5):
+            warm[k % 3].copy_(pristine); call(warm[k % 3]); k += 1
         torch.cuda.synchronize()
-    restore(0)
+    e0, e1 = lib.bdsp_hip_event_create(), lib.bdsp_hip_event_create()
+    lib.bdsp_hip_event_record(e0, sp)
+    for i in range(iters): call(bufs[i])
+    lib.bdsp_hip_event_record(e1, sp)
+    ms = C.c_float(0); lib.bdsp_hip_event_elapsed_ms(e0, e1, C.byref(ms))
+    del bufs, warm
+    return ms.value / iters * 1e3
+
+
+def timeit_hot(call, pristine, iters=20):
+    """The same call on an input that was written just before it (an untimed copy from `pristine` into one of three buffers
+    right before every call: the input is then in the caches, as after a producer kernel); one event pair per call, median
+    of the deltas minus the cost of an empty pair."""
+    if QUICK: return None
+    bufs = [pristine.clone() for _ in range(3)]
+    for k in range(20):
+        bufs[k % 3].copy_(pristine); call(bufs[k % 3])
     pairs = []
     for i in range(iters):
-        restore(i + 1)
+        bufs[i % 3].copy_(pristine)
         a, b = lib.bdsp_hip_event_create(), lib.bdsp_hip_event_create()
-        lib.bdsp_hip_event_record(a, sp); fn(i); lib.bdsp_hip_event_record(b, sp)
+        lib.bdsp_hip_event_record(a, sp); call(bufs[i % 3]); lib.bdsp_hip_event_record(b, sp)
         pairs.append((a, b))
     torch.cuda.synchronize()
     ms = C.c_float(0); d = []
@@ -79,17 +97,20 @@ def timeit_restored(fn, restore, iters=20):
     return d[len(d) // 2] - event_overhead_us()
 
 
-def report(name, us, units, bytes_per_unit, unit_name):
+def report(name, us, units, bytes_per_unit, unit_name, us_hot=None):
     gbs = units * bytes_per_unit / us / 1e3
-    print(json.dumps({"config": name, "us": round(us, 2), "M%s_per_s" % unit_name: round(units / us, 1),
-                      "algorithmic_GBs": round(gbs, 1), "roofline_frac": round(gbs / PEAK, 4)}))
+    row = {"config": name, "us": round(us, 2), "M%s_per_s" % unit_name: round(units / us, 1),
+           "algorithmic_GBs": round(gbs, 1), "roofline_frac": round(gbs / PEAK, 4)}
+    if us_hot is not None:
+        row["us_input_in_cache"] = round(us_hot, 2)
+        row["roofline_frac_input_in_cache"] = round(units * bytes_per_unit / us_hot / 1e3 / PEAK, 4)
+    print(json.dumps(row))
 
 def rnd(n, dt, k=3):
     return [torch.rand(n, device=dev, dtype=dt) * 20 - 10 for _ in range(k)]
 
-x = rnd(65536, torch.float32, 1)[0]; x0 = x.clone()
-us = timeit_restored(lambda i: (lib.bdsp_hip_dev_real_scale(0, x.data_ptr(), 65536, 2.5, sp), lib.bdsp_hip_dev_real_offset(0, x.data_ptr(), 65536, 0, -1.25, sp)),
-                     lambda i: x.copy_(x0), 50)
+x0 = rnd(65536, torch.float32, 1)[0]
+us = timeit_fresh(lambda b: (lib.bdsp_hip_dev_real_scale(0, b.data_ptr(), 65536, 2.5, sp), lib.bdsp_hip_dev_real_offset(0, b.data_ptr(), 65536, 0, -1.25, sp)), x0, 100)
 report("C1 real f32 65536: scale+offset (2 launches, launch-bound)", us, 65536, 16, "samples")
 n = 1 << 26
 xb = rnd(n, torch.float32, 2)
@@ -98,16 +119,15 @@ report("C1' real f32 64M: scale (bandwidth regime)", us, n, 8, "samples")
 del xb
 
 n = 1 << 20
-xs = rnd(2 * n, torch.float32); sc = torch.empty(2 * n, device=dev, dtype=torch.float32); pristine = rnd(2 * n, torch.float32, 1)[0]
-us = timeit_restored(lambda i: lib.bdsp_hip_dev_fft(0, xs[i % 3].data_ptr(), sc.data_ptr(), n, 1, FFT_MAGNITUDE, 1.0, -1, 0.0, C.byref(flag), sp),
-                     lambda i: xs[i % 3].copy_(pristine), 40)
-report("C2 complex f32 1M: plain_fft->magnitude fused (2 passes, latency-bound)", us, n, 12, "points")
+sc = torch.empty(2 * n, device=dev, dtype=torch.float32); pristine = rnd(2 * n, torch.float32, 1)[0]
+c2 = lambda b: lib.bdsp_hip_dev_fft(0, b.data_ptr(), sc.data_ptr(), n, 1, FFT_MAGNITUDE, 1.0, -1, 0.0, C.byref(flag), sp)
+us = timeit_fresh(c2, pristine, 60)
+report("C2 complex f32 1M: plain_fft->magnitude fused (2 passes, latency-bound); every input valid, cold, used once", us, n, 12, "points", timeit_hot(c2, pristine, 60))
 b = 64
-xs = rnd(2 * n * b, torch.float32, 2); sc = torch.empty(2 * n * b, device=dev, dtype=torch.float32); pristine = rnd(2 * n * b, torch.float32, 1)[0]
-us = timeit_restored(lambda i: lib.bdsp_hip_dev_fft(0, xs[i % 2].data_ptr(), sc.data_ptr(), n, b, FFT_MAGNITUDE, 1.0, -1, 0.0, C.byref(flag), sp),
-                     lambda i: xs[i % 2].copy_(pristine), 10)
+sc = torch.empty(2 * n * b, device=dev, dtype=torch.float32); pristine = rnd(2 * n * b, torch.float32, 1)[0]
+us = timeit_fresh(lambda bf: lib.bdsp_hip_dev_fft(0, bf.data_ptr(), sc.data_ptr(), n, b, FFT_MAGNITUDE, 1.0, -1, 0.0, C.byref(flag), sp), pristine, 10)
 report("C2x64 64 x complex f32 1M: plain_fft->magnitude fused", us, n * b, 12, "points")
-del xs, sc, pristine
+del sc, pristine
 
 n, m = 1 << 24, 1024
 xs = rnd(2 * n, torch.float32); y = torch.empty(2 * n, device=dev, dtype=torch.float32)
@@ -122,11 +142,9 @@ xd = rnd(2 * n, torch.float64, 2); yd = torch.empty(2 * n, device=dev, dtype=tor
 us = timeit(lambda i: lib.bdsp_hip_dev_convolve(1, xd[i % 2].data_ptr(), yd.data_ptr(), n, 1, td.data_ptr(), m, sp), 10)
 report("C3 in f64: complex f64 16M (*) 1024 taps", us, n, 32, "samples")
 del xd, yd
-xf = [t.clone() for t in xs]  # (the transform clobbers its input: restored from xs before every call)
-us = timeit_restored(lambda i: lib.bdsp_hip_dev_fft(0, xf[i % 3].data_ptr(), y.data_ptr(), n, 1, 0, 1.0, -1, 0.0, C.byref(flag), sp),
-                     lambda i: xf[i % 3].copy_(xs[i % 3]))
-report("FFT complex f32 16M: plain_fft (3 passes)", us, n, 16, "points")
-del xf
+f16 = lambda b: lib.bdsp_hip_dev_fft(0, b.data_ptr(), y.data_ptr(), n, 1, 0, 1.0, -1, 0.0, C.byref(flag), sp)
+us = timeit_fresh(f16, xs[0], 20)
+report("FFT complex f32 16M: plain_fft (3 passes); every input valid, cold, used once", us, n, 16, "points", timeit_hot(f16, xs[0], 20))
 # real signal, real taps through the facade (B2): two real blocks per complex transform pair
 import numpy as np
 from basic_dsp_amd import DspVec
@@ -148,11 +166,9 @@ del xs, y
 
 n = 1 << 22
 xs = rnd(2 * n, torch.float64); sc = torch.empty(2 * n, device=dev, dtype=torch.float64)
-xf = [t.clone() for t in xs]  # (clobbered by the transform: restored from xs before every call)
-us = timeit_restored(lambda i: lib.bdsp_hip_dev_fft(1, xf[i % 3].data_ptr(), sc.data_ptr(), n, 1, FFT_SHIFT_OUT, 1.0, 4, 0.5, C.byref(flag), sp),
-                     lambda i: xf[i % 3].copy_(xs[i % 3]), 30)
-report("C4a complex f64 4M: windowed_fft(Hann) fused window+fft+shift", us, n, 32, "points")
-del xf
+c4a = lambda b: lib.bdsp_hip_dev_fft(1, b.data_ptr(), sc.data_ptr(), n, 1, FFT_SHIFT_OUT, 1.0, 4, 0.5, C.byref(flag), sp)
+us = timeit_fresh(c4a, xs[0], 30)
+report("C4a complex f64 4M: windowed_fft(Hann) fused window+fft+shift; every input valid, cold, used once", us, n, 32, "points", timeit_hot(c4a, xs[0], 30))
 # ONE protocol for C4b (round 4): three rotating inputs (64 MB each) AND three rotating outputs (256 MB each), like the
 # headline's rotating inputs -- neither side of the operation finds its data in the 256 MB Infinity Cache; 30 calls
 outs = [torch.empty(8 * n, device=dev, dtype=torch.float64) for _ in range(3)]
