@@ -68,6 +68,22 @@ def timeit(fn, iters=200):
 pristine = torch.rand(2 * n, device=dev, dtype=torch.float32) * 20 - 10
 xs = [pristine.clone() for _ in range(3)]
 sc = torch.empty(2 * n, device=dev, dtype=torch.float32)
+def timeit_cold(flags, iters=200):
+    """every call on its own copy of the input, used once: a cold 8 MB read per call; one event pair around the loop"""
+    bufs = [pristine.clone() for _ in range(iters)]
+    for k in range(300):
+        xs[k % 3].copy_(pristine); lib.bdsp_hip_dev_fft(0, xs[k % 3].data_ptr(), sc.data_ptr(), n, 1, flags, 1.0, -1, 0.0, C.byref(flag), sp)
+    torch.cuda.synchronize()
+    e0, e1 = lib.bdsp_hip_event_create(), lib.bdsp_hip_event_create()
+    lib.bdsp_hip_event_record(e0, sp)
+    for b_ in bufs: lib.bdsp_hip_dev_fft(0, b_.data_ptr(), sc.data_ptr(), n, 1, flags, 1.0, -1, 0.0, C.byref(flag), sp)
+    lib.bdsp_hip_event_record(e1, sp)
+    torch.cuda.synchronize()
+    ms = C.c_float(0); lib.bdsp_hip_event_elapsed_ms(e0, e1, C.byref(ms))
+    return ms.value / iters * 1e3
+
+
+print("C2 COLD input: plain_fft->magnitude %.2f us, plain_fft %.2f us" % (timeit_cold(FFT_MAGNITUDE), timeit_cold(0)))
 us = timeit(lambda i: lib.bdsp_hip_dev_fft(0, xs[i % 3].data_ptr(), sc.data_ptr(), n, 1, FFT_MAGNITUDE, 1.0, -1, 0.0, C.byref(flag), sp))
 print("C2 plain_fft->magnitude: %.2f us   (%s%s)" % (us, os.path.basename(bd.LIB_PATH), ", BDSP_FFT_H512" if os.environ.get("BDSP_FFT_H512") else ""))
 us = timeit(lambda i: lib.bdsp_hip_dev_fft(0, xs[i % 3].data_ptr(), sc.data_ptr(), n, 1, 0, 1.0, -1, 0.0, C.byref(flag), sp))
