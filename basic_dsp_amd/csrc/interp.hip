@@ -343,6 +343,93 @@ __global__ __launch_bounds__(256) void k_interp_scalar(const T* __restrict__ x, 
     }
 }
 
+// Round 4: the scalar path again, two to three times faster (fractional factors are what interpolatef is FOR: 44.1 -> 48 kHz
+// is a factor of 1.088).  Same arithmetic as k_interp_scalar where the reference's rounding matters -- j accumulated in
+// T, the sum taken tap by tap in the reference's order with the (w, 0) complex product spelled out -- but per tap
+//   * the raised cosine's cos(pi beta (j0 + k)) = cb0 C_k - sb0 S_k from a per-launch LDS table of cos / sin(pi beta k)
+//     (k = 0 .. 2L, built in double) instead of a four-multiply-add rotation in double carried from tap to tap,
+//   * ONE division: sj c / (pi j (1 - (2 beta j)^2)) (the reference divides twice; the quotient differs by an ulp),
+//   * the two removable singularities by selects instead of branches, the vector read as one 8- or 16-byte load.
+// *Measured* (tools/interp_frac_bench.py, 4M -> 10M points, factor 2.5, conv_len 12): see DESIGN.md 4.4.
+template <typename T> __device__ __forceinline__ T quot(T a, T b) { return a / b; }
+// f32: the quotient through v_rcp_f32 (1 ulp) -- a correctly rounded division is a dozen instructions on this unit, a
+// third of the tap (the kernel is bound by its instruction count: ~25 taps x 10M outputs at 4-5 clocks per wave
+// instruction); the weights move by an ulp or two, three orders below the 1e-6 the path is held to
+template <> __device__ __forceinline__ float quot<float>(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
+
+template <typename T, bool CPLX, typename IDX>
+__global__ __launch_bounds__(256) void k_interp_scalar_v2(const T* __restrict__ x, T* __restrict__ y,
+                                                           long long points_, long long new_points,
+                                                           int conv_len, T factor, T delay, int fid, T rolloff)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T* tabc = reinterpret_cast<T*>(smem_raw);
+    const int ntaps = 2 * conv_len + 1;
+    T* tabs = tabc + ntaps;
+    if (fid != 0) {
+        for (int k = threadIdx.x; k < ntaps; k += 256) {
+            double sk, ck;
+            sincospi((double)rolloff * (double)k, &sk, &ck);
+            tabc[k] = (T)ck;
+            tabs[k] = (T)sk;
+        }
+        __syncthreads();
+    }
+    typedef T vec2 __attribute__((ext_vector_type(2)));
+    const IDX points = (IDX)points_;
+    const T one = (T)1, two = (T)2, pi = (T)3.14159265358979323846;
+    // the value at the raised cosine's second singularity, |j| = 1 / (2 beta) (conv_types.rs:406-424)
+    T wsing = one;
+    const T jsing = fid != 0 ? one / (two * rolloff) : (T)-1;
+    if (fid != 0) {
+        const T arg = pi / two / rolloff;
+        wsing = dev_sin(arg) / arg * pi / (two * two);
+    }
+    const T tworo = two * rolloff;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < new_points;
+         i += (long long)gridDim.x * blockDim.x) {
+        const T center = (T)i / factor;
+        const T rounded = dev_floor<T>(center);
+        long long p0 = ((long long)rounded - conv_len - 1) % points_;
+        if (p0 < 0) p0 += points_;
+        IDX pos = (IDX)p0;
+        T j = -(T)conv_len - (center - rounded) + delay;
+        // (sinpi / sincospi reduce their argument exactly, so T's own versions are as good as the double ones here; the
+        // product beta * j rounds like the reference's own pi * x * beta does)
+        T sj, cdummy;
+        dev_sincospi<T>(j, &sj, &cdummy);
+        T cb0 = one, sb0 = (T)0;
+        if (fid != 0) dev_sincospi<T>(rolloff * j, &sb0, &cb0);
+        vec2 acc = vec2{(T)0, (T)0};
+        T sr = 0;
+#pragma unroll 2
+        for (int k = 0; k < ntaps; ++k) {
+            pos = pos + 1 < points ? pos + 1 : 0;
+            const T pi_x = pi * j;
+            T w;
+            if (fid == 0) {
+                w = quot<T>(sj, pi_x);
+            } else {
+                const T c = cb0 * tabc[k] - sb0 * tabs[k];
+                const T arg = tworo * j;
+                w = quot<T>(sj * c, pi_x * (one - arg * arg));
+                w = dev_abs(j) == jsing ? wsing : w;
+            }
+            w = j == (T)0 ? one : w;
+            sj = -sj;
+            if (CPLX) {
+                // (re, im) x (w, 0) spelled out like the reference's complex product, as two-wide operations
+                const vec2 z = reinterpret_cast<const vec2*>(x)[pos];
+                const vec2 zw = z * vec2{w, w}, z0 = vec2{z.y, z.x} * vec2{(T)0, (T)0};
+                acc = acc + vec2{zw.x - z0.x, zw.y + z0.y};
+            } else sr = sr + x[pos] * w;
+            j = j + (T)1;
+        }
+        if (CPLX) reinterpret_cast<vec2*>(y)[i] = acc;
+        else y[i] = sr;
+    }
+}
+
 // scalar path with host-sampled weights (interpolatef_custom): w[i*ntaps + k] is the callback's value for tap k
 // of output i, sampled on the host with the same accumulated arguments as k_interp_scalar
 template <typename T, bool CPLX>
@@ -540,7 +627,16 @@ int interpolatef_dev(const T* in, T* out, size_t len, bool is_complex, int fid, 
         BDSP_HIP_TRY(hipStreamSynchronize(s)); // the weight table is released on return
         return BDSP_OK;
     } else {
-        if (is_complex)
+        const size_t tab_bytes = (size_t)2 * (2 * conv_len + 1) * sizeof(T);
+        if (tab_bytes <= 48 * 1024) { // (the cos / sin table of the roll-off lattice fits LDS: every practical conv_len)
+#define BDSP_SCALAR_V2(CP, IDXT)                                                                                        \
+    hipLaunchKernelGGL((k_interp_scalar_v2<T, CP, IDXT>), dim3((unsigned)blocks), dim3(256), tab_bytes, s, in, out,    \
+                       (long long)points, (long long)new_points, (int)conv_len, factor, delay, fid, rolloff)
+            const bool small = points < ((size_t)1 << 31); // (32-bit position arithmetic in the tap loop)
+            if (is_complex) { if (small) BDSP_SCALAR_V2(true, int); else BDSP_SCALAR_V2(true, long long); }
+            else { if (small) BDSP_SCALAR_V2(false, int); else BDSP_SCALAR_V2(false, long long); }
+#undef BDSP_SCALAR_V2
+        } else if (is_complex)
             hipLaunchKernelGGL((k_interp_scalar<T, true>), dim3((unsigned)blocks), dim3(256), 0, s, in, out,
                                (long long)points, (long long)new_points, (int)conv_len, factor, delay, fid, rolloff);
         else
