@@ -285,6 +285,7 @@ _proto("bdsp_hip_dev_convolve_ex", _I, _I, _P, _P, _SZ, _SZ, _P, _SZ, _I, _I, _P
 _proto("bdsp_hip_conv_spectrum_points", _SZ)
 _proto("bdsp_hip_fft_passes", _I, _I, _SZ)
 _proto("bdsp_hip_capture_abort", _I, _P)
+_proto("bdsp_hip_capture_reset", _I, _P)
 _proto("bdsp_hip_compute_units", _I)
 _proto("bdsp_hip_dev_conv_prepare", _I, _I, _P, _SZ, _P, _P)
 _proto("bdsp_hip_dev_convolve_prepared", _I, _I, _P, _P, _SZ, _SZ, _P, _SZ, _P)

@@ -123,6 +123,9 @@ template <typename T>
 int fft_pow2(const FftIo<T>& io, T* scratch_a, T* scratch_b, size_t batch, bool inverse,
              hipStream_t s);
 template <typename T> int fft_pow2_passes(size_t n); // 1 (n <= 4096), 2 or 3 trips through memory
+// trips of a PLAIN complex transform (no fused option): the same, except where fft_pow2 has a workgroup-resident kernel
+// for that case only (f32 8192 points: k_fft_wg4); one predicate for the dispatch and for bdsp_hip_fft_passes
+template <typename T> int fft_pow2_plain_trips(size_t n);
 template <typename T>
 int fft_any(const FftIo<T>& io, size_t batch, bool inverse, hipStream_t s);
 bool is_pow2(size_t n);

@@ -61,8 +61,8 @@ int fft_two_buffers(T* a, T* b, size_t points, size_t batch, bool inverse, unsig
         // a -> b -> b for ONE 2^21-point f32 transform: the last pass reads and writes the same index set per workgroup,
         // so it may run in place, and at this size (16 MB per buffer) that measured 31.9 -> 27.0 us (tools/plan_probe.py);
         // every other two-pass size measured equal or slower in place (2^20 f64: 20.8 -> 25.3 us), as did 2^24 (above)
-        static const bool force_inplace = lab_flag("BDSP_FFT_LAST_INPLACE");
-        if (!reshaping && (force_inplace || (sizeof(T) == 4 && points == (size_t(1) << 21) && batch == 1))) {
+        static const bool force_inplace = lab_flag("BDSP_FFT_LAST_INPLACE"), no_inplace = lab_flag("BDSP_FFT_NO_LAST_INPLACE");
+        if (!reshaping && !no_inplace && (force_inplace || (sizeof(T) == 4 && points == (size_t(1) << 21) && batch == 1))) {
             io.out = b;
             *in_b = true;
             return fft_pow2<T>(io, b, nullptr, batch, inverse, s);
@@ -73,7 +73,8 @@ int fft_two_buffers(T* a, T* b, size_t points, size_t batch, bool inverse, unsig
         // 451 at 8 (launches too small) -- so only batches of at least two such chunks are split.  A chunk's output
         // never reaches an unprocessed chunk's input (real input, whose output is larger than the input, is excluded).
         static const bool no_chunks = lab_flag("BDSP_FFT_NO_CHUNKS");
-        const size_t vec_bytes = sizeof(T) * 2 * points, k0 = (size_t(128) << 20) / vec_bytes;
+        static const size_t chunk_mb = [] { const char* e = lab_env("BDSP_FFT_CHUNK_MB"); return e ? (size_t)atoi(e) : (size_t)128; }();
+        const size_t vec_bytes = sizeof(T) * 2 * points, k0 = (chunk_mb << 20) / vec_bytes;
         if (!no_chunks && !(flags & FFT_IN_REAL) && k0 >= 1 && batch >= 2 * k0) {
             const size_t nchunks = batch / k0, k = (batch + nchunks - 1) / nchunks;
             const size_t out_elems = (flags & (BDSP_FFT_MAGNITUDE | FFT_OUT_REAL)) ? points : 2 * points; // scalars per vector
@@ -2429,10 +2430,9 @@ size_t bdsp_hip_conv_spectrum_points(void) { return conv_fft_len(0); }
 int bdsp_hip_fft_passes(int elem, size_t points)
 {
     if (points == 0 || (points & (points - 1)) != 0 || points > (size_t(1) << 30)) return 0;
-    // a PLAIN 8192-point f32 transform -- what bdsp_hip_dev_fft launches without flags, scale or window -- is one
-    // workgroup-resident trip (fft_pow2 -> launch_wg4); with fused options it takes the two passes of the plan
-    if (elem == 0 && points == 8192) return 1;
-    return elem == 0 ? fft_pow2_passes<float>(points) : fft_pow2_passes<double>(points);
+    // (a PLAIN transform -- what bdsp_hip_dev_fft launches without flags, scale or window; the predicate fft_pow2 itself
+    // dispatches on, fft_impl.h: f32 8192 points are one workgroup-resident trip, two passes once an option is fused)
+    return elem == 0 ? fft_pow2_plain_trips<float>(points) : fft_pow2_plain_trips<double>(points);
 }
 
 int bdsp_hip_dev_conv_prepare(int elem, const void* taps_dev, size_t taps, void* spectrum_dev, void* stream)
@@ -2567,19 +2567,26 @@ int bdsp_hip_capture_begin(void* stream)
 // Drops an open capture without building a graph: ends the stream capture, releases what the captured calls pinned and
 // re-opens the library for the next capture_begin.  For a caller whose captured sequence failed half way.  No-op (0)
 // when no capture is open.
-int bdsp_hip_capture_abort(void* stream)
+static int capture_drop(hipStream_t st, bool force)
 {
-    hipStream_t st = pick_stream(stream);
     std::vector<void*> blocks, plans;
     {
         std::lock_guard<std::mutex> lk(g_bs_mu);
         if (!g_capture_open) return BDSP_OK;
         if (g_capture_stream != st) { set_last_error("capture_abort: the open capture is on another stream"); return BDSP_ERR_UNSUPPORTED; }
         // a capture belongs to the thread that opened it (capture_end enforces the same): another thread must not tear it
-        // down, and unpin its plans and blocks, while the owner is still recording
-        if (g_capture_thread != std::this_thread::get_id()) {
-            set_last_error("capture_abort: the open capture belongs to another thread");
-            return BDSP_ERR_UNSUPPORTED;
+        // down, and unpin its plans and blocks, while the owner is still recording -- unless the stream is no longer
+        // recording anything (the capture was invalidated or ended behind the library's back), or the caller says the
+        // owner is gone (bdsp_hip_capture_reset: a thread that exits or dies mid-capture would otherwise leave every
+        // later capture_begin of the process refused)
+        if (!force && g_capture_thread != std::this_thread::get_id()) {
+            hipStreamCaptureStatus cap = hipStreamCaptureStatusActive;
+            const bool query_ok = hipStreamIsCapturing(st, &cap) == hipSuccess;
+            if (!query_ok) (void)hipGetLastError();
+            if (!query_ok || cap == hipStreamCaptureStatusActive) {
+                set_last_error("capture_abort: the open capture belongs to another thread (bdsp_hip_capture_reset drops it if that thread is gone)");
+                return BDSP_ERR_UNSUPPORTED;
+            }
         }
         ws_capture_end(st, &blocks);
         plans.swap(g_capture_plans);
@@ -2595,6 +2602,8 @@ int bdsp_hip_capture_abort(void* stream)
     for (void* p : blocks) ws_free(p, st);
     return BDSP_OK;
 }
+int bdsp_hip_capture_abort(void* stream) { return capture_drop(pick_stream(stream), false); }
+int bdsp_hip_capture_reset(void* stream) { return capture_drop(pick_stream(stream), true); }
 int bdsp_hip_capture_end(void* stream, void** graph_exec)
 {
     if (!graph_exec) return BDSP_ERR_ARG_LENGTH;

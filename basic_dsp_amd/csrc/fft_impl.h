@@ -114,6 +114,9 @@ __host__ __device__ constexpr int pass_wgs_per_cu(size_t lds_bytes, int threads)
 template <typename T, int RP, int W, bool GEN>
 constexpr bool pass_split_exchange()
 {
+#if defined(BDSP_LAB) && defined(BDSP_FFT_NO_SPLIT)
+    return false; // (A/B build: tools/plan_matrix.sh, round 5 -- the whole-complex exchange of round 2, one workgroup per CU)
+#endif
     return !GEN && sizeof(T) == 8 && (size_t)W * col_stride(RP, W) * sizeof(cpx<T>) > 80 * 1024;
 }
 template <typename T, int RP, int W, bool GEN>
@@ -569,9 +572,10 @@ __global__ __launch_bounds__(W * (RP / 16), (pass_min_waves<T, RP, W, GEN>())) v
         } else {
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-                // (non-temporal loads, -DBDSP_FFT_NTLOAD in a LAB build: *measured* round 4)
+                // (non-temporal loads, -DBDSP_FFT_NTLOAD in a LAB build: *measured* round 4, see DESIGN.md 4.2;
+                // -DBDSP_FFT_NTLOAD=2: in the FIRST pass only, whose input is dead once read -- round 5)
 #if defined(BDSP_LAB) && defined(BDSP_FFT_NTLOAD)
-                v[r] = nt_load(&in[(size_t)(ti + (r ^ rx) * NT) * stride_in]);
+                v[r] = (BDSP_FFT_NTLOAD != 2 || ROWMAP) ? nt_load(&in[(size_t)(ti + (r ^ rx) * NT) * stride_in]) : in[(size_t)(ti + (r ^ rx) * NT) * stride_in];
 #else
                 v[r] = in[(size_t)(ti + (r ^ rx) * NT) * stride_in];
 #endif
@@ -930,7 +934,8 @@ static int launch_wg(const FftIo<T>& io, size_t batch, bool inverse, hipStream_t
             occ = o;
         }
         const size_t slots = (size_t)num_cus() * (size_t)occ;
-        if (!gen && grid >= 4 * slots && !(io.flags & (BDSP_FFT_MAGNITUDE | FFT_OUT_REAL | FFT_IN_REAL))) {
+        static const bool no_wgbatch = lab_flag("BDSP_FFT_NO_WGBATCH");
+        if (!no_wgbatch && !gen && grid >= 4 * slots && !(io.flags & (BDSP_FFT_MAGNITUDE | FFT_OUT_REAL | FFT_IN_REAL))) {
             if (inverse) {
                 BDSP_TRY(set_lds(k_fft_wg_batch<T, N, 1>, lds2));
                 hipLaunchKernelGGL((k_fft_wg_batch<T, N, 1>), dim3((unsigned)slots), dim3(256), lds2, s, io, wtab, batch);
@@ -1135,6 +1140,14 @@ static int plan_passes(size_t n, size_t batch, size_t esz, int rp[3], int w[3])
     return passes;
 }
 
+// lengths whose PLAIN transform (no fused option) runs in the one-workgroup kernel k_fft_wg4 instead of two passes
+template <typename T>
+static bool wg4_serves(size_t n)
+{
+    static const bool no_wg4 = lab_flag("BDSP_FFT_NO_WG4");
+    return sizeof(T) == 4 && n == 8192 && !no_wg4;
+}
+
 // Runs the transform described by `io` on power-of-two n.  io.in holds the input.  For n <= 4096
 // the result goes to io.out (io.out may equal io.in unless the input is real).  For n > 4096 the
 // passes ping-pong: in -> scratch_a -> [scratch_b ->] io.out; scratch buffers hold n*batch complex.
@@ -1169,8 +1182,8 @@ int fft_pow2(const FftIo<T>& io, T* scratch_a, T* scratch_b, size_t batch, bool 
         // *measured*: 8192 points, batch 2048: 94.8 us as two passes, 73.3 us in one workgroup each (batch 256:
         // 19.8 -> 13.2 us, a single transform 7.7 vs 7.9 us); the 16384-point instantiation (1024 threads, one
         // workgroup per CU) measured SLOWER than two passes at every batch size and is not built
-        static const bool no_wg4 = lab_flag("BDSP_FFT_NO_WG4");
-        if (!no_wg4 && n == 8192 && !io_is_generic(io) && io.window_id < 0 &&
+        // (wg4_serves: the one predicate this dispatch and bdsp_hip_fft_passes share, above)
+        if (wg4_serves<T>(n) && !io_is_generic(io) && io.window_id < 0 &&
             !(io.flags & (BDSP_FFT_MAGNITUDE | FFT_OUT_REAL | FFT_IN_REAL))) return launch_wg4<T, 8192>(io, batch, inverse, s);
     }
     if constexpr (sizeof(T) == 4) {
@@ -1198,8 +1211,10 @@ int fft_pow2(const FftIo<T>& io, T* scratch_a, T* scratch_b, size_t batch, bool 
     // whole 4-8 KB columns, and nothing gets faster -- C2 17.1 -> 17.5 us, C2 x 64 384 -> 409, C4a 53.2 -> 54.0, C5 equal:
     // the narrow READS were never the cost (32-byte sectors out of the Infinity Cache), and the scattered stores are one.
     static const bool want_tiled = lab_flag("BDSP_FFT_TILED");
+    // (not with the triangular / Blackman-Harris window: the split-exchange f64 tiles carry those as per-window
+    // instantiations, which exist for the natural-order intermediate only -- a tiled one would silently apply Hamming)
     const bool tiled = passes == 2 && want_tiled && rp[0] >= 512 && rp[1] >= 512 && (size_t)w[1] * sizeof(cpx<T>) < 128 &&
-                       reinterpret_cast<const void*>(scratch_a) != io.out;
+                       reinterpret_cast<const void*>(scratch_a) != io.out && io.window_id != 0 && io.window_id != 2;
     int lw2 = 0;
     while ((1 << lw2) < w[1]) ++lw2;
     BDSP_TRY(launch_pass_rp<T>(rp[0], w[0], io, nullptr, sa, n, nsg, batch, inverse, true, false, s, tiled ? 1 : 0, lw2));
@@ -1224,7 +1239,15 @@ int fft_pow2_passes(size_t n)
     return plan_passes(n, 1, sizeof(T), rp, w);
 }
 
+template <typename T>
+int fft_pow2_plain_trips(size_t n)
+{
+    if (n == 0 || (n & (n - 1)) != 0) return 0;
+    return wg4_serves<T>(n) ? 1 : fft_pow2_passes<T>(n);
+}
+
 template int fft_pow2<BDSP_FFT_T>(const FftIo<BDSP_FFT_T>&, BDSP_FFT_T*, BDSP_FFT_T*, size_t, bool, hipStream_t);
 template int fft_pow2_passes<BDSP_FFT_T>(size_t);
+template int fft_pow2_plain_trips<BDSP_FFT_T>(size_t);
 
 } // namespace bdsp

@@ -357,7 +357,7 @@ template <typename T> __device__ __forceinline__ T quot(T a, T b) { return a / b
 // instruction); the weights move by an ulp or two, three orders below the 1e-6 the path is held to
 template <> __device__ __forceinline__ float quot<float>(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
 
-template <typename T, bool CPLX, typename IDX>
+template <typename T, bool CPLX>
 __global__ __launch_bounds__(256) void k_interp_scalar_v2(const T* __restrict__ x, T* __restrict__ y,
                                                            long long points_, long long new_points,
                                                            int conv_len, T factor, T delay, int fid, T rolloff)
@@ -376,6 +376,7 @@ __global__ __launch_bounds__(256) void k_interp_scalar_v2(const T* __restrict__ 
         __syncthreads();
     }
     typedef T vec2 __attribute__((ext_vector_type(2)));
+    typedef int IDX; // 32-bit positions in the tap loop: the launcher sends vectors of 2^31 points or more to k_interp_scalar
     const IDX points = (IDX)points_;
     const T one = (T)1, two = (T)2, pi = (T)3.14159265358979323846;
     // the value at the raised cosine's second singularity, |j| = 1 / (2 beta) (conv_types.rs:406-424)
@@ -497,9 +498,12 @@ static int interp_tap_table(int fid, T rolloff, int conv_len, int f, T delay, hi
     // A table is cached only when this call may synchronise the stream: a cache miss while the stream is being captured
     // into a HIP graph takes the uncached workspace route (the table kernel is then part of the graph), because
     // hipStreamSynchronize on a capturing stream invalidates the capture.
+    // ... and so does a query that FAILS: the legacy null stream while another stream captures in global mode answers
+    // hipErrorStreamCaptureImplicit -- exactly the case in which hipMalloc / hipStreamSynchronize would break that capture
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(s, &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusNone; }
-    const bool cache = g_tap_cache.size() < 32 && cap == hipStreamCaptureStatusNone;
+    bool query_ok = true;
+    if (hipStreamIsCapturing(s, &cap) != hipSuccess) { (void)hipGetLastError(); query_ok = false; }
+    const bool cache = g_tap_cache.size() < 32 && query_ok && cap == hipStreamCaptureStatusNone;
     if (cache) BDSP_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&dst), bytes));
     else { BDSP_TRY(fallback->alloc(bytes, s)); dst = fallback->as<T>(); }
     hipLaunchKernelGGL((k_interp_taps<T>), dim3((f * ntaps + 63) / 64), dim3(64), 0, s, dst, fid, rolloff, conv_len, f, delay);
@@ -628,14 +632,16 @@ int interpolatef_dev(const T* in, T* out, size_t len, bool is_complex, int fid, 
         return BDSP_OK;
     } else {
         const size_t tab_bytes = (size_t)2 * (2 * conv_len + 1) * sizeof(T);
-        if (tab_bytes <= 48 * 1024) { // (the cos / sin table of the roll-off lattice fits LDS: every practical conv_len)
-#define BDSP_SCALAR_V2(CP, IDXT)                                                                                        \
-    hipLaunchKernelGGL((k_interp_scalar_v2<T, CP, IDXT>), dim3((unsigned)blocks), dim3(256), tab_bytes, s, in, out,    \
-                       (long long)points, (long long)new_points, (int)conv_len, factor, delay, fid, rolloff)
-            const bool small = points < ((size_t)1 << 31); // (32-bit position arithmetic in the tap loop)
-            if (is_complex) { if (small) BDSP_SCALAR_V2(true, int); else BDSP_SCALAR_V2(true, long long); }
-            else { if (small) BDSP_SCALAR_V2(false, int); else BDSP_SCALAR_V2(false, long long); }
-#undef BDSP_SCALAR_V2
+        // k_interp_scalar_v2 wherever the cos / sin table of the roll-off lattice fits 48 KB of LDS (every practical conv_len:
+        // up to 3071 taps a side in f32, 1535 in f64) and positions fit 32 bits; otherwise the first-generation kernel
+        // (tests/test_gpu_parity.py::test_interpolatef_fractional_factor_kernel_singularities_and_fallback runs both)
+        if (tab_bytes <= 48 * 1024 && points < ((size_t)1 << 31)) {
+            if (is_complex)
+                hipLaunchKernelGGL((k_interp_scalar_v2<T, true>), dim3((unsigned)blocks), dim3(256), tab_bytes, s, in, out,
+                                   (long long)points, (long long)new_points, (int)conv_len, factor, delay, fid, rolloff);
+            else
+                hipLaunchKernelGGL((k_interp_scalar_v2<T, false>), dim3((unsigned)blocks), dim3(256), tab_bytes, s, in, out,
+                                   (long long)points, (long long)new_points, (int)conv_len, factor, delay, fid, rolloff);
         } else if (is_complex)
             hipLaunchKernelGGL((k_interp_scalar<T, true>), dim3((unsigned)blocks), dim3(256), 0, s, in, out,
                                (long long)points, (long long)new_points, (int)conv_len, factor, delay, fid, rolloff);

@@ -61,6 +61,11 @@ def parse(argv=None):
     ap.add_argument("--vectors-per-gpu", type=int, default=C5_VECTORS_PER_GPU, help="--mode c5")
     ap.add_argument("--chunk-vectors", type=int, default=8, help="--mode c5: vectors per pipelined scatter/gather chunk")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--windows", type=int, default=9,
+                    help="further timed windows of --steps steps after the contract's timed region (value_windows: the noise floor)")
+    ap.add_argument("--e2e-vectors-per-gpu", type=int, default=8,
+                    help="headline mode, ranks in a process group: vectors per GPU of the verified scatter/compute/gather leg")
+    ap.add_argument("--e2e-chunk-vectors", type=int, default=2, help="vectors per pipelined chunk of that leg")
     ap.add_argument("--no-first-call", action="store_true", help="skip the fresh-process first-call measurement (config.first_call_ms)")
     ap.add_argument("--cpu-sample-points", type=int, default=1 << 23)
     ap.add_argument("--dry-run-launch", action="store_true", help="print the per-rank child launches of --gpus N and exit")
@@ -303,7 +308,7 @@ class GpuSampler:
     samples taken between two perf_counter times.  Absent library / device / permission: every figure is None --
     the bench line then says nothing about clocks instead of repeating an old measurement."""
 
-    def __init__(self, pci_bus=None, pci_device=None, period_s=0.002):
+    def __init__(self, pci_bus=None, pci_device=None, period_s=0.0005):
         self.samples = []  # (t, sclk_mhz or None, power_w or None)
         self.cap_w = None
         self.sclk_max_mhz = None
@@ -510,7 +515,33 @@ def run_rank(args):
     # per-kernel durations come from HIP events inside the timed region; an event record costs about 2 us of stream
     # time, so only every `ev_stride`-th step carries the three events (at least five steps do)
     ev_stride = max(1, min(8, args.steps // 5))
-    events = {i: [lib.bdsp_hip_event_create() for _ in range(3)] for i in range(0, args.steps, ev_stride)}
+    ms = C.c_float(0)
+
+    def timed_window():
+        """EXACTLY --steps steps between barrier + synchronize on both sides (the contract's timed region; the further
+        windows of `value_windows` repeat it).  Returns (seconds on this rank, t0, t_end, event deltas conv / fft in ms)."""
+        events = {i: [lib.bdsp_hip_event_create() for _ in range(3)] for i in range(0, args.steps, ev_stride)}
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            step(i, events.get(i))
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        cm, fm = [], []
+        for e in events.values():
+            lib.bdsp_hip_event_elapsed_ms(e[0], e[1], C.byref(ms))
+            cm.append(ms.value)
+            lib.bdsp_hip_event_elapsed_ms(e[1], e[2], C.byref(ms))
+            fm.append(ms.value)
+            for h in e:
+                lib.bdsp_hip_event_destroy(h)
+        return el, t0, t0 + el, cm, fm
+
     # Untimed clock pre-warm: the GPU idles at a few hundred MHz and needs tens of milliseconds of load to reach its
     # sustained clock (*measured*: the same step runs 233 us right after start-up and 216 us once the clock has
     # settled).  Then the W warm-up steps of the contract.
@@ -536,26 +567,21 @@ def run_rank(args):
     for i in range(args.warmup):
         step(i)
     torch.cuda.synchronize()
+    # ---- the contract's timed region: `value`, `ms_per_step`, `roofline` come from THIS window only
+    elapsed, t0, t_end, conv_ms, fft_ms = timed_window()
+    # ---- the noise floor (round 5): further windows of the same K steps, back to back, same barriers.  r03 -> r04 moved
+    # the headline by -2.9 % on identical kernel sources and the record could not say whether that was noise.
+    more = [timed_window() for _ in range(max(0, args.windows))]
+    win_elapsed = [elapsed] + [w[0] for w in more]
     if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i, events.get(i))
-    torch.cuda.synchronize()
-    if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    t_end = t0 + elapsed
-    if use_dist:
-        t = torch.tensor([elapsed], device=cdev, dtype=torch.float64)
+        t = torch.tensor(win_elapsed, device=cdev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        win_elapsed = [float(v) for v in t.tolist()]
+        elapsed = win_elapsed[0]
+    steps_with_events = len(conv_ms)
 
     # what an event pair costs by itself on this stream (two records with nothing between): the per-kernel durations
     # below are event deltas minus this, so they are comparable with rocprofv3's kernel-only durations
-    ms = C.c_float(0)
     empty = []
     for _ in range(20):
         ea, eb = lib.bdsp_hip_event_create(), lib.bdsp_hip_event_create()
@@ -570,14 +596,6 @@ def run_rank(args):
     # pair costs between kernels -- *measured* 18 us medians after a 200-step run -- and would be over-subtracted)
     event_overhead = min(empty)
 
-    conv_ms, fft_ms = [], []
-    for e in events.values():
-        lib.bdsp_hip_event_elapsed_ms(e[0], e[1], C.byref(ms))
-        conv_ms.append(ms.value)
-        lib.bdsp_hip_event_elapsed_ms(e[1], e[2], C.byref(ms))
-        fft_ms.append(ms.value)
-        for h in e:
-            lib.bdsp_hip_event_destroy(h)
     conv_raw = sum(conv_ms) / len(conv_ms)
     conv_avg = max(conv_raw - event_overhead, 1e-6)
     fft_avg = max(sum(fft_ms) / len(fft_ms) - event_overhead, 1e-6)
@@ -585,9 +603,18 @@ def run_rank(args):
     e2e = None
     if c5 and not (share_gpu and world > 1):  # (the chunked scatter/gather sends device tensors: RCCL only)
         e2e = c5_end_to_end(args, bd, torch, dist, dev, rank, world, n, m, nvec, use_dist)
+    elif not c5 and use_dist:
+        # the headline mode is what the driver's scaling runs launch (`bench.py --gpus N`): its ranks work on independent
+        # vectors, so without this leg an N-GPU record would never execute the path's one multi-GPU exchange
+        e2e = verified_scatter_gather(args, torch, dist, dev, rank, world, m, share_gpu)
 
     if rank == 0:
         samples = n * nvec * world * args.steps
+        win_values = [samples / e / 1e6 for e in win_elapsed]
+        sv = sorted(win_values)
+        win_spans = [(t0, t_end)] + [(w[1], w[2]) for w in more]
+        win_conv = [conv_ms] + [w[3] for w in more]
+        win_fft = [fft_ms] + [w[4] for w in more]
         algo_bytes = 16.0 * n * nvec  # 8 B read + 8 B written per complex f32 sample
         passes = int(lib.bdsp_hip_fft_passes(0, n)) or 1  # what bdsp_hip_dev_fft launches for this length
         achieved = algo_bytes / (conv_avg * 1e-3) / 1e9
@@ -651,7 +678,7 @@ def run_rank(args):
                 "cold_ms_per_step_first_20_steps_after_idle": cold_ms,
                 # a fresh process's first plain_fft / convolve_signal against its second and third
                 "first_call_ms": first_call,
-                "steps_with_kernel_events": len(events),
+                "steps_with_kernel_events": steps_with_events,
                 "parallelism": "independent vectors per GPU, no data-path collective" + (
                     " -- TEST HOOK BDSP_BENCH_SHARE_GPU: all ranks on GPU 0, control collectives over gloo" if share_gpu else ""),
             },
@@ -706,6 +733,20 @@ def run_rank(args):
                 "step_frac_of_roofline_algorithmic": step_algo_gbs / HBM_PEAK_GBS,
             },
         }
+        # the noise floor: window 0 IS the contract's timed region (`value`), windows 1.. repeat it back to back
+        wclk = [smi.window(a, b) if smi is not None else {"samples": 0, "sclk_mhz": None, "socket_power_w": None} for a, b in win_spans]
+        out["value_windows"] = {
+            "n": len(win_values), "steps_per_window": args.steps, "first_is_value": True,
+            "min": None if share_gpu else sv[0], "median": None if share_gpu else sv[len(sv) // 2], "max": None if share_gpu else sv[-1],
+            "spread_pct": None if share_gpu else (sv[-1] - sv[0]) / sv[len(sv) // 2] * 100.0,
+            "values": None if share_gpu else win_values,
+            "ms_per_step": [e / args.steps * 1e3 for e in win_elapsed],
+            "conv_ms": [max(sum(c) / len(c) - event_overhead, 1e-6) for c in win_conv],
+            "fft_ms": [max(sum(f) / len(f) - event_overhead, 1e-6) for f in win_fft],
+            "sclk_mhz": [w["sclk_mhz"] for w in wclk], "socket_power_w": [w["socket_power_w"] for w in wclk],
+            "clock_power_samples": [w["samples"] for w in wclk],
+            "sampler_period_ms": 0.5,
+        }
         if share_gpu:
             out["test_hook"] = True
             out["test_hook_value"] = samples / elapsed / 1e6
@@ -748,6 +789,74 @@ def c5_end_to_end(args, bd, torch, dist, dev, rank, world, n, m, nvec, use_dist)
     best = min(times[1:])
     return {"vectors": total, "chunk_vectors": args.chunk_vectors, "ms": best * 1e3,
             "Msamples_s": total * n / best / 1e6, "runs_ms": [t * 1e3 for t in times]}
+
+
+def verified_scatter_gather(args, torch, dist, dev, rank, world, m, share_gpu):
+    """The path's multi-GPU exchange, run AND verified from the headline mode whenever the ranks form a process group
+    (`--gpus N` with N > 1, or `--init-dist`): a C5-shaped batch of `--e2e-vectors-per-gpu` vectors of 2^20 points per
+    rank lives in rank 0's HBM, goes out in chunks of `--e2e-chunk-vectors` over grouped point-to-point sends (RCCL over
+    xGMI), every rank runs convolve_signal -> plain_fft on its chunks while the next ones are in flight, the spectra
+    come back two rounds behind (basic_dsp_amd.batch.scatter_process_gather_chunked; replaces the matrix crate's row
+    loop, matrix/src/lib.rs:195-208).  One untimed run, three timed ones.  Then rank 0 recomputes the first and the last
+    chunk of every peer itself and compares the gathered rows BIT FOR BIT (same kernels, same chunk shape, same data ->
+    the same bits on every GPU); at world size 1 it does so for its own shard.  A mismatch ends every rank non-zero.
+    Under the one-GPU test hook the ranks talk gloo, so the chunks travel as host tensors and the compute step copies
+    them to GPU 0 and back."""
+    from basic_dsp_amd.batch import process_shard_gpu, scatter_process_gather_chunked, shard_bounds
+    n, per, chunk = C5_POINTS, args.e2e_vectors_per_gpu, args.e2e_chunk_vectors
+    total = per * world
+    comm_dev = torch.device("cpu") if share_gpu else dev
+    batch = taps = None
+    if rank == 0:
+        g = torch.Generator(device=dev)
+        g.manual_seed(11)
+        batch = torch.rand((total, 2 * n), generator=g, device=dev, dtype=torch.float32) * 20 - 10
+        taps = (torch.rand(2 * m, generator=g, device=dev, dtype=torch.float32) * 2 - 1) / m
+    if share_gpu:
+        def fn(shard, tp, points):
+            return process_shard_gpu(shard.to(dev), tp.to(dev), points).cpu()
+        cbatch, ctaps = (batch.cpu(), taps.cpu()) if rank == 0 else (None, None)
+    else:
+        fn, cbatch, ctaps = process_shard_gpu, batch, taps
+    times, out = [], None
+    for it in range(4):
+        out = None
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        out = scatter_process_gather_chunked(cbatch, ctaps, n, fn, chunk_vectors=chunk, device=comm_dev)
+        torch.cuda.synchronize()
+        dist.barrier()
+        times.append(time.perf_counter() - t0)
+    ok, rows, bad = 1, 0, []
+    if rank == 0 and share_gpu and os.environ.get("BDSP_BENCH_CORRUPT_E2E") == "1":
+        out[total - 1, 12345] += 1.0  # TEST HOOK (with --test-share-gpu only): the verification below must catch this
+    if rank == 0:
+        for peer in (range(1, world) if world > 1 else [0]):
+            f, l = shard_bounds(total, world, peer)
+            spans = [(a, min(a + chunk, l)) for a in range(f, l, chunk)]
+            for a, b in sorted({spans[0], spans[-1]}):
+                ref = process_shard_gpu(batch[a:b], taps, n)
+                got = out[a:b].to(dev)
+                for v in range(a, b):
+                    rows += 1
+                    if not torch.equal(got[v - a], ref[v - a]):
+                        ok = 0
+                        bad.append(v)
+    flag = torch.tensor([ok], device=torch.device("cpu") if share_gpu else dev, dtype=torch.int64)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if int(flag.item()) != 1:
+        if rank == 0:
+            sys.stderr.write("bench.py: gathered rows %s differ from rank 0's own computation of the same rows\n" % bad[:8])
+        dist.barrier()
+        dist.destroy_process_group()
+        raise SystemExit(3)
+    best = min(times[1:])
+    return {"ms": best * 1e3, "Msamples_s": total * n / best / 1e6, "verified_rows": rows, "peers": world - 1,
+            "verified": "bit-identical to rank 0's own convolve_signal -> plain_fft of the same chunks" +
+                        (" (world size 1: rank 0's own shard)" if world == 1 else ""),
+            "vectors": total, "points": n, "vectors_per_gpu": per, "chunk_vectors": chunk, "taps": m,
+            "runs_ms": [t * 1e3 for t in times], "transport": "gloo, host tensors (one-GPU test hook)" if share_gpu else "RCCL (backend nccl), device tensors"}
 
 
 def main():

@@ -812,6 +812,11 @@ int bdsp_hip_capture_end(void *stream, void **graph_exec);
  * mode, pinned workspace and plans are released, the next capture_begin is accepted.  One capture at a time per
  * process, owned by the thread that opened it; other threads' calls neither disturb it nor are recorded by it. */
 int bdsp_hip_capture_abort(void *stream);
+/* The recovery route: drops the open capture from ANY thread.  For a process whose capturing thread exited or died
+ * between capture_begin and capture_end -- bdsp_hip_capture_abort refuses other threads while the stream still records
+ * (it accepts them once the stream no longer does), so without this every later capture_begin would be refused.  The
+ * caller vouches that the owner is gone.  No-op (0) when no capture is open. */
+int bdsp_hip_capture_reset(void *stream);
 int bdsp_hip_graph_launch(void *graph_exec, void *stream);
 void bdsp_hip_graph_destroy(void *graph_exec);
 

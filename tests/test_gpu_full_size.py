@@ -130,6 +130,29 @@ def test_c4_f64_windowed_fft_and_interpolatef_4m():
     assert rel_l2(v.data(), ref) < 1e-13
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("cplx", [True, False])
+def test_interpolatef_fractional_factor_2m_points(cplx, dtype):
+    """The fractional-factor path (k_interp_scalar_v2; the reference's scalar path, interpolation.rs:92-131) at 2 000 000
+    points -> 5 000 000: sinc and raised cosine, real and complex, both precisions, the whole output against the oracle
+    in the same precision (the reference computes its sampling positions i / factor in T).  Roll-off 0.25 and delay 0: the
+    outputs with an integer position walk over both removable singularities (conv_types.rs:406-424)."""
+    e = 2 if cplx else 1
+    n = 2_000_000
+    x = orc.fill_uniform(e * n, SEED_C4 + 5, -10, 10, dtype)
+    for fid, rolloff in [(0, 0.0), (1, 0.25)]:
+        v = DspVec(x, is_complex=cplx, delta=1.0)
+        assert v.interpolatef(fid, 2.5, 0.0, 12, rolloff) == 0
+        ref, path = orc.interpolatef(x, cplx, fid, rolloff, dtype(2.5), 0.0, 12)
+        assert path == 0 and len(v) == ref.size == e * 5_000_000
+        got = v.data()
+        assert rel_l2(got, ref) < (2e-6 if dtype == np.float32 else 1e-13), (fid, rel_l2(got, ref))
+        # both ends of the result wrap around the input (WrappingIterator, mod.rs:725-786)
+        assert rel_l2(got[:e * 64], ref[:e * 64]) < (2e-6 if dtype == np.float32 else 1e-13)
+        assert rel_l2(got[-e * 64:], ref[-e * 64:]) < (2e-6 if dtype == np.float32 else 1e-13)
+        del got, ref, v
+
+
 def test_c5_shard_of_64_1m_vectors_against_the_oracle():
     """BASELINE config C5, one GPU's shard: 64 vectors of 1 048 576 complex f32 points through the batched
     convolve_signal(1024 taps) -> plain_fft (basic_dsp_amd.batch.process_shard_gpu: two launches for the whole
@@ -377,6 +400,14 @@ def test_bench_py_runs_both_modes_and_prints_the_contract_fields():
     k = d["kernels"]
     assert 0.85 * d["ms_per_step"] < k["conv_ms"] + k["fft_ms"] <= 1.02 * d["ms_per_step"], (k, d["ms_per_step"])
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["fair_allcores_Msamples_s"] > 0
+    # round 5: the noise floor -- window 0 is the contract's timed region, nine more windows of the same K steps follow
+    vw = d["value_windows"]
+    assert vw["n"] == 10 and vw["steps_per_window"] == 16 and vw["first_is_value"] is True
+    assert len(vw["values"]) == len(vw["conv_ms"]) == len(vw["fft_ms"]) == len(vw["sclk_mhz"]) == len(vw["ms_per_step"]) == 10
+    assert vw["values"][0] == d["value"] and vw["min"] <= vw["median"] <= vw["max"] and vw["min"] <= d["value"] <= vw["max"]
+    assert abs(vw["conv_ms"][0] - k["conv_ms"]) < 1e-12 and abs(vw["fft_ms"][0] - k["fft_ms"]) < 1e-12
+    assert all(0.5 * k["conv_ms"] < c < 2 * k["conv_ms"] for c in vw["conv_ms"]) and vw["spread_pct"] >= 0
+    assert "c5_end_to_end" not in d  # (no process group at a plain N = 1: nothing changes)
     p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--mode", "c5", "--steps", "4", "--warmup", "1",
                         "--prewarm", "0.02", "--vectors-per-gpu", "16", "--no-cpu-baseline"], env=env, capture_output=True,
                        text=True, timeout=600)
@@ -408,7 +439,7 @@ def test_bench_py_two_and_three_ranks_through_its_own_launcher_on_one_gpu():
         # the environment variable ALONE must change nothing (ranks == 1 runs without the flag: a plain line with a value)
         hook = ["--test-share-gpu"] if ranks > 1 else []
         p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(ranks), "--steps", "30", "--warmup", "3",
-                            "--prewarm", "0.05", "--no-cpu-baseline"] + hook, env=env, capture_output=True, text=True, timeout=600)
+                            "--prewarm", "0.05", "--no-cpu-baseline", "--e2e-vectors-per-gpu", "4"] + hook, env=env, capture_output=True, text=True, timeout=600)
         assert p.returncode == 0, (ranks, p.stderr[-2000:])
         lines = [l for l in p.stdout.strip().splitlines() if l.startswith("{")]
         assert len(lines) == 1, p.stdout[-2000:]  # rank 0 alone prints
@@ -423,6 +454,18 @@ def test_bench_py_two_and_three_ranks_through_its_own_launcher_on_one_gpu():
             # the ranks share one GPU here, so the whole-job rate stays near the one-rank rate (it is N x work in ~N x time)
             assert 0.5 * one < d["test_hook_value"] < 1.6 * one, (ranks, one, d["test_hook_value"])
             assert "TEST HOOK" in d["config"]["parallelism"]
+            # round 5: in the default mode the ranks of a process group ALSO run the path's one exchange -- rank 0 scatters a
+            # C5-shaped batch in chunks, every rank convolves + transforms, the spectra come back -- and rank 0 checks the
+            # first and last chunk of every peer bit for bit (here over gloo with host tensors: one GPU)
+            e = d["c5_end_to_end"]
+            assert e["peers"] == ranks - 1 and e["verified_rows"] == 4 * (ranks - 1) and e["vectors"] == 4 * ranks
+            assert e["ms"] > 0 and e["Msamples_s"] > 0 and e["chunk_vectors"] == 2 and "gloo" in e["transport"]
+            assert d["value_windows"]["values"] is None and len(d["value_windows"]["ms_per_step"]) == 10
+    # ... and a gathered row that differs from rank 0's own computation ends every rank non-zero
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--prewarm", "0.02",
+                        "--no-cpu-baseline", "--test-share-gpu", "--e2e-vectors-per-gpu", "4", "--windows", "1"],
+                       env=dict(env, BDSP_BENCH_CORRUPT_E2E="1"), capture_output=True, text=True, timeout=600)
+    assert p.returncode != 0 and "differ from rank 0's own computation" in p.stderr, (p.returncode, p.stderr[-1500:])
     # the same two ranks under torch.distributed.run, as the driver launches them
     p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
                         "127.0.0.1", "--master-port", free_port(), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "20",
@@ -646,3 +689,8 @@ def test_rccl_runs_on_the_one_gpu_at_world_size_one(tmp_path):
         assert d["n_gpus"] == 1 and d["ranks_seen"] == 1 and d["value"] > 1000
         if extra:
             assert d["c5_end_to_end"]["vectors"] == 16 and d["c5_end_to_end"]["ms"] > 0 and "C5" in d["metric"]
+        else:
+            # round 5: the verified scatter / compute / gather leg of the DEFAULT mode, here through librccl at world size 1
+            # (8 vectors of 2^20 points, chunks of 2, rank 0's own first and last chunk recomputed and compared bit for bit)
+            e = d["c5_end_to_end"]
+            assert e["peers"] == 0 and e["verified_rows"] == 4 and e["vectors"] == 8 and e["ms"] > 0 and "RCCL" in e["transport"]

@@ -480,6 +480,46 @@ def test_interpolatef_both_paths(cplx, dtype):
     np.testing.assert_allclose(v.data(), ref, atol=1e-5)
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("cplx", [True, False])
+def test_interpolatef_fractional_factor_kernel_singularities_and_fallback(cplx, dtype):
+    """The fractional-factor kernel of round 4, k_interp_scalar_v2 (the reference's scalar path, interpolation.rs:92-131):
+    one quotient per tap, cos(pi beta (j0 + k)) from an LDS table, and the raised cosine's two removable singularities
+    (conv_types.rs:406-424) by SELECTS on the accumulated j.  With factor 2.5 and delay 0 every fifth output has an integer
+    j0 = -conv_len, so its taps walk through j == 0 and |j| == 1 / (2 beta) exactly (beta 0.25 -> 2, beta 0.5 -> 1); an integer
+    delay does the same for every such output with another offset.  Then tap counts whose cos / sin table no longer fits the
+    48 KB of LDS the launcher allows: those take the first-generation kernel (one rotation per tap in double)."""
+    e = 2 if cplx else 1
+    tol = 2e-6 if dtype == np.float32 else 1e-13
+    x = orc.fill_uniform(e * 3000, 201602223, -10, 10, dtype)
+    for fid, rolloff, factor, delay, conv_len in [(1, 0.25, 2.5, 0.0, 12), (1, 0.5, 2.5, 0.0, 12), (1, 0.25, 2.5, 3.0, 9),
+                                                  (1, 0.5, 1.25, -1.0, 4), (0, 0.0, 2.5, 0.0, 12), (0, 0.0, 1.25, 2.0, 30),
+                                                  (1, 0.35, 48.0 / 44.1, 0.3, 20), (1, 0.125, 2.5, 0.0, 6)]:
+        v = DspVec(x, is_complex=cplx, delta=1.0)
+        assert v.interpolatef(fid, factor, delay, conv_len, rolloff) == 0
+        ref, path = orc.interpolatef(x, cplx, fid, rolloff, dtype(factor), delay, conv_len)
+        assert path == 0  # the reference's scalar path
+        assert len(v) == ref.size
+        got = v.data()
+        assert rel_l2(got, ref) < tol, (fid, rolloff, factor, delay, conv_len, rel_l2(got, ref))
+        if delay == 0.0 and factor == 2.5:
+            # the outputs whose taps sit ON the singularities, on their own (a wrong select would be lost in the norm of 7500)
+            idx = np.arange(0, ref.size // e, 5)
+            g, r = got.reshape(-1, e)[idx], ref.reshape(-1, e)[idx]
+            assert rel_l2(g.ravel(), r.ravel()) < tol, (fid, rolloff, "outputs with integer j")
+    # 2 * (2 L + 1) table entries beyond 48 KB: L = 3100 in f32 (49.6 KB), 1600 in f64 (51.2 KB)
+    big = 3100 if dtype == np.float32 else 1600
+    x = orc.fill_uniform(e * 7000, 201602224, -10, 10, dtype)
+    for fid, rolloff in [(0, 0.0), (1, 0.35)]:
+        v = DspVec(x, is_complex=cplx, delta=1.0)
+        assert v.interpolatef(fid, 1.5, 0.25, big, rolloff) == 0
+        ref, path = orc.interpolatef(x, cplx, fid, rolloff, dtype(1.5), 0.25, big)
+        assert path == 0 and len(v) == ref.size
+        # (f32: the reference -- and the oracle -- take sin(pi * j) of a ROUNDED product; at |j| ~ 3000 that argument is off by
+        # 1e-4 rad, which the kernel's exact sinpi does not reproduce: 6201 such taps add up to a few 1e-6 of the result)
+        assert rel_l2(v.data(), ref) < (2e-5 if dtype == np.float32 else 1e-12), (fid, big, rel_l2(v.data(), ref))
+
+
 @pytest.mark.parametrize("cplx", [True, False])
 def test_interpolatef_f64_integer_factors_ragged_lengths(cplx):
     # f64, integer factors with and without a blocked inner kernel (2, 4, 8 / 16), ragged lengths (the last workgroup's
@@ -1006,6 +1046,22 @@ def test_hip_graph_capture_and_replay():
         Graph.capture(boom, warmup=False)
     g6 = Graph.capture(lambda: (w.scale(1.0), w.offset(0.0)))
     g6.launch()
+    # a capture whose owning thread is GONE (it exited between begin and end): every other thread is refused by begin (one
+    # capture per process) and by abort (not theirs, the stream still records) -- bdsp_hip_capture_reset is the way out
+    import ctypes as C
+    import threading
+    rc = []
+    th = threading.Thread(target=lambda: (w.scale(1.0), rc.append(bd.lib.bdsp_hip_capture_begin(C.c_void_p(None))), w.scale(1.0)))
+    th.start()
+    th.join()
+    assert rc == [0]
+    assert bd.lib.bdsp_hip_capture_begin(C.c_void_p(None)) <= -100 and "already open" in bd._lib.last_error()
+    assert bd.lib.bdsp_hip_capture_abort(C.c_void_p(None)) <= -100 and "another thread" in bd._lib.last_error()
+    assert bd.lib.bdsp_hip_capture_reset(C.c_void_p(None)) == 0
+    assert bd.lib.bdsp_hip_capture_reset(C.c_void_p(None)) == 0   # (nothing open: a no-op)
+    g8 = Graph.capture(lambda: (w.scale(1.0), w.offset(0.0)))
+    g8.launch()
+    del g8
     # a chirp-z plan cannot be BUILT inside a capture (it synchronises the stream): a clean error, not a broken capture
     prime = DspVec(orc.fill_uniform(2 * 10007, 8, -10, 10, np.float32), is_complex=True)
     with pytest.raises(bd.BackendError, match="warm the plan"):
