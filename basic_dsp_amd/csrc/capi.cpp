@@ -58,33 +58,25 @@ int fft_two_buffers(T* a, T* b, size_t points, size_t batch, bool inverse, unsig
     io.in = a;
     if (!three) { // a -> b -> a
         io.out = a;
-        // a -> b -> b for ONE 2^21-point f32 transform: the last pass reads and writes the same index set per workgroup,
-        // so it may run in place, and at this size (16 MB per buffer) that measured 31.9 -> 27.0 us (tools/plan_probe.py);
-        // every other two-pass size measured equal or slower in place (2^20 f64: 20.8 -> 25.3 us), as did 2^24 (above)
+        // a -> b -> b from 2^19 points on: the last pass reads and writes the same index set per workgroup, so it may run in
+        // place, and the working set of that pass halves.  *Measured* on valid data, input AND scratch cold / input in the
+        // caches (tools/plan_probe.py, profiles/r05_plan_probe_valid.txt; rounds 2-4 had this for ONE 2^21-point f32 vector
+        // only, chosen in loops that ran on inf / NaN): f32 2^19 15.2 -> 13.9 / 12.0 -> 10.8 us, 2^20 16.9 -> 16.6 / 15.8 -> 15.2,
+        // 2^21 29.6 -> 24.3 / 25.1 -> 19.8, 2^22 43.3 -> 42.8 / 33.4 -> 32.9; f64 2^19 20.4 -> 17.5 / 18.5 -> 16.1, 2^20 22.6 -> 22.2 / =,
+        // 2^21 37.3 -> 36.6 / =, 2^22 69.6 -> 66.9 / 46.4 -> 47.2, 16 x 2^20 f64 218.8 -> 214.0 / 213.5 -> 203.2, 64 x 2^20 f32 equal.
+        // Below 2^19 nothing moves (2^14 ... 2^18: +-0.2 us) except batches, which LOSE (256 x 2^16 f32: 83.5 -> 97-100 us with the
+        // input in the caches), and 2^24's third pass in place measured 135 against 128 us (below).
         static const bool force_inplace = lab_flag("BDSP_FFT_LAST_INPLACE"), no_inplace = lab_flag("BDSP_FFT_NO_LAST_INPLACE");
-        if (!reshaping && !no_inplace && (force_inplace || (sizeof(T) == 4 && points == (size_t(1) << 21) && batch == 1))) {
+        if (!reshaping && !no_inplace && (force_inplace || points >= (size_t(1) << 19))) {
             io.out = b;
             *in_b = true;
             return fft_pow2<T>(io, b, nullptr, batch, inverse, s);
         }
-        // A large batch goes through in chunks whose data plus the (shared) scratch fill the 256 MB Infinity Cache:
-        // the intermediate of a chunk is then re-read from the cache instead of HBM.  *Measured* (tools/chunk_probe.py,
-        // 64 x 1M-point f32 -> magnitude): 402 us in one piece, 372 us in chunks of 16 (128 MB + 128 MB), 424 at 32,
-        // 451 at 8 (launches too small) -- so only batches of at least two such chunks are split.  A chunk's output
-        // never reaches an unprocessed chunk's input (real input, whose output is larger than the input, is excluded).
-        static const bool no_chunks = lab_flag("BDSP_FFT_NO_CHUNKS");
-        static const size_t chunk_mb = [] { const char* e = lab_env("BDSP_FFT_CHUNK_MB"); return e ? (size_t)atoi(e) : (size_t)128; }();
-        const size_t vec_bytes = sizeof(T) * 2 * points, k0 = (chunk_mb << 20) / vec_bytes;
-        if (!no_chunks && !(flags & FFT_IN_REAL) && k0 >= 1 && batch >= 2 * k0) {
-            const size_t nchunks = batch / k0, k = (batch + nchunks - 1) / nchunks;
-            const size_t out_elems = (flags & (BDSP_FFT_MAGNITUDE | FFT_OUT_REAL)) ? points : 2 * points; // scalars per vector
-            for (size_t c0 = 0; c0 < batch; c0 += k) {
-                io.in = a + c0 * 2 * points;
-                io.out = a + c0 * out_elems;
-                BDSP_TRY(fft_pow2<T>(io, b, nullptr, batch - c0 < k ? batch - c0 : k, inverse, s));
-            }
-            return BDSP_OK;
-        }
+        // (Rounds 2-4 sent a large batch through in Infinity-Cache-sized chunks of vectors -- 64 x 1M-point f32: "402 us in one
+        // piece, 372 us in chunks of 16", measured in a loop that fed the transform its own output, i.e. on inf / NaN.  On
+        // valid data, cold and cache-resident (tools/plan_probe.py, profiles/r05_plan_probe_valid.txt): one piece 421 / 420 us,
+        // chunks of 16 423 / 438, of 32 441 / 439, of 8 508 / 500; with a magnitude output 402 / 409 against 404 / 402; 32 x 1M
+        // f64 404 / 397 against 426 / 422.  The chunks are gone.)
         return fft_pow2<T>(io, b, nullptr, batch, inverse, s);
     }
     // a -> b -> a -> b.  (The last Stockham pass reads and writes the same index set per workgroup and could run in
@@ -343,7 +335,8 @@ int conv_real_dev(const T* in, T* out, size_t points, const T* taps, size_t ntap
     }
     if (!(ntaps >= 1 && ntaps <= FUSED_MAX_TAPS && ntaps <= points))
         return convolve_direct<T>(in, out, points, batch, taps, ntaps, false, s);
-    if (true) // one launch: the block kernel reads the real taps and transforms them itself
+    static const bool real_prep = lab_flag("BDSP_CONV_REAL_PREP"); // (LAB: spectrum in its own launch, round 5)
+    if (!real_prep) // one launch: the block kernel reads the real taps and transforms them itself
         return conv_run_blocks<T>(in, out, points, batch, taps, ntaps, -(long long)(ntaps / 2), 0, 0, nullptr, s, true, true);
     WsBlock hc, hsb;
     BDSP_TRY(hc.alloc(sizeof(T) * 2 * ntaps, s));

@@ -402,9 +402,11 @@ int conv_run_blocks(const T* in, T* out, size_t points, size_t batch, const T* h
 {
     constexpr int L = CONV_L;
     // real data with real taps handed in as taps: the second-generation kernel on pairs of real blocks
-    if (real_data && hs_is_taps && !last_block_out && nblocks_limit == 0 && out_off == 0 && in_off == -(long long)(taps / 2) &&
+    // (LAB, BDSP_CONV_REAL_PREP: also on a prepared spectrum, so that the workgroups need not transform the taps themselves)
+    static const bool real_prep = lab_flag("BDSP_CONV_REAL_PREP");
+    if (real_data && (hs_is_taps || real_prep) && !last_block_out && nblocks_limit == 0 && out_off == 0 && in_off == -(long long)(taps / 2) &&
         taps >= 1 && taps - 1 <= 3 * (size_t)L / 4 && conv_v2_applies(points, taps))
-        return conv_v2_run<T>(in, out, points, batch, hs, taps, 0, 0, true, s, true);
+        return conv_v2_run<T>(in, out, points, batch, hs, taps, 0, 0, hs_is_taps, s, true);
     // complex data: the second-generation kernel (conv_v2.hip) whenever the call is a run of whole blocks
     if (!real_data && !last_block_out && taps >= 1 && taps - 1 <= 3 * (size_t)L / 4 && conv_v2_applies(points, taps)) {
         const long long V2 = (long long)conv_v2_block_step(taps);

@@ -55,6 +55,7 @@ struct ConvV2Args {
     unsigned na, nbb;        // interior blocks (all vectors together) given to dispatch groups 0 and 1
     int hs_is_taps;
     unsigned groups;         // dispatch groups = workgroups per CU: 3 (f32), 2 (f64)
+    unsigned stagger_us;     // LAB experiment (BDSP_CONV_STAGGER_US): dispatch groups after the first start this much later
 };
 
 // (ablations: a value the compiler must treat as defined / as used, without an instruction)
@@ -76,7 +77,10 @@ static __device__ __forceinline__ unsigned xcd_contiguous(unsigned bid, unsigned
 // ABL (LAB build only, BDSP_CONV_ABL=<bits>, R0 = 4): timing-only ablations of the interior loop -- 1 no global loads,
 // 2 no global stores, 8 no transform (3 = arithmetic + exchanges alone, 8 = the memory skeleton alone); the output is
 // garbage.  They put a measured bound next to the f64 and real-data kernels' roofline fractions.
-template <typename T, int R0, bool BATCHED, bool REAL = false, int ABL = 0>
+// NTS: the interior blocks' results are STREAMED (non-temporal stores) -- for results the 256 MB Infinity Cache cannot hold
+// anyway (round 5; round 3 measured the compile-time form: 16M f64 points 129 -> 123 us, and +8 us on the headline step,
+// whose 128 MB result the transform that follows reads back from the cache).
+template <typename T, int R0, bool BATCHED, bool REAL = false, int ABL = 0, bool NTS = false>
 __global__ __launch_bounds__(256, sizeof(T) == 4 ? 3 : 2) void k_overlap_save_v2(ConvV2Args<T> a)
 {
     constexpr int L = L2;
@@ -261,6 +265,12 @@ __global__ __launch_bounds__(256, sizeof(T) == 4 ? 3 : 2) void k_overlap_save_v2
     const unsigned ni = a.nb_hi - a.nb_lo, total = ni * a.batch, gs = G / a.groups;
     const unsigned grp = blockIdx.x / gs;
     if (grp >= a.groups) return;
+#ifdef BDSP_LAB
+    if (a.stagger_us && grp > 0) { // (bounded: s_memrealtime counts 100 MHz ticks)
+        const unsigned long long t0 = wall_clock64(), lim = (unsigned long long)a.stagger_us * 100ull * grp;
+        while (wall_clock64() - t0 < lim) __builtin_amdgcn_s_sleep(32);
+    }
+#endif
     const unsigned lo = grp == 0 ? 0u : (grp == 1 ? a.na : a.na + a.nbb);
     const unsigned hi = grp == 0 ? a.na : ((grp == 1 && a.groups == 3) ? a.na + a.nbb : total);
     // (Round 3, measured and NOT adopted: RUNS of consecutive blocks per workgroup.  Block b + 1's first R0 rows are block
@@ -307,7 +317,11 @@ __global__ __launch_bounds__(256, sizeof(T) == 4 ? 3 : 2) void k_overlap_save_v2
         } else {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
+#if defined(BDSP_LAB) && defined(BDSP_CONV_NTL)
+                v[r] = nt_load(&xb[ut + 256u * r]); // (A/B build, round 5: the input is dead once read)
+#else
                 v[r] = xb[ut + 256u * r];
+#endif
             }
         }
         if constexpr (!(ABL & 8)) transform(v);
@@ -322,17 +336,14 @@ __global__ __launch_bounds__(256, sizeof(T) == 4 ? 3 : 2) void k_overlap_save_v2
             // non-temporal loads of x made no difference)
             // (round 3, -DBDSP_CONV_NT in the lab build: streaming stores pay only when the result exceeds the cache --
             // 16M f64 points (256 MB) 129 -> 123 us, 64 x 1M f32 (512 MB) 232 -> 228 -- and cost the headline step 8 us)
-#if defined(BDSP_LAB) && defined(BDSP_CONV_NT)
-            nt_store(&yb[ut + 256u * r], v[r]);
-#else
-            yb[ut + 256u * r] = v[r];
-#endif
+            if constexpr (NTS) nt_store(&yb[ut + 256u * r], v[r]);
+            else yb[ut + 256u * r] = v[r];
         }
     }
 }
 
 template <typename T, int R0>
-static int launch_v2(const ConvV2Args<T>& a, unsigned grid, size_t lds, hipStream_t s, bool real)
+static int launch_v2(const ConvV2Args<T>& a, unsigned grid, size_t lds, hipStream_t s, bool real, bool nts)
 {
 #ifdef BDSP_LAB
     if constexpr (R0 == 4) {
@@ -351,6 +362,14 @@ static int launch_v2(const ConvV2Args<T>& a, unsigned grid, size_t lds, hipStrea
         }
     }
 #endif
+    // streamed results: complex data only, through the batched instantiation (it serves single vectors too)
+    if (!real && nts) {
+        auto kern = k_overlap_save_v2<T, R0, true, false, 0, true>;
+        if (lds > 64 * 1024) BDSP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, a);
+        BDSP_LAUNCH_CHECK();
+        return BDSP_OK;
+    }
     if (real) {
         auto kern = k_overlap_save_v2<T, R0, true, true>; // (the batched instantiation serves single vectors too)
         if (lds > 64 * 1024) BDSP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -366,6 +385,16 @@ static int launch_v2(const ConvV2Args<T>& a, unsigned grid, size_t lds, hipStrea
     }
     BDSP_LAUNCH_CHECK();
     return BDSP_OK;
+}
+
+// results above this size are streamed: see k_overlap_save_v2 NTS (set from the measurements of round 5)
+// *Measured* (tools/conv_probe.py, profiles/r05_conv_probe.txt): 16M complex f64 points (256 MB in, 256 MB out) 124.3-128.1 ->
+// 119.2-122.4 us; 64 x 1M f32 (512 MB) 225 -> 222 us for the kernel and 629 -> 632 for convolve -> fft, so f32 batches are
+// left alone; the headline's 128 MB result must NOT be streamed (step 182 -> 193 us: the transform reads it from the cache).
+template <typename T>
+static bool conv_v2_streams_result(size_t points, size_t batch)
+{
+    return sizeof(T) == 8 && (double)points * (double)batch * 2.0 * sizeof(T) > 192.0 * 1024 * 1024;
 }
 
 // block step of the second-generation kernel: V = 4096 - 256 ceil((M-1)/256)
@@ -415,9 +444,17 @@ int conv_v2_run(const T* in, T* out, size_t points, size_t batch, const T* hs, s
         set_last_error("convolve_overlap_save: too many blocks");
         return BDSP_ERR_UNSUPPORTED;
     }
-    constexpr unsigned GROUPS = sizeof(T) == 4 ? 3 : 2;
+    constexpr unsigned GROUPS_MAX = sizeof(T) == 4 ? 3 : 2; // what the kernel's register budget allows per CU
+    // (LAB: fewer workgroups per CU for the real-data kernel, whose 16M-sample job is 3.6 pairs per workgroup at three)
+    static const unsigned lab_groups = [] { const char* e = lab_env("BDSP_CONV_GROUPS"); return e ? (unsigned)atoi(e) : 0u; }();
+    const unsigned GROUPS = (lab_groups >= 2 && lab_groups <= GROUPS_MAX) ? lab_groups : GROUPS_MAX;
     ConvV2Args<T> a{};
     a.groups = GROUPS;
+    a.stagger_us = [] { const char* e = lab_env("BDSP_CONV_STAGGER_US"); return e ? (unsigned)atoi(e) : 0u; }();
+    // A complex result larger than the Infinity Cache can hold until its reader comes is streamed past the caches
+    // (DESIGN.md 4.3, round 5); LAB: BDSP_CONV_NTS=0 / 1 forces the choice
+    bool nts = !real && conv_v2_streams_result<T>(points, batch);
+    if (const char* e = lab_env("BDSP_CONV_NTS")) nts = !real && atoi(e) != 0;
     a.x = reinterpret_cast<const cpx<T>*>(in);
     a.y = reinterpret_cast<cpx<T>*>(out);
     a.hs = reinterpret_cast<const cpx<T>*>(hs);
@@ -431,7 +468,7 @@ int conv_v2_run(const T* in, T* out, size_t points, size_t batch, const T* hs, s
     // grid: GROUPS workgroups per CU, a multiple of 8 * GROUPS so that every dispatch group is a multiple of 8
     const unsigned long long interior = (unsigned long long)(hi - lo) * batch;
     const unsigned long long wrap = (unsigned long long)((lo - b0) + (b1 - hi)) * batch;
-    constexpr unsigned Q = 8 * GROUPS;
+    const unsigned Q = 8 * GROUPS;
     unsigned grid = (unsigned)num_cus() * GROUPS;
     grid -= grid % Q;
     if (grid < Q) grid = Q;
@@ -456,7 +493,7 @@ int conv_v2_run(const T* in, T* out, size_t points, size_t batch, const T* hs, s
     a.nbb = (unsigned)nbb;
     const size_t lds = (size_t)(sizeof(T) == 4 ? WgFft<T, L2, 256>::LDS_ELEMS3 : WgFft<T, L2, 256>::LDS_ELEMS + 16 * 17) * sizeof(cpx<T>);
     switch (r0) {
-#define BDSP_R0(N) case N: return launch_v2<T, N>(a, grid, lds, s, real);
+#define BDSP_R0(N) case N: return launch_v2<T, N>(a, grid, lds, s, real, nts);
         BDSP_R0(1) BDSP_R0(2) BDSP_R0(3) BDSP_R0(4) BDSP_R0(5) BDSP_R0(6)
         BDSP_R0(7) BDSP_R0(8) BDSP_R0(9) BDSP_R0(10) BDSP_R0(11) BDSP_R0(12)
 #undef BDSP_R0

@@ -922,7 +922,20 @@ static int launch_wg(const FftIo<T>& io, size_t batch, bool inverse, hipStream_t
     size_t lds = wg_lds_bytes<T>(N);
     unsigned grid = (unsigned)((batch + B - 1) / B);
     const bool gen = io_is_generic(io);
-    if constexpr (N >= 1024) {
+    // k_fft_wg_batch (persistent workgroups) serves f32 only.  Round 5, on valid data (profiles/r05_plan_probe_valid.txt; the
+    // round-2 figures came from loops on inf / NaN): f32 4096 x 4096 points 53.5 us cold / 46 hot against 61.3 / 49.7 for the
+    // plain launch, 16384 x 4096 213 / 190 against 209-220 / 200-233; f64 LOSES at every size -- 16384 x 1024 points 107 / 94
+    // against 97 / 89, x 2048 210 / 199 against 186 / 171, x 4096 439 / 426 against 387 / 374, 4096 x 4096 113 / 97 against
+    // 105 / 96 -- so its f64 instantiations exist in the LAB build only (BDSP_FFT_WGBATCH_F64).
+#ifdef BDSP_LAB
+    static const bool wgbatch_f64 = lab_flag("BDSP_FFT_WGBATCH_F64");
+    constexpr bool WGBATCH = N >= 1024;
+    const bool wgbatch_on = sizeof(T) == 4 || wgbatch_f64;
+#else
+    constexpr bool WGBATCH = N >= 1024 && sizeof(T) == 4;
+    const bool wgbatch_on = true;
+#endif
+    if constexpr (WGBATCH) {
         // enough transforms to keep persistent workgroups busy for several rounds
         // resident workgroups per CU as the runtime computes it (registers and LDS), once per kernel
         size_t lds2 = lds + 16 * 17 * sizeof(cpx<T>);
@@ -935,7 +948,7 @@ static int launch_wg(const FftIo<T>& io, size_t batch, bool inverse, hipStream_t
         }
         const size_t slots = (size_t)num_cus() * (size_t)occ;
         static const bool no_wgbatch = lab_flag("BDSP_FFT_NO_WGBATCH");
-        if (!no_wgbatch && !gen && grid >= 4 * slots && !(io.flags & (BDSP_FFT_MAGNITUDE | FFT_OUT_REAL | FFT_IN_REAL))) {
+        if (wgbatch_on && !no_wgbatch && !gen && grid >= 4 * slots && !(io.flags & (BDSP_FFT_MAGNITUDE | FFT_OUT_REAL | FFT_IN_REAL))) {
             if (inverse) {
                 BDSP_TRY(set_lds(k_fft_wg_batch<T, N, 1>, lds2));
                 hipLaunchKernelGGL((k_fft_wg_batch<T, N, 1>), dim3((unsigned)slots), dim3(256), lds2, s, io, wtab, batch);
@@ -979,6 +992,17 @@ constexpr bool pass_tiled_pair()
     return RP >= 512;
 #else
     return false;
+#endif
+}
+
+// tiles the product's plans use as a FIRST pass only: their later-pass instantiations are not built (LAB: all are)
+template <int RP, int W>
+constexpr bool pass_first_only()
+{
+#ifdef BDSP_LAB
+    return false;
+#else
+    return RP == 4096;
 #endif
 }
 
@@ -1038,7 +1062,9 @@ static int launch_pass(const FftIo<T>& io_in, const cpx<T>* src, cpx<T>* dst, si
             if (tl == 1) { BDSP_PASS_V(DIRV, true, 1); break; }                                    \
             if (tl == 2) { BDSP_PASS_V(DIRV, false, 2); break; }                                   \
         }                                                                                          \
-        if (rowmap) BDSP_PASS_V(DIRV, true, 0); else BDSP_PASS_V(DIRV, false, 0);                  \
+        if (rowmap) BDSP_PASS_V(DIRV, true, 0);                                                    \
+        else if constexpr (pass_first_only<RP, W>()) { set_last_error("first-pass-only tile"); return BDSP_ERR_UNSUPPORTED; } \
+        else BDSP_PASS_V(DIRV, false, 0);                                                          \
     } while (0)
     if (inverse) BDSP_PASS_D(1); else BDSP_PASS_D(-1);
 #undef BDSP_PASS_D
@@ -1085,6 +1111,8 @@ static int launch_pass_rp(int rp, int w, const FftIo<T>& io, const cpx<T>* src, 
     // every pair plan_passes can choose by itself ...
     BDSP_CASE(64, 64) BDSP_CASE(128, 32) BDSP_CASE(256, 16) BDSP_CASE(512, 8) BDSP_CASE(1024, 4)
     BDSP_CASE(1024, 8) BDSP_CASE(2048, 4)
+    // (the first pass of 2^22 f32 points, round 5: the ROWMAP instantiations only, see pass_first_only)
+    if constexpr (sizeof(T) == 4) { BDSP_CASE(4096, 4) }
 #ifdef BDSP_LAB
     // ... and the ones only a BDSP_FFT_PLAN experiment reaches (the f64 4096 x 4 tiles spill 12-76 bytes per lane)
     BDSP_CASE(2048, 2) BDSP_CASE(4096, 2) BDSP_CASE(4096, 4) BDSP_CASE(1024, 2)
@@ -1115,14 +1143,24 @@ static int plan_passes(size_t n, size_t batch, size_t esz, int rp[3], int w[3])
         }
         if (k >= 2 && prod == n) return k;
     }
-    // 2^21 and 2^22 points: two passes of 1024/2048-point columns beat three fully coalesced ones although their runs
-    // are only 32-64 bytes (*measured*, tools/plan_probe.py, one transform: 2^21 f32 32.9 -> 26.5 us, f64 36.6 -> 31.9;
-    // 2^22 f32 41.1 -> 38.5, f64 67.3 -> 62.0, config C4a 69.8 -> 63.7; from 2^23 on the 4096-point columns' 16-32-byte runs lose: f32
-    // 66 vs 78-93 us, f64 134 vs 135-153, 2^24 f64 319 vs 407)
+    // 2^21 and 2^22 points: two passes of long columns beat three fully coalesced ones although their runs are only 32-64
+    // bytes.  Round 5, re-measured on VALID data with input and scratch cold / input in the caches (tools/plan_probe.py,
+    // profiles/r05_plan_probe_valid.txt; the figures of rounds 2-3 came from loops that transformed their own output, i.e.
+    // inf / NaN), last pass in place:
+    //   2^21 f32  1024x8 + 2048x4  24.3 / 19.8 us   (2048x4 + 1024x8 24.6 / 19.2; three passes 30.3 / 26.9 out of place)
+    //   2^22 f32  4096x4 + 1024x8  40.4 / 32.3      (2048x4 + 2048x4, the plan until round 5: 42.9 / 33.3; three passes 41.4 / 34.0)
+    //   2^21 f64  1024x4 + 2048x4  36.6 / 28.4      (three passes 39.5 / 34.5)
+    //   2^22 f64  2048x4 + 2048x4  66.9 / 47.0      (2048x2 + 2048x4 70.8 / 50.8; three passes 76.5 / 65.6)
+    // From 2^23 on three passes win on a cold input: f32 71.2 / 65.7 against 78.9-86.7 / 63.3-63.8 for the 4096-point
+    // columns, f64 137.9 / 131.1 against 140-147 / 121-132; 2^24 f32 132.5 / 129.2 against 173 / 149.
     if (bits == 21 || bits == 22) {
-        rp[0] = bits == 21 ? 1024 : 2048; rp[1] = 2048;
-        if (esz == 4) { w[0] = bits == 21 ? 8 : 4; w[1] = 4; }
-        else { w[0] = 4; w[1] = 4; } // 2^22 f64: 2-wide tiles are 2 us faster plain (59.6 vs 62.0) but 7 us slower with a fused window
+        if (esz == 4) {
+            if (bits == 21) { rp[0] = 1024; w[0] = 8; rp[1] = 2048; w[1] = 4; }
+            else { rp[0] = 4096; w[0] = 4; rp[1] = 1024; w[1] = 8; }
+        } else {
+            rp[0] = bits == 21 ? 1024 : 2048; rp[1] = 2048;
+            w[0] = 4; w[1] = 4; // 2^22 f64: 2-wide first-pass tiles are no faster plain (above) and 7 us slower with a fused window
+        }
         return 2;
     }
     int passes = bits <= 20 ? 2 : 3;

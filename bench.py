@@ -66,6 +66,8 @@ def parse(argv=None):
     ap.add_argument("--e2e-vectors-per-gpu", type=int, default=8,
                     help="headline mode, ranks in a process group: vectors per GPU of the verified scatter/compute/gather leg")
     ap.add_argument("--e2e-chunk-vectors", type=int, default=2, help="vectors per pipelined chunk of that leg")
+    ap.add_argument("--e2e-timeout", type=float, default=300.0,
+                    help="seconds before a scatter/compute/gather leg that hangs is given up: the line is printed with an error in its place")
     ap.add_argument("--no-first-call", action="store_true", help="skip the fresh-process first-call measurement (config.first_call_ms)")
     ap.add_argument("--cpu-sample-points", type=int, default=1 << 23)
     ap.add_argument("--dry-run-launch", action="store_true", help="print the per-rank child launches of --gpus N and exit")
@@ -600,14 +602,7 @@ def run_rank(args):
     conv_avg = max(conv_raw - event_overhead, 1e-6)
     fft_avg = max(sum(fft_ms) / len(fft_ms) - event_overhead, 1e-6)
 
-    e2e = None
-    if c5 and not (share_gpu and world > 1):  # (the chunked scatter/gather sends device tensors: RCCL only)
-        e2e = c5_end_to_end(args, bd, torch, dist, dev, rank, world, n, m, nvec, use_dist)
-    elif not c5 and use_dist:
-        # the headline mode is what the driver's scaling runs launch (`bench.py --gpus N`): its ranks work on independent
-        # vectors, so without this leg an N-GPU record would never execute the path's one multi-GPU exchange
-        e2e = verified_scatter_gather(args, torch, dist, dev, rank, world, m, share_gpu)
-
+    out = None
     if rank == 0:
         samples = n * nvec * world * args.steps
         win_values = [samples / e / 1e6 for e in win_elapsed]
@@ -750,13 +745,47 @@ def run_rank(args):
         if share_gpu:
             out["test_hook"] = True
             out["test_hook_value"] = samples / elapsed / 1e6
+
+    # ---- the path's multi-GPU exchange, AFTER every figure of the line above is final and under a watchdog: a leg that
+    # hangs in a collective must not cost the record the measurements that were complete before it started
+    def e2e_leg():
+        if c5 and not (share_gpu and world > 1):  # (the chunked scatter/gather sends device tensors: RCCL only)
+            return c5_end_to_end(args, bd, torch, dist, dev, rank, world, n, m, nvec, use_dist)
+        if not c5 and use_dist:
+            # the headline mode is what the driver's scaling runs launch (`bench.py --gpus N`): its ranks work on independent
+            # vectors, so without this leg an N-GPU record would never execute the path's one multi-GPU exchange
+            return verified_scatter_gather(args, torch, dist, dev, rank, world, m, share_gpu)
+        return None
+
+    def e2e_timed_out():
+        if rank == 0:
+            out["c5_end_to_end"] = {"error": "no result after %.0f s (--e2e-timeout): the scatter / compute / gather leg hung; every other "
+                                             "figure of this line was final before the leg started" % args.e2e_timeout}
+            print(json.dumps(out))
+            sys.stdout.flush()
+        else:
+            time.sleep(5)
+        os._exit(0)
+
+    import threading
+    e2e_done = threading.Event()
+    threading.Thread(target=lambda: e2e_done.wait(args.e2e_timeout) or e2e_timed_out(), daemon=True).start()
+    group_ok = True
+    try:
+        e2e = e2e_leg()
+    except Exception as exc:  # noqa: BLE001  (a failed collective: say so in the line; a verification MISMATCH is a SystemExit and ends the run)
+        e2e, group_ok = {"error": "%s: %s" % (type(exc).__name__, str(exc)[-400:])}, False
+    finally:
+        e2e_done.set()
+
+    if rank == 0:
         if e2e is not None:
             out["c5_end_to_end"] = e2e
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(n, m, args.cpu_sample_points, nvec if c5 else 1)
         print(json.dumps(out))
         sys.stdout.flush()
-    if use_dist:
+    if use_dist and group_ok:
         dist.barrier()
         dist.destroy_process_group()
 
@@ -818,6 +847,8 @@ def verified_scatter_gather(args, torch, dist, dev, rank, world, m, share_gpu):
         cbatch, ctaps = (batch.cpu(), taps.cpu()) if rank == 0 else (None, None)
     else:
         fn, cbatch, ctaps = process_shard_gpu, batch, taps
+    if share_gpu and os.environ.get("BDSP_BENCH_HANG_E2E") == "1" and rank == world - 1:
+        time.sleep(3600)  # TEST HOOK (with --test-share-gpu only): a rank that never joins the leg -- the watchdog must end the run
     times, out = [], None
     for it in range(4):
         out = None

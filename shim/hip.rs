@@ -11,11 +11,13 @@
 // (vector/src/gpu_support/mod.rs:18-46).  Link with `-lbasic_dsp_hip` (build: make -C basic_dsp_amd/csrc).
 // NOT compiled in this repository's image (no rustc / cargo here): the ABI it binds is exercised from C
 // (tests/c_abi/facade_demo.c) and Python (tests/test_abi.py, tests/test_gpu_parity.py: test_b1_*).
+// (imports as vector/src/gpu_support/fallback.rs:3-6 -- `RealNumber` and `Float` both come out of crate::numbers --
+// plus what the FFI needs)
 use super::GpuSupport;
-use crate::RealNumber;
+use crate::numbers::*;
+use std::ops::Range;
 use rustfft::FftDirection;
 use std::mem;
-use std::ops::Range;
 use std::ffi::CStr;
 use std::os::raw::{c_char, c_int};
 
@@ -43,14 +45,22 @@ fn last_error() -> String {
     unsafe { CStr::from_ptr(bdsp_hip_last_error()).to_string_lossy().into_owned() }
 }
 
-pub type Gpu32 = f32;            // as fallback.rs:8-24
+// The marker types the rest of the crate names (vector/src/lib.rs:110,162,183,204,208-209: `type GpuReg = Gpu32 / Gpu64`,
+// `RealNumber: Float + DspNumber + GpuFloat + ...`).  This backend needs nothing from them -- it takes the caller's
+// slices as they are -- so they are EXACTLY the CPU arm's (vector/src/gpu_support/fallback.rs:8-24): plain scalars and two
+// empty traits over `Float` with blanket impls.  (The OpenCL arm binds them to ocl / clFFT types instead,
+// ocl/mod.rs:20-37.)
+pub type Gpu32 = f32;
+
 pub type Gpu64 = f64;
-pub trait GpuRegTrait: Copy {}
-impl GpuRegTrait for f32 {}
-impl GpuRegTrait for f64 {}
-pub trait GpuFloat { type Reg: GpuRegTrait; }
-impl GpuFloat for f32 { type Reg = f32; }
-impl GpuFloat for f64 { type Reg = f64; }
+
+pub trait GpuFloat: Float {}
+
+pub trait GpuRegTrait: Float {}
+
+impl<T> GpuFloat for T where T: Float {}
+
+impl<T> GpuRegTrait for T where T: Float {}
 
 impl<T: RealNumber> GpuSupport<T> for T {
     fn has_gpu_support() -> bool {                       // gpu_support/mod.rs:21

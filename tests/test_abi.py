@@ -156,3 +156,26 @@ def test_library_exports_nothing_but_the_declared_c_abi():
     extra = sorted(exported - set(declared_functions()))
     assert not [n for n in extra if n.startswith("_Z")], extra[:5]
     assert not extra, extra[:10]
+
+
+def test_rust_shim_is_what_integration_md_prints_and_its_markers_are_the_cpu_arms():
+    """shim/hip.rs has never met a compiler (no rustc here), so it is kept literal where it can be: INTEGRATION.md section 1
+    reproduces it verbatim, the marker types are the ones of the reference's CPU arm (two empty traits over `Float` with
+    blanket impls, gpu_support/fallback.rs:8-24 -- not invented associated types), the imports follow fallback.rs:3-6, and
+    every extern it declares is a symbol the library exports."""
+    import re
+    import basic_dsp_amd as b
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    shim = open(os.path.join(root, "shim", "hip.rs")).read()
+    md = open(os.path.join(root, "INTEGRATION.md")).read()
+    body = shim[shim.index("// (imports as"):].rstrip("\n")
+    assert body in md
+    for line in ("use crate::numbers::*;", "pub trait GpuFloat: Float {}", "pub trait GpuRegTrait: Float {}",
+                 "impl<T> GpuFloat for T where T: Float {}", "impl<T> GpuRegTrait for T where T: Float {}",
+                 "pub type Gpu32 = f32;", "pub type Gpu64 = f64;", "impl<T: RealNumber> GpuSupport<T> for T {"):
+        assert line in shim, line
+    assert "type Reg" not in shim and "crate::RealNumber" not in shim
+    externs = re.findall(r"fn (bdsp_hip_\w+)\(", shim[shim.index('extern "C"'):shim.index("fn last_error")])
+    assert len(externs) == 11
+    for name in externs:
+        assert hasattr(b.lib, name), name

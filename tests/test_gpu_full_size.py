@@ -466,6 +466,15 @@ def test_bench_py_two_and_three_ranks_through_its_own_launcher_on_one_gpu():
                         "--no-cpu-baseline", "--test-share-gpu", "--e2e-vectors-per-gpu", "4", "--windows", "1"],
                        env=dict(env, BDSP_BENCH_CORRUPT_E2E="1"), capture_output=True, text=True, timeout=600)
     assert p.returncode != 0 and "differ from rank 0's own computation" in p.stderr, (p.returncode, p.stderr[-1500:])
+    # ... and a leg that HANGS (a rank never joins it) does not cost the record its measurements: after --e2e-timeout rank 0
+    # prints the line -- every other figure was final before the leg started -- with an error in the leg's place
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--prewarm", "0.02",
+                        "--no-cpu-baseline", "--test-share-gpu", "--e2e-vectors-per-gpu", "4", "--windows", "1", "--e2e-timeout", "20"],
+                       env=dict(env, BDSP_BENCH_HANG_E2E="1"), capture_output=True, text=True, timeout=600)
+    lines = [l for l in p.stdout.strip().splitlines() if l.startswith("{")]
+    assert p.returncode == 0 and len(lines) == 1, (p.returncode, p.stdout[-500:], p.stderr[-1500:])
+    d = json.loads(lines[0])
+    assert "hung" in d["c5_end_to_end"]["error"] and d["ranks_seen"] == 2 and d["test_hook_value"] > 0 and len(d["value_windows"]["ms_per_step"]) == 2
     # the same two ranks under torch.distributed.run, as the driver launches them
     p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
                         "127.0.0.1", "--master-port", free_port(), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "20",

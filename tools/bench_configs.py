@@ -48,11 +48,15 @@ def event_overhead_us():
     return _EV_OVERHEAD
 
 
-def timeit_fresh(call, pristine, iters=20):
-    """For calls that CLOBBER their input (the in-place transforms): `call(buf)` runs on a buffer that holds valid data and
+def timeit_fresh(call, pristine, iters=20, scratch=None):
+    """For calls that CLOBBER their input (the in-place transforms): `call(buf, scr)` runs on a buffer that holds valid data and
     is used exactly ONCE in the timed loop -- `iters` copies of `pristine` are made beforehand (288 GB of HBM: room is not
     the problem), so every call reads a cold, valid input and nothing untimed runs between the calls; the pre-warm runs on
     three more buffers that are restored before each use.  One event pair around the loop.
+    Round 5: every call also gets a SCRATCH buffer of its own (`scratch` = a tensor to model them on), as cold as its input
+    -- a B2 handle's trade buffer is.  With one shared scratch a transform that leaves its result in the scratch buffer
+    never writes a result back to HBM in such a loop (the next call overwrites it in the Infinity Cache), one that leaves
+    it in the rotating input does: the loop then ranks plans by where they put the result, not by what they cost.
     Round 4: a loop of in-place transforms on the same buffers feeds each call the previous call's output -- the values
     grow by sqrt(n) per call and are inf / NaN long before the timed region, and kernels run measurably faster on such
     constant bit patterns than on data (config C4b, whose inputs config C4a had left that way: 54-56 us against 68-74)."""
@@ -60,33 +64,34 @@ def timeit_fresh(call, pristine, iters=20):
     if QUICK: iters = 2
     warm = [pristine.clone() for _ in range(3)]
     bufs = [pristine.clone() for _ in range(iters)]
+    scrs = [torch.zeros_like(scratch) for _ in range(iters)] if scratch is not None else [None] * iters
     t0 = _t.perf_counter(); k = 0
     while _t.perf_counter() - t0 < (0.0 if QUICK else 0.15):
         for _ in range(5):
-            warm[k % 3].copy_(pristine); call(warm[k % 3]); k += 1
+            warm[k % 3].copy_(pristine); call(warm[k % 3], scratch); k += 1
         torch.cuda.synchronize()
     e0, e1 = lib.bdsp_hip_event_create(), lib.bdsp_hip_event_create()
     lib.bdsp_hip_event_record(e0, sp)
-    for i in range(iters): call(bufs[i])
+    for i in range(iters): call(bufs[i], scrs[i] if scrs[i] is not None else scratch)
     lib.bdsp_hip_event_record(e1, sp)
     ms = C.c_float(0); lib.bdsp_hip_event_elapsed_ms(e0, e1, C.byref(ms))
-    del bufs, warm
+    del bufs, warm, scrs
     return ms.value / iters * 1e3
 
 
-def timeit_hot(call, pristine, iters=20):
+def timeit_hot(call, pristine, iters=20, scratch=None):
     """The same call on an input that was written just before it (an untimed copy from `pristine` into one of three buffers
     right before every call: the input is then in the caches, as after a producer kernel); one event pair per call, median
     of the deltas minus the cost of an empty pair."""
     if QUICK: return None
     bufs = [pristine.clone() for _ in range(3)]
     for k in range(20):
-        bufs[k % 3].copy_(pristine); call(bufs[k % 3])
+        bufs[k % 3].copy_(pristine); call(bufs[k % 3], scratch)
     pairs = []
     for i in range(iters):
         bufs[i % 3].copy_(pristine)
         a, b = lib.bdsp_hip_event_create(), lib.bdsp_hip_event_create()
-        lib.bdsp_hip_event_record(a, sp); call(bufs[i % 3]); lib.bdsp_hip_event_record(b, sp)
+        lib.bdsp_hip_event_record(a, sp); call(bufs[i % 3], scratch); lib.bdsp_hip_event_record(b, sp)
         pairs.append((a, b))
     torch.cuda.synchronize()
     ms = C.c_float(0); d = []
@@ -110,7 +115,7 @@ def rnd(n, dt, k=3):
     return [torch.rand(n, device=dev, dtype=dt) * 20 - 10 for _ in range(k)]
 
 x0 = rnd(65536, torch.float32, 1)[0]
-us = timeit_fresh(lambda b: (lib.bdsp_hip_dev_real_scale(0, b.data_ptr(), 65536, 2.5, sp), lib.bdsp_hip_dev_real_offset(0, b.data_ptr(), 65536, 0, -1.25, sp)), x0, 100)
+us = timeit_fresh(lambda b, s_: (lib.bdsp_hip_dev_real_scale(0, b.data_ptr(), 65536, 2.5, sp), lib.bdsp_hip_dev_real_offset(0, b.data_ptr(), 65536, 0, -1.25, sp)), x0, 100)
 report("C1 real f32 65536: scale+offset (2 launches, launch-bound)", us, 65536, 16, "samples")
 n = 1 << 26
 xb = rnd(n, torch.float32, 2)
@@ -120,12 +125,12 @@ del xb
 
 n = 1 << 20
 sc = torch.empty(2 * n, device=dev, dtype=torch.float32); pristine = rnd(2 * n, torch.float32, 1)[0]
-c2 = lambda b: lib.bdsp_hip_dev_fft(0, b.data_ptr(), sc.data_ptr(), n, 1, FFT_MAGNITUDE, 1.0, -1, 0.0, C.byref(flag), sp)
-us = timeit_fresh(c2, pristine, 60)
-report("C2 complex f32 1M: plain_fft->magnitude fused (2 passes, latency-bound); every input valid, cold, used once", us, n, 12, "points", timeit_hot(c2, pristine, 60))
+c2 = lambda b, s_: lib.bdsp_hip_dev_fft(0, b.data_ptr(), s_.data_ptr(), n, 1, FFT_MAGNITUDE, 1.0, -1, 0.0, C.byref(flag), sp)
+us = timeit_fresh(c2, pristine, 60, sc)
+report("C2 complex f32 1M: plain_fft->magnitude fused (2 passes, latency-bound); every input valid, cold, used once, own scratch", us, n, 12, "points", timeit_hot(c2, pristine, 60, sc))
 b = 64
 sc = torch.empty(2 * n * b, device=dev, dtype=torch.float32); pristine = rnd(2 * n * b, torch.float32, 1)[0]
-us = timeit_fresh(lambda bf: lib.bdsp_hip_dev_fft(0, bf.data_ptr(), sc.data_ptr(), n, b, FFT_MAGNITUDE, 1.0, -1, 0.0, C.byref(flag), sp), pristine, 10)
+us = timeit_fresh(lambda bf, s_: lib.bdsp_hip_dev_fft(0, bf.data_ptr(), s_.data_ptr(), n, b, FFT_MAGNITUDE, 1.0, -1, 0.0, C.byref(flag), sp), pristine, 10, sc)
 report("C2x64 64 x complex f32 1M: plain_fft->magnitude fused", us, n * b, 12, "points")
 del sc, pristine
 
@@ -142,9 +147,9 @@ xd = rnd(2 * n, torch.float64, 2); yd = torch.empty(2 * n, device=dev, dtype=tor
 us = timeit(lambda i: lib.bdsp_hip_dev_convolve(1, xd[i % 2].data_ptr(), yd.data_ptr(), n, 1, td.data_ptr(), m, sp), 10)
 report("C3 in f64: complex f64 16M (*) 1024 taps", us, n, 32, "samples")
 del xd, yd
-f16 = lambda b: lib.bdsp_hip_dev_fft(0, b.data_ptr(), y.data_ptr(), n, 1, 0, 1.0, -1, 0.0, C.byref(flag), sp)
-us = timeit_fresh(f16, xs[0], 20)
-report("FFT complex f32 16M: plain_fft (3 passes); every input valid, cold, used once", us, n, 16, "points", timeit_hot(f16, xs[0], 20))
+f16 = lambda b, s_: lib.bdsp_hip_dev_fft(0, b.data_ptr(), s_.data_ptr(), n, 1, 0, 1.0, -1, 0.0, C.byref(flag), sp)
+us = timeit_fresh(f16, xs[0], 20, y)
+report("FFT complex f32 16M: plain_fft (3 passes); every input valid, cold, used once, own scratch", us, n, 16, "points", timeit_hot(f16, xs[0], 20, y))
 # real signal, real taps through the facade (B2): two real blocks per complex transform pair
 import numpy as np
 from basic_dsp_amd import DspVec
@@ -166,9 +171,9 @@ del xs, y
 
 n = 1 << 22
 xs = rnd(2 * n, torch.float64); sc = torch.empty(2 * n, device=dev, dtype=torch.float64)
-c4a = lambda b: lib.bdsp_hip_dev_fft(1, b.data_ptr(), sc.data_ptr(), n, 1, FFT_SHIFT_OUT, 1.0, 4, 0.5, C.byref(flag), sp)
-us = timeit_fresh(c4a, xs[0], 30)
-report("C4a complex f64 4M: windowed_fft(Hann) fused window+fft+shift; every input valid, cold, used once", us, n, 32, "points", timeit_hot(c4a, xs[0], 30))
+c4a = lambda b, s_: lib.bdsp_hip_dev_fft(1, b.data_ptr(), s_.data_ptr(), n, 1, FFT_SHIFT_OUT, 1.0, 4, 0.5, C.byref(flag), sp)
+us = timeit_fresh(c4a, xs[0], 30, sc)
+report("C4a complex f64 4M: windowed_fft(Hann) fused window+fft+shift; every input valid, cold, used once, own scratch", us, n, 32, "points", timeit_hot(c4a, xs[0], 30, sc))
 # ONE protocol for C4b (round 4): three rotating inputs (64 MB each) AND three rotating outputs (256 MB each), like the
 # headline's rotating inputs -- neither side of the operation finds its data in the 256 MB Infinity Cache; 30 calls
 outs = [torch.empty(8 * n, device=dev, dtype=torch.float64) for _ in range(3)]

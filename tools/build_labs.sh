@@ -18,4 +18,8 @@ for v in "nosplit:-DBDSP_FFT_NO_SPLIT" "ntload2:-DBDSP_FFT_NTLOAD=2" "nt:-DBDSP_
   done
   make -j$J BUILD=build_lab_$name OUT=../lib/libbasic_dsp_hip_lab_$name.so EXTRA="-DBDSP_LAB $def" all > /tmp/build_lab_$name.log 2>&1 || { tail -30 /tmp/build_lab_$name.log; exit 1; }
 done
+# ... and one whose block kernel reads its input with non-temporal loads (-DBDSP_CONV_NTL): only conv_v2.o differs
+rm -rf build_lab_ntl; mkdir -p build_lab_ntl
+for o in build_lab/*.o build_lab/exports.map; do case $o in */conv_v2.o) ;; *) cp -p $o build_lab_ntl/;; esac; done
+make -j$J BUILD=build_lab_ntl OUT=../lib/libbasic_dsp_hip_lab_ntl.so EXTRA="-DBDSP_LAB -DBDSP_CONV_NTL" all > /tmp/build_lab_ntl.log 2>&1 || { tail -30 /tmp/build_lab_ntl.log; exit 1; }
 ls -la ../lib

@@ -9,7 +9,7 @@ pp() { # pp <lib suffix or ""> <env assignments or -> <tag> args...
   local lib=$L$1.so envs=$2 tag=$3; shift 3
   env BDSP_HIP_LIBRARY=$lib $( [ "$envs" != "-" ] && echo $envs ) timeout 300 python3 tools/plan_probe.py --tag "$tag" "$@" 2>&1 | grep -v "amdgpu.ids" | tee -a $OUT
 }
-SECTIONS=${SECTIONS:-A B C D E F G}
+SECTIONS=${SECTIONS:-A B C E F G}   # (D measured the chunked batch schedule, which round 5 removed together with its switches)
 date > $OUT
 for S in $SECTIONS; do case $S in
 A) echo "## A. two against three passes (batch 1, plain complex transform)" | tee -a $OUT
@@ -96,5 +96,48 @@ I) echo "## I. config C4a: in-place last pass x non-temporal first-pass loads, t
      echo "lab$v $ip" | tee -a $OUT
      python3 tools/trace_tail.py gpurun_out/prof_c4a 20 k_fft_pass | tee -a $OUT
    done; done ;;
+J) echo "## J. cold = input AND scratch cold (one scratch per call): in-place last pass, f32 2^21 / 2^22 plans, C4a; twice" | tee -a $OUT
+   for rep in 1 2; do
+     for p in f32 f64; do
+       pp "" BDSP_FFT_NO_LAST_INPLACE=1 out-of-place --prec $p --bits 17,19,20,21,22
+       pp "" BDSP_FFT_LAST_INPLACE=1 in-place --prec $p --bits 17,19,20,21,22
+     done
+     pp "" BDSP_FFT_NO_LAST_INPLACE=1 out-of-place --prec f32 --bits 22 --plans default,256x16:128x32:128x32,4096x4:1024x8,1024x8:4096x4
+     pp "" BDSP_FFT_LAST_INPLACE=1 in-place --prec f32 --bits 22 --plans default,4096x4:1024x8,1024x8:4096x4
+     pp "" BDSP_FFT_NO_LAST_INPLACE=1 out-of-place --prec f32 --bits 21 --plans default,2048x4:1024x8,128x32:128x32:128x32
+     pp "" BDSP_FFT_LAST_INPLACE=1 in-place --prec f32 --bits 21 --plans default,2048x4:1024x8
+     pp "" BDSP_FFT_NO_LAST_INPLACE=1 out-of-place --prec f64 --bits 22 --plans default,256x16:128x32:128x32,2048x2:2048x4
+     pp "" BDSP_FFT_NO_LAST_INPLACE=1 out-of-place --prec f64 --bits 20 --batch 16
+     pp "" BDSP_FFT_LAST_INPLACE=1 in-place --prec f64 --bits 20 --batch 16
+     for v in "" _ntload2; do
+       pp "$v" BDSP_FFT_NO_LAST_INPLACE=1 "lab$v out-of-place" --prec f64 --bits 22 --flags 2 --window 4 0.5 --plans default,256x16:128x32:128x32
+       pp "$v" BDSP_FFT_LAST_INPLACE=1 "lab$v in-place" --prec f64 --bits 22 --flags 2 --window 4 0.5
+     done
+   done ;;
+K) echo "## K. non-temporal loads in the FIRST pass only, across sizes (the library's own plans, last pass in place from 2^19 on)" | tee -a $OUT
+   for rep in 1 2; do for v in "" _ntload2; do for p in f32 f64; do
+     pp "$v" - "lab$v" --prec $p --bits 18,19,20,21,22,23
+   done; done; done
+   for v in "" _ntload2; do
+     pp "$v" - "lab$v" --prec f64 --bits 20 --batch 16
+     pp "$v" - "lab$v" --prec f32 --bits 20 --flags 8
+     pp "$v" - "lab$v" --prec f64 --bits 21,22 --flags 2 --window 4 0.5
+   done ;;
+L) echo "## L. non-temporal first-pass loads where the first pass reads whole 128-byte lines (3-pass sizes, batches), twice" | tee -a $OUT
+   for rep in 1 2; do for v in "" _ntload2; do
+     pp "$v" - "lab$v" --prec f32 --bits 23,24,25
+     pp "$v" - "lab$v" --prec f64 --bits 23,24
+     pp "$v" - "lab$v" --prec f32 --bits 20 --batch 16
+     pp "$v" - "lab$v" --prec f32 --bits 20 --batch 64
+     pp "$v" - "lab$v" --prec f32 --bits 16 --batch 256
+     pp "$v" - "lab$v" --prec f32 --bits 14 --batch 4096
+     pp "$v" - "lab$v" --prec f64 --bits 20 --batch 4
+     pp "$v" - "lab$v" --prec f64 --bits 20 --batch 16
+     pp "$v" - "lab$v" --prec f64 --bits 20 --batch 32
+     pp "$v" - "lab$v" --prec f64 --bits 16 --batch 256
+     pp "$v" - "lab$v" --prec f64 --bits 22 --batch 4
+   done; done
+   echo "## L'. is an uploaded vector cold?  (tools/upload_probe.py through the facade)" | tee -a $OUT
+   for v in "" _ntload2; do BDSP_HIP_LIBRARY=$L$v.so timeout 300 python3 tools/upload_probe.py 2>&1 | grep -v amdgpu.ids | tee -a $OUT; done ;;
 esac; done
 date >> $OUT

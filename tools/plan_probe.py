@@ -5,7 +5,8 @@
         --bits 21,22 --prec f64 [--batch 16] [--flags 2] [--window 4 0.5] --plans default,2048x4:2048x4,256x16:128x32:128x32 [--tag text]
 
 One row per (size, precision, plan): `us` = every call reads a pristine copy of the random input that was written long ago
-and is used exactly once (a COLD input: the caches were flushed with a 1 GB fill after the copies were made), one event
+and is used exactly once, and ping-pongs through a scratch buffer of its own (a COLD input and a cold trade buffer: the
+caches were flushed with a 1 GB fill after the copies were made; `--scratch shared` = one scratch for all calls), one event
 pair around the loop; `us_hot` = the input was copied into its buffer right before the call (in the caches, as after a
 producer kernel), one event pair per call, median minus the cost of an empty pair.  This is the protocol of
 tools/bench_configs.py; rounds 1-3 timed loops of in-place transforms that fed every call the previous call's output, i.e.
@@ -33,6 +34,8 @@ ap.add_argument("--plans", default="default")
 ap.add_argument("--iters", type=int, default=0)
 ap.add_argument("--tag", default="")
 ap.add_argument("--json", action="store_true")
+ap.add_argument("--scratch", choices=("per-call", "shared"), default="per-call",
+                help="cold loop: every call gets its own scratch buffer as well (default) or all calls share one")
 ap.add_argument("--only", choices=("both", "cold"), default="both", help="cold: the cold loop is the LAST thing the process runs (for a kernel trace)")
 a = ap.parse_args()
 
@@ -72,10 +75,10 @@ for bits in [int(b) for b in a.bits.split(",")]:
     pristine = torch.rand(2 * n * b, device=dev, dtype=dt, generator=g) * 20 - 10
     y = torch.empty(2 * n * b, device=dev, dtype=dt)
     vec_bytes = 2 * n * b * esz
-    iters = a.iters or max(6, min(30, int(3e9 // vec_bytes)))
+    iters = a.iters or max(6, min(30, int(3e9 // vec_bytes)))  # (x 2 buffers per call + the flush)
 
-    def call(buf):
-        return lib.bdsp_hip_dev_fft(elem, buf.data_ptr(), y.data_ptr(), n, b, a.flags, 1.0, wid, walpha, C.byref(flag), sp)
+    def call(buf, scratch=None):
+        return lib.bdsp_hip_dev_fft(elem, buf.data_ptr(), (y if scratch is None else scratch).data_ptr(), n, b, a.flags, 1.0, wid, walpha, C.byref(flag), sp)
 
     def result(buf):
         """what the call left, as a flat array of scalars of the output's size"""
@@ -115,18 +118,25 @@ for bits in [int(b) for b in a.bits.split(",")]:
                 warm[k % 2].copy_(pristine); call(warm[k % 2]); k += 1
             torch.cuda.synchronize()
         # cold: every input valid, written long ago, used once
+        # ... and so is its scratch buffer (a B2 handle's trade buffer is as cold as its data).  With ONE shared scratch a plan
+        # that leaves its result IN the scratch buffer (the in-place last pass) never writes a result back to HBM in this
+        # loop -- the next call overwrites it in the Infinity Cache -- while a plan that leaves it in the (rotating) input
+        # buffer pays for the write-back of the previous call's result: run 2 of round 5 measured that artefact, not the plan
         bufs = [pristine.clone() for _ in range(iters)]
+        scr = [torch.empty_like(y) for _ in range(iters)] if a.scratch == "per-call" else [None] * iters
+        for t in scr:
+            if t is not None: t.copy_(y)
         junk.fill_(1.0)
         for _ in range(2):  # (the clock again, on buffers that do not matter)
             warm[0].copy_(pristine); call(warm[0])
         junk.fill_(2.0)
         e0, e1 = lib.bdsp_hip_event_create(), lib.bdsp_hip_event_create()
         lib.bdsp_hip_event_record(e0, sp)
-        for i in range(iters): call(bufs[i])
+        for i in range(iters): call(bufs[i], scr[i])
         lib.bdsp_hip_event_record(e1, sp)
         lib.bdsp_hip_event_elapsed_ms(e0, e1, C.byref(ms))
         cold = ms.value / iters * 1e3
-        del bufs
+        del bufs, scr
         if a.only == "cold":
             torch.cuda.synchronize()
             print("2^%-2d %s x%-3d fl=%-2d win=%-2d %-28s %-22s cold %8.2f us" % (bits, a.prec, b, a.flags, wid, plan, a.tag, cold), flush=True)
