@@ -342,6 +342,144 @@ __global__ __launch_bounds__(256, sizeof(T) == 4 ? 3 : 2) void k_overlap_save_v2
     }
 }
 
+#ifdef BDSP_LAB
+// ------------------------------------------------------------------------------------------------------------------
+// LAB experiment, round 5 (BDSP_CONV_V3=1; complex f64, 770 ... 1025 taps: the block step of the product's R0 = 4): the third candidate of VERDICT r04's item 4 --
+// the same block, 512 threads x EIGHT points per thread, 4096 = 8 x 8 x 8 x 8.  Half the registers per wave (v and H are
+// 32 VGPRs each instead of 64: a 128-register budget), so a CU holds two 512-thread workgroups = FOUR waves per SIMD where
+// the product kernel has two, at the price of a fourth stage and a third LDS exchange per transform (12 barriers per
+// block instead of 8).  Rows are 512 points: R0 = ceil((M - 1) / 512) = 2 discarded rows for 1024 taps, V = 3072 as in the
+// product.  Stage-2 / stage-3 twiddles (four values per thread: dft8_tw) from LDS tables of 8 x 4 and 64 x 4 entries,
+// stage 4 from two held values {w^2, w} (w^4 by squaring, w W8 by a constant).  tools/conv_probe.py compares it with the
+// product kernel's result and times it.
+template <int R0, bool NTS>
+__global__ __launch_bounds__(512, 4) void k_overlap_save_v3(ConvV2Args<double> a)
+{
+    using T = double;
+    constexpr int L = L2, NTH = 512;
+    constexpr unsigned V = L - 512 * R0, OV = 512 * R0;
+    using C64 = cpx<T>;
+    using F = WgFft<T, L, NTH>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    C64* lds = reinterpret_cast<C64*>(smem_raw);
+    const int t = threadIdx.x;
+    const unsigned ut = t;
+    const T hscale = (T)1 / (T)L;
+    auto tww = [&](int mm) { return a.wtab[mm]; };
+    C64* tw2l = lds + F::LDS_ELEMS;       // [8][4]
+    C64* tw3l = tw2l + 8 * 4;             // [64][4]
+    if (t < 32) {
+        const int k = t >> 2, j = t & 3, e = k * (L / 64);
+        tw2l[t] = a.wtab[j == 0 ? 4 * e : j == 1 ? 2 * e : j == 2 ? e : e + L / 8];
+    }
+    if (t < 256) {
+        const int k = t >> 2, j = t & 3, e = k * (L / 512);
+        tw3l[t] = a.wtab[j == 0 ? 4 * e : j == 1 ? 2 * e : j == 2 ? e : e + L / 8];
+    }
+    const C64 w4q[2] = {a.wtab[(2 * t) & (L - 1)], a.wtab[t]}; // stage 4 (NS = 512): e = t -> {w^2, w}
+    __syncthreads();
+    const C64* tw2p = tw2l + (t & 7) * 4;
+    const C64* tw3p = tw3l + (t & 63) * 4;
+    auto stage_tab = [&](C64 (&v)[8], const C64* tp, auto D) {
+        const C64 tl[4] = {tp[0], tp[1], tp[2], tp[3]};
+        dft8_tw<decltype(D)::value>(&v[0], tl);
+    };
+    auto stage4 = [&](C64 (&v)[8], auto D) {
+        const T h = (T)0.70710678118654752440;
+        const C64 w2 = w4q[0], w1 = w4q[1];
+        const C64 tl[4] = {C64{(w2.x - w2.y) * (w2.x + w2.y), (T)2 * w2.x * w2.y}, w2, w1, C64{(w1.x + w1.y) * h, (w1.y - w1.x) * h}};
+        dft8_tw<decltype(D)::value>(&v[0], tl);
+    };
+    auto xform = [&](C64 (&v)[8], auto D) {
+        constexpr int DIR = decltype(D)::value;
+        F::template compute<8, 1, DIR>(v, t, tww);
+        __syncthreads(); // the previous transform's last gather is done
+        F::template scatter<8, 1>(v, t, lds);
+        __syncthreads();
+        F::template gather<8>(v, t, lds);
+        stage_tab(v, tw2p, D);
+        __syncthreads();
+        F::template scatter<8, 8>(v, t, lds);
+        __syncthreads();
+        F::template gather<8>(v, t, lds);
+        stage_tab(v, tw3p, D);
+        __syncthreads();
+        F::template scatter<8, 64>(v, t, lds);
+        __syncthreads();
+        F::template gather<8>(v, t, lds);
+        stage4(v, D);
+    };
+    // ---- the filter spectrum, delayed by d samples, x 1/L: H'[t + 512 r] in register r
+    C64 hreg[8];
+    const unsigned d = OV - (a.taps - 1);
+    {
+        C64 hv[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const unsigned i = ut + 512u * r;
+            hv[r] = (i >= d && i - d < a.taps) ? a.hs[i - d] : C64{(T)0, (T)0};
+        }
+        xform(hv, std::integral_constant<int, -1>{});
+#pragma unroll
+        for (int r = 0; r < 8; ++r) hreg[r] = C64{hv[r].x * hscale, hv[r].y * hscale};
+    }
+    auto transform = [&](C64 (&v)[8]) {
+        xform(v, std::integral_constant<int, -1>{});
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] = cmul(v[r], hreg[r]);
+        xform(v, std::integral_constant<int, 1>{});
+    };
+    const long long in_off = -(long long)(a.taps / 2);
+    const unsigned G = gridDim.x;
+    // ---- blocks that wrap around the ends of the vector: general code, taken first
+    {
+        const unsigned nw = (a.nb_lo - a.b_first) + (a.b_end - a.nb_hi), total_w = nw * a.batch;
+        for (unsigned w = blockIdx.x; w < total_w; w += G) {
+            const unsigned vec = w / nw, k = w % nw;
+            const unsigned b = k < a.nb_lo - a.b_first ? a.b_first + k : a.nb_hi + (k - (a.nb_lo - a.b_first));
+            const C64* xv = a.x + (size_t)vec * a.n;
+            C64* yv = a.y + (size_t)vec * a.n;
+            long long sb = ((long long)b * V + in_off) % (long long)a.n;
+            if (sb < 0) sb += a.n;
+            C64 v[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) v[r] = xv[((unsigned long long)sb + ut + 512u * r) % a.n];
+            transform(v);
+            const long long obase = (long long)b * V - OV;
+            const long long room = (long long)a.n - obase;
+            const unsigned lim = room <= 0 ? 0u : (room > L ? (unsigned)L : (unsigned)room);
+            C64* yb = yv + obase;
+#pragma unroll
+            for (int r = R0; r < 8; ++r) {
+                const unsigned np = ut + 512u * r;
+                if (np < lim) yb[np] = v[r];
+            }
+        }
+    }
+    // ---- interior blocks: two dispatch groups with skewed shares, as in the product kernel
+    const unsigned ni = a.nb_hi - a.nb_lo, total = ni * a.batch, gs = G / a.groups;
+    const unsigned grp = blockIdx.x / gs;
+    if (grp >= a.groups) return;
+    const unsigned lo = grp == 0 ? 0u : a.na;
+    const unsigned hi = grp == 0 ? a.na : total;
+    const unsigned w2 = xcd_contiguous(blockIdx.x - grp * gs, gs);
+    for (unsigned id = lo + w2; id < hi; id += gs) {
+        const unsigned vec = id / ni, b = a.nb_lo + id % ni;
+        const C64* xb = a.x + ((size_t)vec * a.n + ((long long)b * V + in_off));
+        C64* yb = a.y + ((size_t)vec * a.n + ((long long)b * V - OV));
+        C64 v[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] = xb[ut + 512u * r];
+        transform(v);
+#pragma unroll
+        for (int r = R0; r < 8; ++r) {
+            if constexpr (NTS) nt_store(&yb[ut + 512u * r], v[r]);
+            else yb[ut + 512u * r] = v[r];
+        }
+    }
+}
+#endif // BDSP_LAB
+
 template <typename T, int R0>
 static int launch_v2(const ConvV2Args<T>& a, unsigned grid, size_t lds, hipStream_t s, bool real, bool nts)
 {
@@ -492,6 +630,19 @@ int conv_v2_run(const T* in, T* out, size_t points, size_t batch, const T* hs, s
     a.na = (unsigned)na;
     a.nbb = (unsigned)nbb;
     const size_t lds = (size_t)(sizeof(T) == 4 ? WgFft<T, L2, 256>::LDS_ELEMS3 : WgFft<T, L2, 256>::LDS_ELEMS + 16 * 17) * sizeof(cpx<T>);
+#ifdef BDSP_LAB
+    if constexpr (sizeof(T) == 8) {
+        if (lab_flag("BDSP_CONV_V3") && !real && r0 == 4 && GROUPS == 2) {
+            using F3 = WgFft<double, L2, 512>;
+            const size_t lds3 = (size_t)(F3::LDS_ELEMS + 8 * 4 + 64 * 4) * sizeof(cpx<double>);
+            auto kern = nts ? k_overlap_save_v3<2, true> : k_overlap_save_v3<2, false>;
+            BDSP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds3, s, a);
+            BDSP_LAUNCH_CHECK();
+            return BDSP_OK;
+        }
+    }
+#endif
     switch (r0) {
 #define BDSP_R0(N) case N: return launch_v2<T, N>(a, grid, lds, s, real, nts);
         BDSP_R0(1) BDSP_R0(2) BDSP_R0(3) BDSP_R0(4) BDSP_R0(5) BDSP_R0(6)

@@ -60,6 +60,28 @@ __device__ __forceinline__ T window_value_sym(int id, T alpha, size_t i, size_t 
     return window_value<T>(id, alpha, j, points);
 }
 
+// The raised cosine near its second singularity (round 5).  cos(pi beta x) / (1 - (2 beta x)^2) cancels in numerator AND
+// denominator as u = |2 beta x| -> 1: evaluated as the reference writes it (conv_types.rs:419-421), a tap that lands next
+// to the singularity without being EQUAL to it has no correct digit left -- in the reference too (x = -6 - 0.8 + 0.3 is 2.5
+// or one ulp beside it depending on the rounding of the accumulation).  With t = 1 - u and y = (pi t / 2)^2,
+//     cos(pi u / 2) / (1 - u^2) = sin(pi t / 2) / (t (2 - t)) = rc_near_num(t) / (2 - t),   rc_near_num = (pi / 2) sin(x) / x,
+// a short polynomial for |t| < 0.25 (|x| < 0.4: five terms reach f32's rounding, nine f64's): no cancellation, no
+// division by t, and t = 0 needs no special case.  Every raised-cosine evaluation of the library takes this form inside
+// |t| < 0.25; exactly AT the singularity the reference's own value is returned (the same limit).  tests/ compares these
+// taps with the oracle's exact-weights mode (oracle/: orc_set_exact_weights), everything else with its literal restatement.
+template <typename T>
+__device__ __forceinline__ T rc_near_num(T t)
+{
+    const T x = (T)1.57079632679489661923 * t, y = x * x;
+    T p;
+    if (sizeof(T) == 4)
+        p = (T)1 + y * ((T)(-1.0 / 6) + y * ((T)(1.0 / 120) + y * ((T)(-1.0 / 5040) + y * (T)(1.0 / 362880))));
+    else
+        p = (T)1 + y * ((T)(-1.0 / 6) + y * ((T)(1.0 / 120) + y * ((T)(-1.0 / 5040) + y * ((T)(1.0 / 362880) + y * ((T)(-1.0 / 39916800) +
+            y * ((T)(1.0 / 6227020800.0) + y * ((T)(-1.0 / 1307674368000.0) + y * (T)(1.0 / 355687428096000.0))))))));
+    return (T)1.57079632679489661923 * p;
+}
+
 // conv function ids (interop/src/lib.rs:166-192): 0 sinc, otherwise raised cosine(rolloff)
 template <typename T>
 __device__ __forceinline__ T conv_time_value(int id, T rolloff, T x)
@@ -77,6 +99,8 @@ __device__ __forceinline__ T conv_time_value(int id, T rolloff, T x)
     }
     T pi_x = pi * x;
     T arg = two * rolloff * x;
+    const T t = one - dev_abs(arg);
+    if (dev_abs(t) < (T)0.25) return dev_sin(pi_x) * rc_near_num<T>(t) / pi_x / (two - t);
     return dev_sin(pi_x) * dev_cos(pi_x * rolloff) / pi_x / (one - (arg * arg));
 }
 

@@ -323,7 +323,9 @@ __global__ __launch_bounds__(256) void k_interp_scalar(const T* __restrict__ x, 
             } else {
                 T pi_x = pi * j;
                 T arg = two * rolloff * j;
-                w = (T)sj * (T)cbj / pi_x / (one - (arg * arg));
+                const T t = one - dev_abs(arg);
+                if (dev_abs(t) < (T)0.25) w = (T)sj * rc_near_num<T>(t) / pi_x / (two - t); // (dsp_funcs.h: no cancellation)
+                else w = (T)sj * (T)cbj / pi_x / (one - (arg * arg));
             }
             sj = -sj;
             if (fid != 0) {
@@ -414,21 +416,12 @@ __global__ __launch_bounds__(256) void k_interp_scalar_v2(const T* __restrict__ 
                 const T arg = tworo * j;
                 const T t = one - dev_abs(arg);
                 if (dev_abs(t) < (T)0.25) {
-                    // near the second singularity, |2 beta j| -> 1, numerator and denominator both cancel.  With u = |2 beta j|,
-                    // t = 1 - u and x = pi t / 2:  cos(pi u / 2) / (1 - u^2) = sin(x) / (t (2 - t)) = (pi / 2) P(x^2) / (2 - t),
-                    // P(y) = sin(x) / x = 1 - y/6 + y^2/120 - ... (|x| < 0.4: five terms reach f32's rounding, nine f64's) -- no
-                    // cancellation and no division by t left.  (Round 5: the table product's 1e-7 of absolute error on a
-                    // cosine that is itself only 1e-2 put the f32 result 3.6e-6 from the oracle -- four times the reference's
-                    // own rounding -- for roll-off 0.35, conv_len 20; with this branch 9e-7, the oracle's own distance from
-                    // the exact weights.  Two to four of the 2 L + 1 tap iterations of a wave take it.)
-                    const T x = (pi * (T)0.5) * t, y = x * x;
-                    T p;
-                    if (sizeof(T) == 4)
-                        p = (T)1 + y * ((T)(-1.0 / 6) + y * ((T)(1.0 / 120) + y * ((T)(-1.0 / 5040) + y * (T)(1.0 / 362880))));
-                    else
-                        p = (T)1 + y * ((T)(-1.0 / 6) + y * ((T)(1.0 / 120) + y * ((T)(-1.0 / 5040) + y * ((T)(1.0 / 362880) + y * ((T)(-1.0 / 39916800) +
-                            y * ((T)(1.0 / 6227020800.0) + y * ((T)(-1.0 / 1307674368000.0) + y * (T)(1.0 / 355687428096000.0))))))));
-                    w = quot<T>(sj * ((pi * (T)0.5) * p), pi_x * (two - t));
+                    // near the second singularity, |2 beta j| -> 1: the cancellation-free form of dsp_funcs.h (rc_near_num).
+                    // (Round 5: the table product's 1e-7 of absolute error on a cosine that is itself only 1e-2 put the f32
+                    // result 3.6e-6 from the oracle -- four times the reference's own rounding -- for roll-off 0.35, conv_len
+                    // 20; with this branch 9e-7, the oracle's own distance from the exact weights.  Two to four of the 2 L + 1
+                    // tap iterations of a wave take it.)
+                    w = quot<T>(sj * rc_near_num<T>(t), pi_x * (two - t));
                 } else {
                     const T c = cb0 * tabc[k] - sb0 * tabs[k];
                     w = quot<T>(sj * c, pi_x * (one - arg * arg));

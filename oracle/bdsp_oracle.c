@@ -21,6 +21,31 @@
 #define M_PI 3.14159265358979323846
 #endif
 
+/* ---- exact-weights mode of the raised cosine (round 5) -----------------------------------------------------------------
+ * The reference evaluates sin(pi x) cos(pi x beta) / (pi x) / (1 - (2 beta x)^2) in T (conv_types.rs:419-421).  Next to the
+ * second singularity, |2 beta x| -> 1, numerator and denominator cancel: a tap that lands within an ulp of 1 / (2 beta)
+ * without being EQUAL to it (x = -6 - 0.8 + 0.3 against 2.5) comes out of that expression without a correct digit, in the
+ * reference as in its literal restatement below, and a result computed from such a tap cannot be compared with anybody
+ * else's.  orc_set_exact_weights(1) makes orc_conv_time return, for the SAME argument x in T, the weight evaluated in long
+ * double through the cancellation-free form cos(pi u / 2) / (1 - u^2) = sin(pi t / 2) / (t (2 - t)), t = 1 - |u|, u = 2 beta x:
+ * the yardstick for the taps the reference itself cannot vouch for.  Default 0 = the literal restatement, which the
+ * reference's golden vectors pin (tests/test_oracle_golden.py).  Test infrastructure; not thread-safe against a
+ * concurrent switch. */
+static int g_exact_weights = 0;
+void orc_set_exact_weights(int on) { g_exact_weights = on; }
+int orc_get_exact_weights(void) { return g_exact_weights; }
+static long double orc_rc_exact(long double rolloff, long double x)
+{
+    const long double pi = 3.14159265358979323846264338327950288L;
+    if (x == 0.0L) return 1.0L;
+    const long double sinc = sinl(pi * x) / (pi * x);
+    const long double u = 2.0L * rolloff * x, au = fabsl(u), t = 1.0L - au;
+    long double g;
+    if (fabsl(t) < 0.25L) g = t == 0.0L ? pi / 4.0L : sinl(pi * t / 2.0L) / (t * (2.0L - t));
+    else g = cosl(pi * u / 2.0L) / (1.0L - u * u);
+    return sinc * g;
+}
+
 /* ---- f32 instantiation ---- */
 #define REAL float
 #define SFX(x) x##_f32

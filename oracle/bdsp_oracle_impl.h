@@ -214,6 +214,7 @@ REAL SFX(orc_conv_time)(int id, REAL rolloff, REAL x)
         REAL pi_x = pi * x;
         return R_SIN(pi_x) / pi_x;
     }
+    if (g_exact_weights) return (REAL)orc_rc_exact((long double)rolloff, (long double)x); /* (bdsp_oracle.c: the yardstick mode) */
     /* conv_types.rs:406-424 */
     const REAL four = two * two;
     if (R_FABS(x) == one / (two * rolloff)) {

@@ -129,6 +129,21 @@ def conv_time(fid, rolloff, x, dtype=np.float32):
     return fn(fid, rolloff, x)
 
 
+class exact_weights:
+    """Context manager: inside it the oracle's raised cosine returns, for the same argument in T, the weight evaluated in
+    long double through the cancellation-free form near its second singularity (oracle/bdsp_oracle.c: the reference's
+    own expression has no correct digit left for a tap that lands NEXT to 1 / (2 beta)).  Everything built on
+    orc_conv_time follows: interpolatef (both paths), convolve(function)."""
+
+    def __enter__(self):
+        lib.orc_set_exact_weights(1)
+        return self
+
+    def __exit__(self, *a):
+        lib.orc_set_exact_weights(0)
+        return False
+
+
 def conv_freq(fid, rolloff, x, dtype=np.float32):
     fn = _fn("orc_conv_freq", dtype); r = _real(dtype)
     fn.argtypes = [C.c_int, r, r]; fn.restype = r

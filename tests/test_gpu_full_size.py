@@ -183,12 +183,14 @@ def test_c5_shard_of_64_1m_vectors_against_the_oracle():
     assert np.array_equal(piped.cpu().numpy(), out)
 
 
-@pytest.mark.parametrize("bits,dtype", [(21, np.float32), (22, np.float32), (21, np.float64), (22, np.float64)])
+@pytest.mark.parametrize("bits,dtype", [(19, np.float32), (21, np.float32), (22, np.float32), (19, np.float64), (21, np.float64), (22, np.float64)])
 def test_two_pass_lengths_2m_and_4m_with_every_fused_option(bits, dtype):
-    """2^21 and 2^22 points run as TWO passes of 1024/2048-point columns (plan_passes, fft_impl.h) -- the 2^21-point f32
-    transform with its last pass in place.  Against the oracle's f64 transform: plain_fft, fft (shift fused into the
-    last pass), windowed_fft (window fused into the first), plain_fft -> magnitude (reshaping output), and the round
-    trip through ifft."""
+    """2^21 and 2^22 points run as TWO passes of long columns (plan_passes, fft_impl.h; round 5: 2^22 f32 = 4096-point
+    columns in 4-wide tiles, then 1024-point columns), and from 2^19 points on the last pass of a two-pass plan runs in
+    place (capi.cpp fft_two_buffers: the result is left in the trade buffer).  Against the oracle's f64 transform:
+    plain_fft, fft (shift fused into the last pass), windowed_fft (window fused into the first), plain_fft -> magnitude
+    (reshaping output: not in place), the round trip through ifft, and a REAL vector's plain_fft (real input read by the
+    first pass)."""
     n = 1 << bits
     tol = 1e-6 if dtype == np.float32 else 1e-12
     x = orc.fill_uniform(2 * n, SEED_C2 + bits, -10, 10, dtype)
@@ -206,9 +208,15 @@ def test_two_pass_lengths_2m_and_4m_with_every_fused_option(bits, dtype):
     v = DspVec(x, is_complex=True)
     assert v.plain_fft() == 0 and v.magnitude() == 0
     assert len(v) == n and rel_l2(v.data(), orc.magnitude(ref)) < tol
+    xr = x[:n].copy()
+    v = DspVec(xr, is_complex=False)
+    assert v.plain_fft() == 0 and v.is_complex() and len(v) == 2 * n
+    xc = np.zeros(2 * n, np.float64)
+    xc[0::2] = xr
+    assert rel_l2(v.data(), orc.fft(xc)) < tol
 
 
-@pytest.mark.parametrize("bits,dtype", [(13, np.float32), (20, np.float32), (23, np.float32), (14, np.float64), (21, np.float64)])
+@pytest.mark.parametrize("bits,dtype", [(13, np.float32), (19, np.float32), (20, np.float32), (22, np.float32), (23, np.float32), (14, np.float64), (19, np.float64), (21, np.float64)])
 def test_every_reference_window_fused_into_the_first_global_pass(bits, dtype):
     """Above 4096 points all four reference windows (triangular, Hamming / Hann, Blackman-Harris, rectangular) are applied
     in the registers of the first global pass (k_fft_pass: two sincospi per thread + host constants for the cosine
@@ -285,11 +293,11 @@ def test_bluestein_lengths_over_two_pass_transforms(n, dtype):
     assert rel_l2(v.data().astype(np.float64) / n, x) < (4e-6 if dtype == np.float32 else 1e-12)
 
 
-def test_c2_batch_of_40_fft_magnitude_in_cache_sized_chunks():
-    """40 x 1 048 576-point complex f32 plain_fft -> magnitude in ONE device call (config C2 batched): 320 MB of data, which
-    the library walks in two chunks of 20 vectors that share the scratch buffer (fft_two_buffers, capi.cpp).  The
-    magnitudes come back compact (1M reals per vector at the head of the data buffer): every vector must equal the
-    single-vector fused call bit for bit, vector 0 and the last one also the oracle's f64 transform."""
+def test_c2_batch_of_40_fft_magnitude_in_one_call():
+    """40 x 1 048 576-point complex f32 plain_fft -> magnitude in ONE device call (config C2 batched): 320 MB of data in
+    one piece (rounds 2-4 walked such a batch in cache-sized chunks of vectors; on valid data that bought nothing, DESIGN.md
+    4.2).  The magnitudes come back compact (1M reals per vector at the head of the data buffer): every vector must equal
+    the single-vector fused call bit for bit, vector 0 and the last one also the oracle's f64 transform."""
     import ctypes as C
     import torch
     from basic_dsp_amd import _lib

@@ -520,6 +520,35 @@ def test_interpolatef_fractional_factor_kernel_singularities_and_fallback(cplx, 
         assert rel_l2(v.data(), ref) < (2e-5 if dtype == np.float32 else 1e-12), (fid, big, rel_l2(v.data(), ref))
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("cplx", [True, False])
+def test_raised_cosine_next_to_its_second_singularity(cplx, dtype):
+    """Roll-off 0.2 puts the raised cosine's second singularity at |x| = 2.5, and with a delay of 0.3 or 0.5 the accumulated
+    tap arguments land ON it or an ulp BESIDE it (-6 - 0.8 + 0.3).  Beside it the reference's expression
+    sin(pi x) cos(pi x beta) / (pi x) / (1 - (2 beta x)^2) (conv_types.rs:419-421) cancels in numerator and denominator and
+    keeps no correct digit -- the literal oracle returns 0.1098 where the weight is 0.1000 -- so a result built on such a tap
+    cannot be compared with the reference's.  Every raised-cosine evaluation of the library takes the cancellation-free
+    form there (dsp_funcs.h rc_near_num) and is held to the oracle's EXACT-weights mode (same lattice of arguments in T,
+    weights in long double); the literal oracle must be the one that is off.  Both interpolatef paths."""
+    e = 2 if cplx else 1
+    tol = 2e-6 if dtype == np.float32 else 1e-12
+    x = orc.fill_uniform(e * 3000, 201602225, -10, 10, dtype)
+    literal_off = 0
+    for factor, delay, conv_len, rolloff in [(2.5, 0.3, 6, 0.2), (2.5, 0.5, 6, 0.2), (48.0 / 44.1, 0.5, 16, 0.2), (2.0, 0.5, 6, 0.2),
+                                             (4.0, 0.5, 12, 0.2), (2.5, 0.5, 8, 0.5), (3.0, 0.25, 9, 0.4)]:
+        v = DspVec(x, is_complex=cplx, delta=1.0)
+        assert v.interpolatef(1, factor, delay, conv_len, rolloff) == 0
+        with orc.exact_weights():
+            ref, path = orc.interpolatef(x, cplx, 1, rolloff, dtype(factor), delay, conv_len)
+        lit, _ = orc.interpolatef(x, cplx, 1, rolloff, dtype(factor), delay, conv_len)
+        got = v.data()
+        assert len(v) == ref.size
+        assert rel_l2(got, ref) < tol, (factor, delay, conv_len, rolloff, path, rel_l2(got, ref), rel_l2(lit, ref))
+        literal_off += rel_l2(lit, ref) > 10 * tol
+    if dtype == np.float64:
+        assert literal_off >= 2  # (the reference's own arithmetic is what fails these cases, by 1e-6 ... 1e-3)
+
+
 @pytest.mark.parametrize("cplx", [True, False])
 def test_interpolatef_f64_integer_factors_ragged_lengths(cplx):
     # f64, integer factors with and without a blocked inner kernel (2, 4, 8 / 16), ragged lengths (the last workgroup's

@@ -548,3 +548,27 @@ def test_reference_overlap_discard_schedule_leaves_a_gap_for_some_sizes():
     h2 = orc.fill_uniform(2 * 1024, 9, -1, 1, np.float64) / 1024
     code, y2, _ = orc.convolve_signal(x, h2, True)
     assert code == 0 and np.max(np.abs(y2 - orc.convolve_direct(x, h2, True))) < 1e-9
+
+
+def test_exact_weights_mode_is_the_literal_raised_cosine_where_that_is_well_conditioned():
+    """orc_set_exact_weights(1) (oracle/bdsp_oracle.c) replaces the raised cosine's literal expression by a long-double,
+    cancellation-free evaluation at the same argument: away from the second singularity the two agree to rounding, AT it
+    both return the reference's limit value, and an ulp beside it the literal one has lost its digits (which is why the
+    mode exists).  The golden vectors above pin the literal mode, the default."""
+    import ctypes as C
+    assert orc.lib.orc_get_exact_weights() == 0
+    for dtype, tol in ((np.float32, 3e-6), (np.float64, 1e-13)):
+        for beta in (0.2, 0.35, 0.5):
+            xs = [x for x in np.linspace(-12.3, 12.3, 247) if abs(1 - abs(2 * beta * x)) > 0.05]
+            lit = np.array([orc.conv_time(1, beta, float(x), dtype) for x in xs])
+            with orc.exact_weights():
+                assert orc.lib.orc_get_exact_weights() == 1
+                ex = np.array([orc.conv_time(1, beta, float(x), dtype) for x in xs])
+                at = orc.conv_time(1, beta, 1 / (2 * beta), dtype)
+            assert orc.lib.orc_get_exact_weights() == 0
+            assert np.max(np.abs(lit - ex)) < tol
+            assert abs(at - orc.conv_time(1, beta, 1 / (2 * beta), dtype)) < tol
+    beside = float(np.nextafter(2.5, 3.0))
+    with orc.exact_weights():
+        good = orc.conv_time(1, 0.2, beside, np.float64)
+    assert abs(good - 0.1) < 1e-12 and abs(orc.conv_time(1, 0.2, beside, np.float64) - 0.1) > 1e-3

@@ -34,7 +34,7 @@ def timed(fn, iters, sp, warm_s=0.3):
 
 
 def setenv(d):
-    for k in ("BDSP_CONV_NTS", "BDSP_CONV_STAGGER_US"):
+    for k in ("BDSP_CONV_NTS", "BDSP_CONV_STAGGER_US", "BDSP_CONV_V3"):
         os.environ.pop(k, None)
     os.environ.update(d)
 
@@ -58,6 +58,9 @@ if what in ("f64", "c5"):
                      ("shares 60 / 40", {}, (60, 0)), ("shares 52 / 48", {}, (52, 0)),
                      ("streamed stores, second group 6 us later", {"BDSP_CONV_NTS": "1", "BDSP_CONV_STAGGER_US": "6"}, None),
                      ("streamed stores, equal shares", {"BDSP_CONV_NTS": "1"}, (50, 0)),
+                     ("512 threads x 8 points (k_overlap_save_v3)", {"BDSP_CONV_V3": "1"}, None),
+                     ("512 threads x 8 points, streamed stores", {"BDSP_CONV_V3": "1", "BDSP_CONV_NTS": "1"}, None),
+                     ("512 threads x 8 points, equal shares", {"BDSP_CONV_V3": "1"}, (50, 0)),
                      ("default (again)", {}, None)]
     for name, env, shares in variants:
         setenv(env)
@@ -68,8 +71,9 @@ if what in ("f64", "c5"):
         torch.cuda.synchronize()
         if ref is None: ref = y.clone(); same = True
         else: same = bool(torch.equal(y, ref))
+        err = 0.0 if same else float(torch.linalg.vector_norm((y - ref).double()) / torch.linalg.vector_norm(ref.double()))
         us = timed(conv, iters, sp)
-        line = "%-4s %-46s %8.1f us  (%.3f of 8 TB/s)  result %s" % (what, name, us, 2 * n * b * (16 if elem else 8) / us / 1e3 / 8000, "bit-identical" if same else "DIFFERS")
+        line = "%-4s %-46s %8.1f us  (%.3f of 8 TB/s)  result %s" % (what, name, us, 2 * n * b * (16 if elem else 8) / us / 1e3 / 8000, "bit-identical" if same else "rel-L2 %.1e from the default's" % err)
         if what == "c5":
             def both(i):
                 conv(i)

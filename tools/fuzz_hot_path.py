@@ -34,6 +34,7 @@ def pick_n(hi):
 
 t_end = time.time() + budget
 count = 0
+ill_conditioned = 0  # raised-cosine cases the reference itself cannot vouch for (judged against exact weights)
 while time.time() < t_end:
     dtype = np.float32 if rng.random() < 0.6 else np.float64
     tol = 2e-6 if dtype == np.float32 else 1e-11
@@ -74,21 +75,35 @@ while time.time() < t_end:
         ok, what = max(r, head) < tol * 2, ("conv", n, m, cplx, dtype.__name__, r, head)
     elif op == 2:  # interpolatef
         n = int(rng.integers(30, 60000))
-        factor = float(rng.choice([2.0, 3.0, 4.0, 8.0, 1.5, 2.5, 0.75, 5.0]))
+        # round 5: fractional factors that are not short binary fractions, every roll-off whose second singularity the taps can
+        # hit exactly (1 / (2 beta) = 4, 2, 1) next to 0.35, integer and fractional delays -- the fractional-factor kernel's
+        # selects and its cancellation-free branch near |2 beta j| = 1
+        factor = float(rng.choice([2.0, 3.0, 4.0, 8.0, 1.5, 2.5, 0.75, 5.0, 48.0 / 44.1, 1.25, 44.1 / 48.0, 3.7]))
         L = int(rng.integers(1, 20))
-        fid, ro = (0, 0.0) if rng.random() < 0.5 else (1, 0.35)
+        fid, ro = (0, 0.0) if rng.random() < 0.4 else (1, float(rng.choice([0.35, 0.125, 0.25, 0.5, 0.2])))
+        delay = float(rng.choice([0.0, 0.0, 1.0, -2.0, 0.3, 0.5]))
         x = orc.fill_uniform(e * n, seed, -10, 10, dtype)
         v = DspVec(x, is_complex=cplx)
-        assert v.interpolatef(fid, factor, 0.0, L, rolloff=ro) == 0
+        assert v.interpolatef(fid, factor, delay, L, rolloff=ro) == 0
         # the oracle runs in the vector's own precision for the output length and the path choice, in f64 for the values
         # the sampling positions i / factor are computed in T by the reference (and here): for fractional factors the
         # comparison must use the oracle in the SAME precision, an f64 oracle sits 1e-3 away at f32 (position error
         # 6e-8 * 4e4 samples); power-of-two factors have exact positions and are held to the f64 oracle
-        exact = factor in (2.0, 4.0, 8.0)   # i / factor is exact in binary floating point only for these
-        ref, _path = orc.interpolatef(x.astype(np.float64) if exact else x, cplx, fid, ro, factor, 0.0, L)
+        exact = factor in (2.0, 4.0, 8.0) and delay == 0.0   # i / factor is exact in binary floating point only for these
+        ref, _path = orc.interpolatef(x.astype(np.float64) if exact else x, cplx, fid, ro, dtype(factor) if not exact else factor, delay, L)
         r = rel(v.data(), ref) if len(ref) == len(v.data()) else 1.0
         lim = tol * 3 if exact else (3e-5 if dtype == np.float32 else 1e-10)
-        ok, what = r < lim, ("interpolatef", n, factor, L, fid, cplx, dtype.__name__, r)
+        ok, what = r < lim, ("interpolatef", n, factor, delay, L, fid, ro, cplx, dtype.__name__, r)
+        if not ok and fid == 1:
+            # a tap next to the raised cosine's second singularity: the reference's expression (and the literal oracle) has
+            # no correct digit there; the library's cancellation-free form is held to the oracle's exact-weights mode, and
+            # the literal oracle must be the one that is off (oracle/bdsp_oracle.c)
+            with orc.exact_weights():
+                ref2, _ = orc.interpolatef(x.astype(np.float64) if exact else x, cplx, fid, ro, dtype(factor) if not exact else factor, delay, L)
+            r2, rl = rel(v.data(), ref2), rel(ref, ref2)
+            ok = r2 < lim and rl > lim / 4
+            ill_conditioned += ok
+            what = what + ("vs exact weights", r2, "literal oracle vs exact", rl)
     elif op == 4:  # windowed_fft with every window, any length
         n = pick_n(100000)
         if n < 2: n = 2
@@ -254,4 +269,5 @@ while time.time() < t_end:
     if not ok:
         print("MISMATCH", what)
         sys.exit(1)
-print("fuzz ok: %d cases in %.0f s" % (count, budget))
+print("fuzz ok: %d cases in %.0f s (seed %s, size scale %d; %d raised-cosine cases next to the second singularity judged against exact weights)" %
+      (count, budget, sys.argv[2] if len(sys.argv) > 2 else "12345", SCALE, ill_conditioned))
