@@ -78,8 +78,8 @@ static __device__ __forceinline__ unsigned xcd_contiguous(unsigned bid, unsigned
 // 2 no global stores, 8 no transform (3 = arithmetic + exchanges alone, 8 = the memory skeleton alone); the output is
 // garbage.  They put a measured bound next to the f64 and real-data kernels' roofline fractions.
 // NTS: the interior blocks' results are STREAMED (non-temporal stores) -- for results the 256 MB Infinity Cache cannot hold
-// anyway (round 5; round 3 measured the compile-time form: 16M f64 points 129 -> 123 us, and +8 us on the headline step,
-// whose 128 MB result the transform that follows reads back from the cache).
+// anyway (round 5, conv_v2_streams_result below; round 3 measured the compile-time form on the headline step: +8 us, its
+// 128 MB result is read back from the cache by the transform that follows).
 template <typename T, int R0, bool BATCHED, bool REAL = false, int ABL = 0, bool NTS = false>
 __global__ __launch_bounds__(256, sizeof(T) == 4 ? 3 : 2) void k_overlap_save_v2(ConvV2Args<T> a)
 {
@@ -350,8 +350,9 @@ __global__ __launch_bounds__(256, sizeof(T) == 4 ? 3 : 2) void k_overlap_save_v2
 // the product kernel has two, at the price of a fourth stage and a third LDS exchange per transform (12 barriers per
 // block instead of 8).  Rows are 512 points: R0 = ceil((M - 1) / 512) = 2 discarded rows for 1024 taps, V = 3072 as in the
 // product.  Stage-2 / stage-3 twiddles (four values per thread: dft8_tw) from LDS tables of 8 x 4 and 64 x 4 entries,
-// stage 4 from two held values {w^2, w} (w^4 by squaring, w W8 by a constant).  tools/conv_probe.py compares it with the
-// product kernel's result and times it.
+// stage 4 from two held values {w^2, w} (w^4 by squaring, w W8 by a constant).  128 VGPRs, no scratch, four waves per SIMD.
+// *Measured* (tools/conv_probe.py: correct on its first run, 6.3e-16 rel-L2 from the product kernel's result): 145.5-150.2 us
+// against 120.5-123.1 -- twice the waves buy nothing, the fourth stage and the third exchange cost 20 %.  Not adopted.
 template <int R0, bool NTS>
 __global__ __launch_bounds__(512, 4) void k_overlap_save_v3(ConvV2Args<double> a)
 {
@@ -526,9 +527,10 @@ static int launch_v2(const ConvV2Args<T>& a, unsigned grid, size_t lds, hipStrea
 }
 
 // results above this size are streamed: see k_overlap_save_v2 NTS (set from the measurements of round 5)
-// *Measured* (tools/conv_probe.py, profiles/r05_conv_probe.txt): 16M complex f64 points (256 MB in, 256 MB out) 124.3-128.1 ->
-// 119.2-122.4 us; 64 x 1M f32 (512 MB) 225 -> 222 us for the kernel and 629 -> 632 for convolve -> fft, so f32 batches are
-// left alone; the headline's 128 MB result must NOT be streamed (step 182 -> 193 us: the transform reads it from the cache).
+// *Measured* (tools/conv_probe.py, profiles/r05_conv_probe.txt): 16M complex f64 points (256 MB in, 256 MB out), twelve interleaved
+// runs each way in two processes: 121.5 / 123.0 -> 118.8 / 120.3 us (-2.2 %; single runs move by +-5 % on one box); 64 x 1M f32
+// (512 MB) 225 -> 222 us for the kernel and 629 -> 632 for convolve -> fft, so f32 batches are left alone; the headline's 128 MB
+// result must NOT be streamed (step 181 -> 192 us: the transform reads it from the cache).
 template <typename T>
 static bool conv_v2_streams_result(size_t points, size_t batch)
 {

@@ -235,7 +235,7 @@ def cpu_baseline(points, taps, sample_points, vectors=1):
     }
 
 
-PROFILE_TAG = "r04"  # profiles/<tag>_* are the files tools/profile_round.sh writes (TAG=r04)
+PROFILE_TAG = "r05"  # profiles/<tag>_* are the files tools/profile_round.sh writes (TAG=r05)
 
 
 def kernel_source_sha16():

@@ -39,6 +39,26 @@ def setenv(d):
     os.environ.update(d)
 
 
+if what == "f64ab":
+    # streamed stores against plain ones, INTERLEAVED (a single pair of timings moves by +-5 % on one box): 12 alternations
+    sp = bd._lib.torch_stream_arg()
+    n, elem = 1 << 24, 1
+    g = torch.Generator(device=dev).manual_seed(3)
+    xs = [torch.rand(2 * n, device=dev, dtype=torch.float64, generator=g) * 20 - 10 for _ in range(2)]
+    taps = (torch.rand(2 * m, device=dev, dtype=torch.float64, generator=g) * 2 - 1) / m
+    y = torch.empty(2 * n, device=dev, dtype=torch.float64)
+    conv = lambda i: lib.bdsp_hip_dev_convolve(elem, xs[i % 2].data_ptr(), y.data_ptr(), n, 1, taps.data_ptr(), m, sp)
+    res = {"0": [], "1": []}
+    for rep in range(12):
+        for mode in ("0", "1") if rep % 2 == 0 else ("1", "0"):
+            os.environ["BDSP_CONV_NTS"] = mode
+            res[mode].append(timed(conv, 15, sp, warm_s=0.15 if rep else 0.4))
+    for mode, name in (("0", "plain stores"), ("1", "streamed stores")):
+        v = sorted(res[mode])
+        print("f64 16M (*) 1024 taps, %-16s median of 12 interleaved runs %6.1f us  (min %.1f, max %.1f)  all: %s" %
+              (name, (v[5] + v[6]) / 2, v[0], v[-1], " ".join("%.1f" % t for t in res[mode])), flush=True)
+    sys.exit(0)
+
 if what in ("f64", "c5"):
     sp = bd._lib.torch_stream_arg()
     if what == "f64": n, b, dt, elem, nbuf, iters = 1 << 24, 1, torch.float64, 1, 2, 15

@@ -2,7 +2,7 @@
 # Per-round profiles (TAG=r04 ...) (run on the GPU box through gpurun): rocprofv3 kernel stats and PMC counters for the bench step
 # and for every BASELINE config (tools/bench_configs.py).  Outputs under gpurun_out/${TAG}prof/, copied to profiles/.
 set -u
-TAG=${TAG:-r04}
+TAG=${TAG:-r05}
 RP="timeout -k 5 600 rocprofv3"   # a counter set the hardware cannot collect makes the tool abort and then hang: bound every run
 ROOT=$GRAFT_REPO_ROOT
 OUT=$ROOT/gpurun_out/${TAG}prof
