@@ -510,7 +510,9 @@ __device__ __forceinline__ void pass_window16(const FftIo<T>& io, size_t i0, siz
 // the first pass and output of the last keep their W-wide runs.
 // WIN: -1 = the window id is read at run time (and is Hamming / Hann where the tile uses the split exchange); 0 / 2: the
 // split-exchange tiles' instantiations for the triangular and the Blackman-Harris window (pass_window16 FIXED).
-template <typename T, int RP, int W, int DIR, bool ROWMAP, bool GEN, bool SIMPLE = false, int TL = 0, int WIN = -1>
+// NTL (round 5): the FIRST pass reads its input -- dead once read -- with non-temporal loads.  f64 only, and only where the
+// tile's runs are whole 128-byte lines (pass_ntl_candidate): see launch_pass for the measurements.
+template <typename T, int RP, int W, int DIR, bool ROWMAP, bool GEN, bool SIMPLE = false, int TL = 0, int WIN = -1, bool NTL = false>
 __global__ __launch_bounds__(W * (RP / 16), (pass_min_waves<T, RP, W, GEN>())) void k_fft_pass(FftIo<T> io, const cpx<T>* src, // (src may equal dst: the in-place last pass)
                                                    cpx<T>* dst,
                                                    const cpx<T>* __restrict__ wtab, size_t n,
@@ -577,7 +579,7 @@ __global__ __launch_bounds__(W * (RP / 16), (pass_min_waves<T, RP, W, GEN>())) v
 #if defined(BDSP_LAB) && defined(BDSP_FFT_NTLOAD)
                 v[r] = (BDSP_FFT_NTLOAD != 2 || ROWMAP) ? nt_load(&in[(size_t)(ti + (r ^ rx) * NT) * stride_in]) : in[(size_t)(ti + (r ^ rx) * NT) * stride_in];
 #else
-                v[r] = in[(size_t)(ti + (r ^ rx) * NT) * stride_in];
+                v[r] = NTL ? nt_load(&in[(size_t)(ti + (r ^ rx) * NT) * stride_in]) : in[(size_t)(ti + (r ^ rx) * NT) * stride_in];
 #endif
         }
         if (!SIMPLE && ROWMAP && io.in_scale != (T)1) {
@@ -995,6 +997,13 @@ constexpr bool pass_tiled_pair()
 #endif
 }
 
+// first-pass tiles that read their (dead) input with non-temporal loads: f64, whole 128-byte lines per row (launch_pass)
+template <typename T, int RP, int W>
+constexpr bool pass_ntl_candidate()
+{
+    return sizeof(T) == 8 && (size_t)W * sizeof(cpx<T>) >= 128;
+}
+
 // tiles the product's plans use as a FIRST pass only: their later-pass instantiations are not built (LAB: all are)
 template <int RP, int W>
 constexpr bool pass_first_only()
@@ -1034,15 +1043,30 @@ static int launch_pass(const FftIo<T>& io_in, const cpx<T>* src, cpx<T>* dst, si
     // plain first / last pass?  (then no option is looked at inside the kernel)
     const bool simple = !gen && (rowmap ? ((io.flags & (FFT_IN_REAL | BDSP_FFT_SHIFT_IN)) == 0 && io.in_scale == (T)1 && io.window_id < 0)
                                         : (!last || (io.flags & (BDSP_FFT_SHIFT_OUT | BDSP_FFT_MAGNITUDE | FFT_OUT_REAL | FFT_WINDOW_OUT_DIV)) == 0));
+    // Non-temporal loads in the FIRST pass of an f64 transform whose tile reads whole 128-byte lines (W >= 8: the 3-pass plans'
+    // 256 x 16 / 128 x 32 tiles, the 1024 x 8 / 512 x 8 tiles of batches and of 2^18 points).  *Measured* (round 5, LAB build with
+    // -DBDSP_FFT_NTLOAD=2, cold / input in the caches, profiles/r05_plan_probe_valid.txt runs 4-5): 16 x 2^20 214 -> 185 / 205 -> 185 us,
+    // 4 x 2^20 61.6 -> 54.0 / =, 2^23 141 -> 133 / 130 -> 127, 2^24 327 -> 324 / 312 -> 304, 32 x 2^20 419 -> 417 / 404 -> 398, 256 x 2^16 and
+    // 2^18 equal.  NOT where the tile reads half lines (2^21 / 2^22 f64 single vectors: cold 36.6 -> 33.7 / 67.2 -> 60.8 but with
+    // the input in the caches 28.1 -> 32.5 / 46.1 -> 62.3 -- every half line becomes a fetch of its own), and not in f32, where it
+    // is a wash or worse (2^23 -5 % cold, 2^24 -6 % cold / +1 % hot, 2^25 +6 %, 64 x 2^20 +8 %, 4096 x 2^14 +1 %).
+    const bool ntl = pass_ntl_candidate<T, RP, W>() && first && rowmap && !gen && !(io.flags & FFT_IN_REAL);
     // (tiled instantiations exist for the long columns only: pass_tiled_pair)
     if (tl != 0 && (!pass_tiled_pair<RP>() || (tl == 1) != rowmap)) { set_last_error("tiled intermediate: unsupported pass"); return BDSP_ERR_UNSUPPORTED; }
-#define BDSP_PASS(DIRV, RM, GENV, SV, TLV, WINV)                                                   \
+#define BDSP_PASS_K(DIRV, RM, GENV, SV, TLV, WINV, NTLV)                                            \
     do {                                                                                           \
         constexpr size_t lds = pass_tile_lds_bytes<T, RP, W, GENV>() +                             \
                                (pass_lds_twiddles<T, RP, W, GENV>() ? (size_t)RP * sizeof(cpx<T>) : 0); \
-        BDSP_TRY(set_lds(k_fft_pass<T, RP, W, DIRV, RM, GENV, SV, TLV, WINV>, lds));               \
-        hipLaunchKernelGGL((k_fft_pass<T, RP, W, DIRV, RM, GENV, SV, TLV, WINV>), grid, dim3(THREADS), lds, s, \
+        BDSP_TRY(set_lds(k_fft_pass<T, RP, W, DIRV, RM, GENV, SV, TLV, WINV, NTLV>, lds));         \
+        hipLaunchKernelGGL((k_fft_pass<T, RP, W, DIRV, RM, GENV, SV, TLV, WINV, NTLV>), grid, dim3(THREADS), lds, s, \
                            io, src, dst, wtab, n, nsg, tiles, (int)last, aux);                     \
+    } while (0)
+#define BDSP_PASS(DIRV, RM, GENV, SV, TLV, WINV)                                                   \
+    do {                                                                                           \
+        if constexpr (pass_ntl_candidate<T, RP, W>() && RM && !GENV && TLV == 0) {                 \
+            if (ntl) { BDSP_PASS_K(DIRV, RM, GENV, SV, TLV, WINV, true); break; }                  \
+        }                                                                                          \
+        BDSP_PASS_K(DIRV, RM, GENV, SV, TLV, WINV, false);                                         \
     } while (0)
 #define BDSP_PASS_V(DIRV, RM, TLV)                                                                 \
     do {                                                                                           \
@@ -1070,6 +1094,7 @@ static int launch_pass(const FftIo<T>& io_in, const cpx<T>* src, cpx<T>* dst, si
 #undef BDSP_PASS_D
 #undef BDSP_PASS_V
 #undef BDSP_PASS
+#undef BDSP_PASS_K
     BDSP_LAUNCH_CHECK();
     return BDSP_OK;
 }
