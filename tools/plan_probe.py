@@ -24,7 +24,8 @@ import numpy as np, torch
 import basic_dsp_amd as bd
 
 ap = argparse.ArgumentParser()
-ap.add_argument("--bits", required=True)
+ap.add_argument("--bits", default=None)
+ap.add_argument("--points", default=None, help="any lengths instead of --bits (mixed-radix / chirp-z plans): comma separated")
 ap.add_argument("--prec", default="f32")
 ap.add_argument("--batch", type=int, default=1)
 ap.add_argument("--flags", type=int, default=0)
@@ -69,9 +70,11 @@ def set_plan(p):
 junk = torch.empty(1 << 28, device=dev, dtype=torch.float32)  # 1 GB: what flushes the L2s and the 256 MB Infinity Cache
 EV0 = ev_overhead()
 
-for bits in [int(b) for b in a.bits.split(",")]:
-    n, b = 1 << bits, a.batch
-    g = torch.Generator(device=dev).manual_seed(5 + bits)
+sizes = [(int(b), 1 << int(b)) for b in a.bits.split(",")] if a.bits else [(None, int(v)) for v in a.points.split(",")]
+for bits, n in sizes:
+    b = a.batch
+    label = ("2^%-2d" % bits) if bits is not None else ("%-9d" % n)
+    g = torch.Generator(device=dev).manual_seed(5 + (bits if bits is not None else n % 1000))
     pristine = torch.rand(2 * n * b, device=dev, dtype=dt, generator=g) * 20 - 10
     y = torch.empty(2 * n * b, device=dev, dtype=dt)
     vec_bytes = 2 * n * b * esz
@@ -91,10 +94,10 @@ for bits in [int(b) for b in a.bits.split(",")]:
         set_plan(plan)
         w = pristine.clone()
         rc = call(w); torch.cuda.synchronize()
-        row = {"bits": bits, "prec": a.prec, "batch": b, "flags": a.flags, "window": wid, "plan": plan, "tag": a.tag}
+        row = {"bits": bits, "points": n, "prec": a.prec, "batch": b, "flags": a.flags, "window": wid, "plan": plan, "tag": a.tag}
         if rc != 0:
             row["rc"] = rc
-            print(json.dumps(row) if a.json else "2^%-2d %s x%-3d %-28s %-22s rc=%d (unsupported)" % (bits, a.prec, b, plan, a.tag, rc), flush=True)
+            print(json.dumps(row) if a.json else "%s %s x%-3d %-28s %-22s rc=%d (unsupported)" % (label, a.prec, b, plan, a.tag, rc), flush=True)
             continue
         res = result(w)
         if a.flags == 0 and wid < 0 and not a.inverse:
@@ -139,7 +142,7 @@ for bits in [int(b) for b in a.bits.split(",")]:
         del bufs, scr
         if a.only == "cold":
             torch.cuda.synchronize()
-            print("2^%-2d %s x%-3d fl=%-2d win=%-2d %-28s %-22s cold %8.2f us" % (bits, a.prec, b, a.flags, wid, plan, a.tag, cold), flush=True)
+            print("%s %s x%-3d fl=%-2d win=%-2d %-28s %-22s cold %8.2f us" % (label, a.prec, b, a.flags, wid, plan, a.tag, cold), flush=True)
             continue
         # hot: the input written right before the call
         pairs = []
@@ -159,7 +162,7 @@ for bits in [int(b) for b in a.bits.split(",")]:
         row.update({"us": round(cold, 2), "us_hot": round(hot, 2), "rel_l2": err, "iters": iters})
         if a.json: print(json.dumps(row), flush=True)
         else:
-            print("2^%-2d %s x%-3d fl=%-2d win=%-2d %-28s %-22s cold %8.2f us   hot %8.2f us   err %.2e" %
-                  (bits, a.prec, b, a.flags, wid, plan, a.tag, cold, hot, err), flush=True)
+            print("%s %s x%-3d fl=%-2d win=%-2d %-28s %-22s cold %8.2f us   hot %8.2f us   err %.2e" %
+                  (label, a.prec, b, a.flags, wid, plan, a.tag, cold, hot, err), flush=True)
     del pristine, y
     torch.cuda.empty_cache()
