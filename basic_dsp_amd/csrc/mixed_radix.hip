@@ -410,7 +410,10 @@ template <typename T> static size_t mr_pass_max(int W) { return MR_LDS_BYTES / (
 template <typename T>
 static bool mr_split(size_t n, size_t* n1, size_t* n2, int* wmax)
 {
-    for (int W = mr_tile<T>(); W >= 2; W /= 2) {
+    // (W = 1, round 5: single columns -- 8 / 16-byte pieces -- still beat the chirp-z path, which is what served these lengths
+    // before: f64 3 * 10^6 points ... see DESIGN.md 4.2)
+    static const bool no_w1 = lab_flag("BDSP_MR_NO_W1");
+    for (int W = mr_tile<T>(); W >= (no_w1 ? 2 : 1); W /= 2) {
         const size_t pm = mr_pass_max<T>(W);
         if (n > pm * pm) continue;
         size_t best = 0;
@@ -506,7 +509,7 @@ int mr_fft(const T* in, T* out, T* scratch, size_t n, size_t batch, bool inverse
     // tile width: W adjacent columns / rows per workgroup (64-byte runs); a lone transform narrows the tile until
     // every CU has a workgroup -- each tile is a chain of dependent LDS stages, so latency, not bandwidth, rules
     int W = wmax;
-    const int wmin = n >= 200000 ? 4 : 2; // *measured* 10^6 points: W = 8 / 4 / 2 -> 45.7 / 36.5 / 48.5 us; 10^5: 18.0 / 14.7 / 14.1
+    const int wmin = wmax < 2 ? 1 : (n >= 200000 ? 4 : 2); // *measured* 10^6 points: W = 8 / 4 / 2 -> 45.7 / 36.5 / 48.5 us; 10^5: 18.0 / 14.7 / 14.1
     while (W > wmin && ((n2 + W - 1) / W) * batch < (size_t)num_cus()) W /= 2;
     static const int w_env = [] { const char* e = lab_env("BDSP_MR_W"); return e ? atoi(e) : 0; }();
     if (w_env > 0 && w_env <= wmax) W = w_env;

@@ -337,6 +337,31 @@ def test_mixed_radix_three_million_points():
     assert np.linalg.norm(back - x) / np.linalg.norm(x) < 2e-6
 
 
+@pytest.mark.parametrize("n,dtype", [(3_000_000, np.float64), (3 * (1 << 20), np.float64), (16_000_000, np.float32)])
+def test_mixed_radix_single_column_tiles(n, dtype):
+    """Round 5: the four-step mixed-radix form with ONE-column tiles.  In f64 the 2-wide tiles end at factors of 1843 points
+    (3 000 000 = 1500 x 2000 does not fit), in f32 at 3686 (about 13M points); until round 5 the chirp-z path served the
+    lengths beyond, at twice the time and error.  plain_fft against the oracle's f64 transform, fft -> ifft round trip with
+    the shifts fused, and a Hann-windowed transform."""
+    tol = 1e-6 if dtype == np.float32 else 1e-12
+    x = orc.fill_uniform(2 * n, 515151 + n % 97, -10, 10, dtype)
+    v = DspVec(x, is_complex=True)
+    assert v.plain_fft() == 0
+    ref = orc.fft(x.astype(np.float64))
+    assert rel_l2(v.data(), ref) < tol
+    del v
+    v = DspVec(x, is_complex=True)
+    assert v.fft() == 0
+    assert rel_l2(v.data(), orc.swap_halves(ref, True, True)) < tol
+    assert v.ifft() == 0 and rel_l2(v.data(), x) < 2 * tol
+    del ref
+    if n <= 4_000_000:
+        v = DspVec(x, is_complex=True)
+        assert v.windowed_fft(V.WINDOW_HANN) == 0
+        w = orc.apply_window(x.astype(np.float64), True, 1, 0.5)
+        assert rel_l2(v.data(), orc.swap_halves(orc.fft(w), True, True)) < tol
+
+
 @pytest.mark.gpu
 def test_f64_and_real_convolution_4m_whole_output():
     """The f64 block kernel (filter spectrum and twiddles in registers, taps transformed in the kernel) and the real
