@@ -209,6 +209,7 @@ template <typename T> int interpolate_real_dev(const T* in, T* out, size_t len, 
 // mixed_radix.hip: lengths 2^a 3^b 5^c 7^d that are not powers of two
 template <typename T> bool mr_supported(size_t n);
 template <typename T> bool mr_resident(size_t n); // one workgroup-resident transform (may run in place)
+template <typename T> int mr_passes(size_t n);    // 1 resident, 2 four-step (result in `out`), 3 Stockham passes (out must be `scratch`)
 template <typename T> int mr_fft(const T* in, T* out, T* scratch, size_t n, size_t batch, bool inverse, unsigned flags, T in_scale,
                                  int window_id, T window_alpha, hipStream_t s);
 

@@ -186,7 +186,8 @@ int fft_any_len(T* a, T* b, size_t n, size_t batch, bool inverse, unsigned flags
         // workgroup-resident form runs in place unless the output has another shape than the input.
         const bool reshaping = (flags & (FFT_IN_REAL | BDSP_FFT_MAGNITUDE | FFT_OUT_REAL)) != 0;
         const bool resident = mr_resident<T>(n);
-        T* out = (resident && reshaping) ? b : a;
+        // (three global passes -- lengths whose four-step tile would be narrow -- end in the scratch buffer: a -> b -> a -> b)
+        T* out = ((resident && reshaping) || mr_passes<T>(n) == 3) ? b : a;
         *in_b = out == b;
         return mr_fft<T>(a, out, b, n, batch, inverse, flags, in_scale, window_id, window_alpha, s);
     }

@@ -8,13 +8,19 @@
 //   * larger n = n1 * n2 (both smooth, both <= MR_PASS_MAX): four-step --
 //       pass 1: tiles of W adjacent columns, FFT_n1 down the columns, x w_n^(k1 c), same layout out;
 //       pass 2: W adjacent rows per workgroup, FFT_n2 along the rows, transposed store X[k1 + n1 k2]
-//     -- two trips through HBM with 64-byte runs at worst (W complex values).
+//     -- two trips through HBM with 64-byte runs at worst (W complex values);
+//   * where that tile would be a single column, or n has no such split: n = r0 r1 r2, three global Stockham passes
+//     (k_mr_gpass, round 5) with 8 ... 16-wide tiles.
 // Both take the same fused options as the power-of-two and Bluestein paths: input rotation (ifft_shift), input
 // scale, window on the input or divided out of the output, real input, output rotation (fft_shift), real-part or
 // magnitude output.  Unnormalised in both directions.
 #include "bdsp_internal.h"
 #include "dsp_funcs.h"
+#include <algorithm>
 #include <cstdlib>
+#include <mutex>
+#include <unordered_map>
+#include <vector>
 
 namespace bdsp {
 
@@ -397,6 +403,62 @@ __global__ __launch_bounds__(MR_THREADS) void k_mr_pass2(MrIo<T> io, const cpx<T
     }
 }
 
+// ---- three global Stockham passes (round 5): n = R1 R2 R3, each pass an mr_stage whose butterfly is a whole RP-point
+// mixed-radix transform held in LDS -- the structure of the power-of-two k_fft_pass with any smooth super-radix:
+//     column j < n / RP, k = j mod nsg:  v[r] = in[j + r n / RP] w_n^(r k n / (nsg RP));  out[(j / nsg) nsg RP + k + r nsg] = DFT_RP(v)[r]
+// A tile is W adjacent columns: loads are runs of W values, stores runs of RP values in the first pass (nsg = 1: whole
+// output columns) and of W values afterwards.  With three factors of a few hundred points the tile stays W = 8 ... 16
+// wide (64 ... 128-byte runs, 256 in f64) where the four-step form of the same length is down to 2- or 1-wide tiles.
+template <typename T, int DIR>
+__global__ __launch_bounds__(MR_THREADS) void k_mr_gpass(MrIo<T> io, const cpx<T>* __restrict__ src, cpx<T>* __restrict__ dst,
+                                                  MrStages st, const cpx<T>* __restrict__ tw, unsigned long long n, int RP,
+                                                  unsigned long long nsg, int W, int first, int last)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    cpx<T>* a = reinterpret_cast<cpx<T>*>(smem_raw);
+    cpx<T>* b = a + (size_t)RP * W;
+    tw = mr_table_to_lds<T>(b + (size_t)RP * W, tw, RP);
+    const unsigned long long vec = blockIdx.y, cols = n / RP, j0 = (unsigned long long)blockIdx.x * W;
+    const int live = cols - j0 < (unsigned long long)W ? (int)(cols - j0) : W;
+    const cpx<T>* sv = src + vec * n;
+    const unsigned long long tstep = n / (nsg * RP);
+    const double inv = 2.0 / (double)n;
+    for (int id = threadIdx.x; id < RP * W; id += blockDim.x) {
+        const int q = id % W, r = id / W;
+        cpx<T> v{(T)0, (T)0};
+        if (q < live) {
+            const unsigned long long j = j0 + q, i = j + (unsigned long long)r * cols;
+            v = first ? mr_load<T>(io, vec, i) : sv[i];
+            if (nsg > 1 && r > 0) {
+                const unsigned long long e = (unsigned long long)r * (j % nsg) * tstep; // < n: r < RP, k < nsg
+                if (e) {
+                    double sn, cs;
+                    sincospi((double)e * inv, &sn, &cs);
+                    v = cmul(v, cpx<T>{(T)cs, (T)(DIR < 0 ? -sn : sn)});
+                }
+            }
+        }
+        a[id] = v;
+    }
+    cpx<T>* res = mr_transform<DIR, T>(a, b, RP, W, st, tw);
+    cpx<T>* dv = dst + vec * n;
+    if (nsg == 1) { // whole output columns: r fastest
+        for (int id = threadIdx.x; id < RP * W; id += blockDim.x) {
+            const int r = id % RP, q = id / RP;
+            if (q >= live) continue;
+            const unsigned long long o = (j0 + q) * RP + r;
+            if (last) mr_store<T>(io, vec, o, res[r * W + q]); else dv[o] = res[r * W + q];
+        }
+    } else {
+        for (int id = threadIdx.x; id < RP * W; id += blockDim.x) {
+            const int q = id % W, r = id / W;
+            if (q >= live) continue;
+            const unsigned long long j = j0 + q, o = (j / nsg) * nsg * RP + (j % nsg) + (unsigned long long)r * nsg;
+            if (last) mr_store<T>(io, vec, o, res[id]); else dv[o] = res[id];
+        }
+    }
+}
+
 // ---- planning and launch ------------------------------------------------------------------------------------------
 constexpr size_t MR_LDS_BYTES = 144 * 1024; // of the CU's 160 KB; one workgroup per CU either way
 
@@ -405,15 +467,25 @@ template <typename T> static int mr_tile() { return sizeof(T) == 4 ? 8 : 4; }   
 // longest sub-transform a tile of W lanes can hold: 2 ping-pong buffers of len * W points + the table
 template <typename T> static size_t mr_pass_max(int W) { return MR_LDS_BYTES / (sizeof(cpx<T>) * (2 * W + 1)); }
 
+// Four-step or three Stockham passes?  *Measured* (round 5, tools/plan_probe.py --points, cold / hot, LAB switch BDSP_MR_PLAN;
+// profiles/r05_plan_probe_valid.txt runs 8-10): while the four-step's tile is 4 or 8 wide it wins (f32 10^6 points 34 / 31 us
+// against 49 / 48, f64 37 / 34 against 65 / 60; 64 x 10^5 126 / 110 against 184 / 168); at 2-wide tiles it depends on the
+// factors (f32 3 * 10^6 82 against 116, 10^7 376 against 404, 1.296 * 10^7 448 against 496 -- but 1.2 * 10^7 559 against 462;
+// f64 2 * 10^6 112 against 89, 3.24 * 10^6 155 against 193): the four-step keeps them; where it would need single columns
+// or has no split at all, three passes take over: f64 3 * 10^6 152 / 143 us (single columns 236, chirp-z 400), 3 * 2^20 126
+// (214, 411), 6 * 10^6 315 (450, 861), 10^7 500 (chirp-z 1822); f32 2 * 10^7 724 / 692 (1115, 2019), 3 * 10^7 1004 (1613, 2083).
+template <typename T> static int mr_plan2_min_tile() { return 2; }
+constexpr size_t MR_PLAN3_MIN = 100000;
+
 // n1 * n2 = n with both factors smooth: the most balanced split, at the widest tile (W_max, W_max/2, ... 2) whose
 // LDS holds both factors (n <= 1024^2 at the full 64-byte tile, up to ~13M points with 2-wide tiles)
 template <typename T>
 static bool mr_split(size_t n, size_t* n1, size_t* n2, int* wmax)
 {
-    // (W = 1, round 5: single columns -- 8 / 16-byte pieces -- still beat the chirp-z path, which is what served these lengths
-    // before: f64 3 * 10^6 points ... see DESIGN.md 4.2)
-    static const bool no_w1 = lab_flag("BDSP_MR_NO_W1");
-    for (int W = mr_tile<T>(); W >= (no_w1 ? 2 : 1); W /= 2) {
+    // (LAB, BDSP_MR_W1: also single-column tiles -- measured in round 5: they beat the chirp-z path that served such lengths
+    // until then (f64 3 * 10^6 points 400 -> 236 us) and lose to three Stockham passes (152 us), which is what runs now)
+    static const bool w1 = lab_flag("BDSP_MR_W1");
+    for (int W = mr_tile<T>(); W >= (w1 ? 1 : 2); W /= 2) {
         const size_t pm = mr_pass_max<T>(W);
         if (n > pm * pm) continue;
         size_t best = 0;
@@ -427,16 +499,94 @@ static bool mr_split(size_t n, size_t* n1, size_t* n2, int* wmax)
     return false;
 }
 
+// n = r0 r1 r2, all smooth, for the three-pass Stockham form: the most balanced split (smallest largest factor), at the
+// widest tile W in {16, 8, 4} whose LDS holds that factor; the largest factor goes first.
+template <typename T>
+static bool mr_split3(size_t n, size_t r[3], int* wmax)
+{
+    std::vector<size_t> divs;
+    for (size_t d = 1; d * d <= n; ++d)
+        if (n % d == 0) { divs.push_back(d); if (d != n / d) divs.push_back(n / d); }
+    std::sort(divs.begin(), divs.end());
+    size_t best = 0, b0 = 0, b1 = 0, b2 = 0;
+    MrStages st;
+    const size_t cap = mr_pass_max<T>(4);
+    for (size_t d0 : divs) {
+        if (d0 < 2 || d0 > cap) continue;
+        if (!mr_factor(d0, &st)) continue;
+        const size_t m = n / d0;
+        for (size_t d1 : divs) {
+            if (d1 < 2 || d1 > d0 || m % d1) continue; // d0 >= d1 >= d2
+            const size_t d2 = m / d1;
+            if (d2 < 2 || d2 > d1) continue;
+            if (!mr_factor(d1, &st) || !mr_factor(d2, &st)) continue;
+            if (best == 0 || d0 < best) { best = d0; b0 = d0; b1 = d1; b2 = d2; }
+        }
+    }
+    if (!best) return false;
+    r[0] = b0; r[1] = b1; r[2] = b2;
+    int W = 16;
+    while (W > 4 && mr_pass_max<T>(W) < b0) W /= 2;
+    *wmax = W;
+    return true;
+}
+
+// which global form serves n (above the workgroup-resident range): 2 = four-step, 3 = three Stockham passes, 0 = neither.
+// Three passes take over where the four-step's tile would be narrower than 64 bytes in f32 / ... (measured: see mr_fft).
+struct MrPlan { int plan; size_t n1, n2, r3[3]; int w2, w3; };
+template <typename T>
+static int mr_global_plan(size_t n, size_t* n1, size_t* n2, int* w2, size_t r3[3], int* w3)
+{
+    // (the splits enumerate divisors: remembered per length -- a handle asks three times per transform)
+    static std::mutex mu;
+    static std::unordered_map<size_t, MrPlan> cache;
+    MrPlan p{};
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        auto it = cache.find(n);
+        if (it != cache.end()) p = it->second;
+        else {
+            static const int forced = [] { const char* e = lab_env("BDSP_MR_PLAN"); return e ? atoi(e) : 0; }();
+            const bool ok2 = mr_split<T>(n, &p.n1, &p.n2, &p.w2);
+            const bool ok3 = n >= (size_t)MR_PLAN3_MIN && mr_split3<T>(n, p.r3, &p.w3);
+            if (forced == 2 && ok2) p.plan = 2;
+            else if (forced == 3 && ok3) p.plan = 3;
+            else if (ok2 && (p.w2 >= mr_plan2_min_tile<T>() || !ok3)) p.plan = 2;
+            else if (ok3) p.plan = 3;
+            else p.plan = ok2 ? 2 : 0;
+            if (cache.size() < 4096) cache[n] = p;
+        }
+    }
+    *n1 = p.n1; *n2 = p.n2; *w2 = p.w2; *w3 = p.w3;
+    r3[0] = p.r3[0]; r3[1] = p.r3[1]; r3[2] = p.r3[2];
+    return p.plan;
+}
+
 template <typename T>
 bool mr_supported(size_t n)
 {
     MrStages s;
     if (n < 2 || is_pow2(n) || !mr_factor(n, &s)) return false;
     if (n <= mr_wg_max<T>()) return twiddle_table_available<T>((int)n);
-    size_t n1, n2;
-    int w;
-    return mr_split<T>(n, &n1, &n2, &w) && twiddle_table_available<T>((int)n1) && twiddle_table_available<T>((int)n2);
+    size_t n1, n2, r3[3];
+    int w2, w3;
+    const int plan = mr_global_plan<T>(n, &n1, &n2, &w2, r3, &w3);
+    if (plan == 2) return twiddle_table_available<T>((int)n1) && twiddle_table_available<T>((int)n2);
+    if (plan == 3) return twiddle_table_available<T>((int)r3[0]) && twiddle_table_available<T>((int)r3[1]) && twiddle_table_available<T>((int)r3[2]);
+    return false;
 }
+
+// trips through global memory: 1 resident, 2 four-step (in -> scratch -> out), 3 Stockham passes (in -> scratch -> in -> out)
+template <typename T>
+int mr_passes(size_t n)
+{
+    if (n <= mr_wg_max<T>()) return 1;
+    size_t n1, n2, r3[3];
+    int w2, w3;
+    return mr_global_plan<T>(n, &n1, &n2, &w2, r3, &w3);
+}
+template int mr_passes<float>(size_t);
+template int mr_passes<double>(size_t);
 
 template <typename T> bool mr_resident(size_t n) { return n <= mr_wg_max<T>(); }
 template bool mr_resident<float>(size_t);
@@ -497,9 +647,41 @@ int mr_fft(const T* in, T* out, T* scratch, size_t n, size_t batch, bool inverse
         BDSP_LAUNCH_CHECK();
         return BDSP_OK;
     }
-    size_t n1, n2;
-    int wmax = 0;
-    if (!mr_split<T>(n, &n1, &n2, &wmax) || batch > 65535) return BDSP_ERR_UNSUPPORTED;
+    size_t n1, n2, r3[3];
+    int wmax = 0, w3 = 0;
+    const int plan = mr_global_plan<T>(n, &n1, &n2, &wmax, r3, &w3);
+    if (plan == 0 || batch > 65535) return BDSP_ERR_UNSUPPORTED;
+    if (plan == 3) {
+        // in -> scratch -> (the input's buffer, dead by then) -> out; the caller passes out = scratch (mr_passes == 3)
+        cpx<T>* bufs[2] = {reinterpret_cast<cpx<T>*>(scratch), reinterpret_cast<cpx<T>*>(const_cast<T*>(in))};
+        if (out != scratch) { set_last_error("mixed radix, three passes: the result goes to the scratch buffer"); return BDSP_ERR_UNSUPPORTED; }
+        int W = w3;
+        while (W > 4 && ((n / r3[0] + W - 1) / W) * batch < 2 * (size_t)num_cus()) W /= 2;
+        unsigned long long nsg = 1;
+        const cpx<T>* src = nullptr;
+        for (int p = 0; p < 3; ++p) {
+            const size_t RP = r3[p];
+            MrStages sp;
+            mr_factor(RP, &sp);
+            const cpx<T>* twp;
+            BDSP_TRY(twiddle_table<T>((int)RP, &twp));
+            const size_t lds = sizeof(cpx<T>) * (2 * RP * W + RP);
+            cpx<T>* dst = p == 2 ? nullptr : bufs[p];
+            const dim3 g((unsigned)((n / RP + W - 1) / W), (unsigned)batch);
+            const unsigned th = mr_threads(2 * RP * W);
+            if (inverse) {
+                BDSP_TRY(mr_set_lds(k_mr_gpass<T, 1>, lds));
+                hipLaunchKernelGGL((k_mr_gpass<T, 1>), g, dim3(th), lds, s, io, src, dst, sp, twp, (unsigned long long)n, (int)RP, nsg, W, p == 0, p == 2);
+            } else {
+                BDSP_TRY(mr_set_lds(k_mr_gpass<T, -1>, lds));
+                hipLaunchKernelGGL((k_mr_gpass<T, -1>), g, dim3(th), lds, s, io, src, dst, sp, twp, (unsigned long long)n, (int)RP, nsg, W, p == 0, p == 2);
+            }
+            BDSP_LAUNCH_CHECK();
+            src = dst;
+            nsg *= RP;
+        }
+        return BDSP_OK;
+    }
     MrStages s1, s2;
     mr_factor(n1, &s1);
     mr_factor(n2, &s2);

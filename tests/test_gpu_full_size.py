@@ -337,12 +337,14 @@ def test_mixed_radix_three_million_points():
     assert np.linalg.norm(back - x) / np.linalg.norm(x) < 2e-6
 
 
-@pytest.mark.parametrize("n,dtype", [(3_000_000, np.float64), (3 * (1 << 20), np.float64), (16_000_000, np.float32)])
-def test_mixed_radix_single_column_tiles(n, dtype):
-    """Round 5: the four-step mixed-radix form with ONE-column tiles.  In f64 the 2-wide tiles end at factors of 1843 points
-    (3 000 000 = 1500 x 2000 does not fit), in f32 at 3686 (about 13M points); until round 5 the chirp-z path served the
-    lengths beyond, at twice the time and error.  plain_fft against the oracle's f64 transform, fft -> ifft round trip with
-    the shifts fused, and a Hann-windowed transform."""
+@pytest.mark.parametrize("n,dtype", [(3_000_000, np.float64), (3 * (1 << 20), np.float64), (10_000_000, np.float64), (16_000_000, np.float32)])
+def test_mixed_radix_three_stockham_passes(n, dtype):
+    """Round 5: smooth lengths whose four-step form would need single-column tiles (f64 beyond factors of 1843 points:
+    3 000 000 = 1500 x 2000 does not fit; f32 beyond 3686: about 13M points) or has no two-factor split at all (10^7 in f64)
+    run as THREE global Stockham passes with any smooth super-radix (k_mr_gpass: n = r0 r1 r2, tiles 8 ... 16 columns wide;
+    the result ends in the trade buffer).  Until round 5 the chirp-z path served them at 2.6 ... 3.6 times the time and twice
+    the error.  plain_fft against the oracle's f64 transform, fft -> ifft round trip with the shifts fused, and a
+    Hann-windowed transform."""
     tol = 1e-6 if dtype == np.float32 else 1e-12
     x = orc.fill_uniform(2 * n, 515151 + n % 97, -10, 10, dtype)
     v = DspVec(x, is_complex=True)
@@ -360,6 +362,16 @@ def test_mixed_radix_single_column_tiles(n, dtype):
         assert v.windowed_fft(V.WINDOW_HANN) == 0
         w = orc.apply_window(x.astype(np.float64), True, 1, 0.5)
         assert rel_l2(v.data(), orc.swap_halves(orc.fft(w), True, True)) < tol
+        # a REAL vector (the first pass reads n reals, the second writes n complex values over them) and the magnitude
+        # of its spectrum (the last pass writes n reals)
+        xr = x[:n].copy()
+        v = DspVec(xr, is_complex=False)
+        assert v.plain_fft() == 0 and v.is_complex() and len(v) == 2 * n
+        xc = np.zeros(2 * n, np.float64)
+        xc[0::2] = xr
+        refr = orc.fft(xc)
+        assert rel_l2(v.data(), refr) < tol
+        assert v.magnitude() == 0 and rel_l2(v.data(), orc.magnitude(refr)) < tol
 
 
 @pytest.mark.gpu
