@@ -657,6 +657,8 @@ int mr_fft(const T* in, T* out, T* scratch, size_t n, size_t batch, bool inverse
         if (out != scratch) { set_last_error("mixed radix, three passes: the result goes to the scratch buffer"); return BDSP_ERR_UNSUPPORTED; }
         int W = w3;
         while (W > 4 && ((n / r3[0] + W - 1) / W) * batch < 2 * (size_t)num_cus()) W /= 2;
+        static const int w3_env = [] { const char* e = lab_env("BDSP_MR_W3"); return e ? atoi(e) : 0; }();
+        if (w3_env > 0 && w3_env <= w3) W = w3_env;
         unsigned long long nsg = 1;
         const cpx<T>* src = nullptr;
         for (int p = 0; p < 3; ++p) {
