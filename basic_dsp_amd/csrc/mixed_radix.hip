@@ -225,8 +225,19 @@ __device__ __forceinline__ void mr_stage(const cpx<T>* __restrict__ in, cpx<T>* 
                                          int ns, const cpx<T>* __restrict__ tw)
 {
     const int nb = len / R, tstep = len / (ns * R);
+    // index arithmetic without integer divisions (two divisions and two remainders per butterfly were a quarter of a
+    // radix-10 butterfly's instructions): `lanes` is a power of two in every global pass (shift / mask), and j / ns by a
+    // float reciprocal with one correction step (j < 2^16: exact after the correction)
+    const bool lp2 = (lanes & (lanes - 1)) == 0;
+    const int lsh = __ffs(lanes) - 1;
+    const float rns = 1.0f / (float)ns;
     for (int id = threadIdx.x; id < nb * lanes; id += blockDim.x) {
-        const int q = id % lanes, j = id / lanes, k = j % ns;
+        int q, j;
+        if (lp2) { q = id & (lanes - 1); j = id >> lsh; }
+        else { q = id % lanes; j = id / lanes; }
+        int jq = (int)((float)j * rns), k = j - jq * ns;
+        if (k >= ns) { k -= ns; ++jq; }
+        if (k < 0) { k += ns; --jq; }
         cpx<T> v[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) v[r] = in[(j + r * nb) * lanes + q];
@@ -235,7 +246,7 @@ __device__ __forceinline__ void mr_stage(const cpx<T>* __restrict__ in, cpx<T>* 
             for (int r = 1; r < R; ++r) v[r] = twmul<DIR>(v[r], tw[r * k * tstep]);
         }
         mr_dft<R, DIR>(v);
-        const int o = (j / ns) * ns * R + k;
+        const int o = jq * ns * R + k;
 #pragma unroll
         for (int r = 0; r < R; ++r) out[(o + r * ns) * lanes + q] = v[r];
     }
@@ -349,6 +360,23 @@ __global__ __launch_bounds__(MR_THREADS) void k_mr_wg(MrIo<T> io, MrStages st, c
     }
 }
 
+// exp(-/+ 2 pi i m / n) for the twiddles between global passes: the angle is formed in double (m / n is not a float), the
+// trigonometry runs in T -- sincospif's 1e-7 is the f32 transform's own rounding, and a double sincospi per element was a
+// fifth of the f32 three-pass transform of 2 * 10^7 points
+template <typename T, int DIR>
+__device__ __forceinline__ cpx<T> mr_unit(unsigned long long m, double two_over_n)
+{
+    if constexpr (sizeof(T) == 4) {
+        float sn, cs;
+        sincospif((float)((double)m * two_over_n), &sn, &cs);
+        return cpx<T>{cs, DIR < 0 ? -sn : sn};
+    } else {
+        double sn, cs;
+        sincospi((double)m * two_over_n, &sn, &cs);
+        return cpx<T>{(T)cs, (T)(DIR < 0 ? -sn : sn)};
+    }
+}
+
 // ---- four-step, pass 1: W adjacent columns c of the n1 x n2 view x[r n2 + c]; FFT_n1 over r, times w_n^(k1 c) ----
 template <typename T, int DIR>
 __global__ __launch_bounds__(MR_THREADS) void k_mr_pass1(MrIo<T> io, cpx<T>* __restrict__ tmp, MrStages st,
@@ -361,21 +389,19 @@ __global__ __launch_bounds__(MR_THREADS) void k_mr_pass1(MrIo<T> io, cpx<T>* __r
     const unsigned long long vec = blockIdx.y;
     const int c0 = blockIdx.x * W;
     const int live = n2 - c0 < W ? n2 - c0 : W;
+    const int wsh = __ffs(W) - 1; // (W is a power of two)
     for (int id = threadIdx.x; id < n1 * W; id += blockDim.x) {
-        const int q = id % W, r = id / W;
+        const int q = id & (W - 1), r = id >> wsh;
         a[id] = q < live ? mr_load<T>(io, vec, (unsigned long long)r * n2 + c0 + q) : cpx<T>{(T)0, (T)0};
     }
     cpx<T>* res = mr_transform<DIR, T>(a, b, n1, W, st, tw);
     cpx<T>* tv = tmp + vec * io.n;
     const double inv = 2.0 / (double)io.n;
     for (int id = threadIdx.x; id < n1 * W; id += blockDim.x) {
-        const int q = id % W, k1 = id / W;
+        const int q = id & (W - 1), k1 = id >> wsh;
         if (q >= live) continue;
-        const unsigned long long m = ((unsigned long long)k1 * (unsigned long long)(c0 + q)) % io.n;
-        double sn, cs;
-        sincospi((double)m * inv, &sn, &cs); // exp(-/+ 2 pi i m / n)
-        const cpx<T> w{(T)cs, (T)(DIR < 0 ? -sn : sn)};
-        tv[(unsigned long long)k1 * n2 + c0 + q] = cmul(res[id], w);
+        const unsigned long long m = (unsigned long long)k1 * (unsigned long long)(c0 + q); // < n1 n2 = n
+        tv[(unsigned long long)k1 * n2 + c0 + q] = cmul(res[id], mr_unit<T, DIR>(m, inv));
     }
 }
 
@@ -392,13 +418,13 @@ __global__ __launch_bounds__(MR_THREADS) void k_mr_pass2(MrIo<T> io, const cpx<T
     const int r0 = blockIdx.x * W;
     const int live = n1 - r0 < W ? n1 - r0 : W;
     const cpx<T>* tv = tmp + vec * io.n;
-    for (int id = threadIdx.x; id < n2 * W; id += blockDim.x) {
-        const int q = id / n2, c = id % n2; // unit stride along a row
-        a[c * W + q] = q < live ? tv[(unsigned long long)(r0 + q) * n2 + c] : cpx<T>{(T)0, (T)0};
-    }
+    for (int q = 0; q < W; ++q) // unit stride along a row
+        for (int c = threadIdx.x; c < n2; c += blockDim.x)
+            a[c * W + q] = q < live ? tv[(unsigned long long)(r0 + q) * n2 + c] : cpx<T>{(T)0, (T)0};
     cpx<T>* res = mr_transform<DIR, T>(a, b, n2, W, st, tw);
+    const int wsh = __ffs(W) - 1; // (W is a power of two)
     for (int id = threadIdx.x; id < n2 * W; id += blockDim.x) {
-        const int q = id % W, k2 = id / W; // W adjacent k1 are adjacent bins
+        const int q = id & (W - 1), k2 = id >> wsh; // W adjacent k1 are adjacent bins
         if (q < live) mr_store<T>(io, vec, (unsigned long long)(r0 + q) + (unsigned long long)n1 * k2, res[id]);
     }
 }
@@ -423,19 +449,20 @@ __global__ __launch_bounds__(MR_THREADS) void k_mr_gpass(MrIo<T> io, const cpx<T
     const cpx<T>* sv = src + vec * n;
     const unsigned long long tstep = n / (nsg * RP);
     const double inv = 2.0 / (double)n;
+    // (no per-element divisions: W is a power of two, and a tile's W columns j0 + q cross a multiple of nsg at most once
+    // -- nsg is 1 or a whole first factor, never less than W -- so j / nsg and j mod nsg follow from the tile's own pair)
+    const int wsh = __ffs(W) - 1;
+    const unsigned long long jd0 = j0 / nsg, k0 = j0 % nsg;
     for (int id = threadIdx.x; id < RP * W; id += blockDim.x) {
-        const int q = id % W, r = id / W;
+        const int q = id & (W - 1), r = id >> wsh;
         cpx<T> v{(T)0, (T)0};
         if (q < live) {
             const unsigned long long j = j0 + q, i = j + (unsigned long long)r * cols;
             v = first ? mr_load<T>(io, vec, i) : sv[i];
             if (nsg > 1 && r > 0) {
-                const unsigned long long e = (unsigned long long)r * (j % nsg) * tstep; // < n: r < RP, k < nsg
-                if (e) {
-                    double sn, cs;
-                    sincospi((double)e * inv, &sn, &cs);
-                    v = cmul(v, cpx<T>{(T)cs, (T)(DIR < 0 ? -sn : sn)});
-                }
+                const unsigned long long kk = k0 + q >= nsg ? k0 + q - nsg : k0 + q;
+                const unsigned long long e = (unsigned long long)r * kk * tstep; // < n: r < RP, k < nsg
+                if (e) v = cmul(v, mr_unit<T, DIR>(e, inv));
             }
         }
         a[id] = v;
@@ -451,9 +478,11 @@ __global__ __launch_bounds__(MR_THREADS) void k_mr_gpass(MrIo<T> io, const cpx<T
         }
     } else {
         for (int id = threadIdx.x; id < RP * W; id += blockDim.x) {
-            const int q = id % W, r = id / W;
+            const int q = id & (W - 1), r = id >> wsh;
             if (q >= live) continue;
-            const unsigned long long j = j0 + q, o = (j / nsg) * nsg * RP + (j % nsg) + (unsigned long long)r * nsg;
+            const bool wrap = k0 + q >= nsg;
+            const unsigned long long kk = wrap ? k0 + q - nsg : k0 + q, jd = wrap ? jd0 + 1 : jd0;
+            const unsigned long long o = jd * nsg * RP + kk + (unsigned long long)r * nsg;
             if (last) mr_store<T>(io, vec, o, res[id]); else dv[o] = res[id];
         }
     }
@@ -483,7 +512,7 @@ template <typename T>
 static bool mr_split(size_t n, size_t* n1, size_t* n2, int* wmax)
 {
     // (LAB, BDSP_MR_W1: also single-column tiles -- measured in round 5: they beat the chirp-z path that served such lengths
-    // until then (f64 3 * 10^6 points 400 -> 236 us) and lose to three Stockham passes (152 us), which is what runs now)
+    // until then (f64 3 * 10^6 points 400 -> 236 us) and lose to three Stockham passes (130 us), which is what runs now)
     static const bool w1 = lab_flag("BDSP_MR_W1");
     for (int W = mr_tile<T>(); W >= (w1 ? 1 : 2); W /= 2) {
         const size_t pm = mr_pass_max<T>(W);
@@ -525,8 +554,10 @@ static bool mr_split3(size_t n, size_t r[3], int* wmax)
     }
     if (!best) return false;
     r[0] = b0; r[1] = b1; r[2] = b2;
-    int W = 16;
-    while (W > 4 && mr_pass_max<T>(W) < b0) W /= 2;
+    // (*measured*, BDSP_MR_W3: f64 3 / 6 / 10 * 10^6 points 157 / 315 / 499 us at 16-wide tiles, 172 / 318 / 473 at 8, 143 / 282 / 460 at
+    // 4; f32 2 / 3 * 10^7 714 / 1003 at 16, 627 / 936 at 8, 657 / 992 at 4: the 64-byte tile of the four-step form)
+    int W = mr_tile<T>();
+    while (W > 2 && mr_pass_max<T>(W) < b0) W /= 2;
     *wmax = W;
     return true;
 }
@@ -656,9 +687,9 @@ int mr_fft(const T* in, T* out, T* scratch, size_t n, size_t batch, bool inverse
         cpx<T>* bufs[2] = {reinterpret_cast<cpx<T>*>(scratch), reinterpret_cast<cpx<T>*>(const_cast<T*>(in))};
         if (out != scratch) { set_last_error("mixed radix, three passes: the result goes to the scratch buffer"); return BDSP_ERR_UNSUPPORTED; }
         int W = w3;
-        while (W > 4 && ((n / r3[0] + W - 1) / W) * batch < 2 * (size_t)num_cus()) W /= 2;
         static const int w3_env = [] { const char* e = lab_env("BDSP_MR_W3"); return e ? atoi(e) : 0; }();
         if (w3_env > 0 && w3_env <= w3) W = w3_env;
+        while (W & (W - 1)) W &= W - 1;
         unsigned long long nsg = 1;
         const cpx<T>* src = nullptr;
         for (int p = 0; p < 3; ++p) {
@@ -697,6 +728,7 @@ int mr_fft(const T* in, T* out, T* scratch, size_t n, size_t batch, bool inverse
     while (W > wmin && ((n2 + W - 1) / W) * batch < (size_t)num_cus()) W /= 2;
     static const int w_env = [] { const char* e = lab_env("BDSP_MR_W"); return e ? atoi(e) : 0; }();
     if (w_env > 0 && w_env <= wmax) W = w_env;
+    while (W & (W - 1)) W &= W - 1; // (the kernels index a tile by shifts: a power of two)
     const size_t lds1 = sizeof(cpx<T>) * (2 * n1 * W + n1), lds2 = sizeof(cpx<T>) * (2 * n2 * W + n2);
     cpx<T>* tmp = reinterpret_cast<cpx<T>*>(scratch);
     // a lone transform wants every wave it can get per tile; a batch has parallelism across tiles already
