@@ -226,15 +226,14 @@ __device__ __forceinline__ void mr_stage(const cpx<T>* __restrict__ in, cpx<T>* 
 {
     const int nb = len / R, tstep = len / (ns * R);
     // index arithmetic without integer divisions (two divisions and two remainders per butterfly were a quarter of a
-    // radix-10 butterfly's instructions): `lanes` is a power of two in every global pass (shift / mask), and j / ns by a
-    // float reciprocal with one correction step (j < 2^16: exact after the correction)
-    const bool lp2 = (lanes & (lanes - 1)) == 0;
-    const int lsh = __ffs(lanes) - 1;
-    const float rns = 1.0f / (float)ns;
+    // radix-10 butterfly's instructions): id / lanes and j / ns by float reciprocals with one correction step each
+    // (id < 2^17, j < 2^13: exact after the correction).  (A shift / mask path for power-of-two `lanes` next to the
+    // general one cost the f64 resident kernel 20 bytes of reserved scratch: one branch-free form instead.)
+    const float rns = 1.0f / (float)ns, rl = 1.0f / (float)lanes;
     for (int id = threadIdx.x; id < nb * lanes; id += blockDim.x) {
-        int q, j;
-        if (lp2) { q = id & (lanes - 1); j = id >> lsh; }
-        else { q = id % lanes; j = id / lanes; }
+        int j = (int)((float)id * rl), q = id - j * lanes;
+        if (q >= lanes) { q -= lanes; ++j; }
+        if (q < 0) { q += lanes; --j; }
         int jq = (int)((float)j * rns), k = j - jq * ns;
         if (k >= ns) { k -= ns; ++jq; }
         if (k < 0) { k += ns; --jq; }
@@ -435,11 +434,15 @@ __global__ __launch_bounds__(MR_THREADS) void k_mr_pass2(MrIo<T> io, const cpx<T
 // A tile is W adjacent columns: loads are runs of W values, stores runs of RP values in the first pass (nsg = 1: whole
 // output columns) and of W values afterwards.  With three factors of a few hundred points the tile stays W = 8 ... 16
 // wide (64 ... 128-byte runs, 256 in f64) where the four-step form of the same length is down to 2- or 1-wide tiles.
-template <typename T, int DIR>
+// POS: 0 first pass (fused input options: mr_load), 1 middle, 2 last (fused output options: mr_store) -- compile-time, so
+// that no instantiation carries both option paths (with both, hipcc reserved 52-68 bytes of scratch per lane for scalar
+// spills it then kept in vector lanes after all: no kernel of the library has a private segment).
+template <typename T, int DIR, int POS>
 __global__ __launch_bounds__(MR_THREADS) void k_mr_gpass(MrIo<T> io, const cpx<T>* __restrict__ src, cpx<T>* __restrict__ dst,
                                                   MrStages st, const cpx<T>* __restrict__ tw, unsigned long long n, int RP,
-                                                  unsigned long long nsg, int W, int first, int last)
+                                                  unsigned long long nsg, int W)
 {
+    constexpr bool first = POS == 0, last = POS == 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     cpx<T>* a = reinterpret_cast<cpx<T>*>(smem_raw);
     cpx<T>* b = a + (size_t)RP * W;
@@ -702,13 +705,14 @@ int mr_fft(const T* in, T* out, T* scratch, size_t n, size_t batch, bool inverse
             cpx<T>* dst = p == 2 ? nullptr : bufs[p];
             const dim3 g((unsigned)((n / RP + W - 1) / W), (unsigned)batch);
             const unsigned th = mr_threads(2 * RP * W);
-            if (inverse) {
-                BDSP_TRY(mr_set_lds(k_mr_gpass<T, 1>, lds));
-                hipLaunchKernelGGL((k_mr_gpass<T, 1>), g, dim3(th), lds, s, io, src, dst, sp, twp, (unsigned long long)n, (int)RP, nsg, W, p == 0, p == 2);
-            } else {
-                BDSP_TRY(mr_set_lds(k_mr_gpass<T, -1>, lds));
-                hipLaunchKernelGGL((k_mr_gpass<T, -1>), g, dim3(th), lds, s, io, src, dst, sp, twp, (unsigned long long)n, (int)RP, nsg, W, p == 0, p == 2);
-            }
+#define BDSP_GPASS(DIRV, POSV)                                                                                          \
+    do {                                                                                                                \
+        BDSP_TRY(mr_set_lds(k_mr_gpass<T, DIRV, POSV>, lds));                                                           \
+        hipLaunchKernelGGL((k_mr_gpass<T, DIRV, POSV>), g, dim3(th), lds, s, io, src, dst, sp, twp, (unsigned long long)n, (int)RP, nsg, W); \
+    } while (0)
+            if (inverse) { if (p == 0) BDSP_GPASS(1, 0); else if (p == 1) BDSP_GPASS(1, 1); else BDSP_GPASS(1, 2); }
+            else { if (p == 0) BDSP_GPASS(-1, 0); else if (p == 1) BDSP_GPASS(-1, 1); else BDSP_GPASS(-1, 2); }
+#undef BDSP_GPASS
             BDSP_LAUNCH_CHECK();
             src = dst;
             nsg *= RP;
