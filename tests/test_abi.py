@@ -179,3 +179,51 @@ def test_rust_shim_is_what_integration_md_prints_and_its_markers_are_the_cpu_arm
     assert len(externs) == 11
     for name in externs:
         assert hasattr(b.lib, name), name
+
+
+def test_no_kernel_of_the_shipped_library_has_a_private_segment(tmp_path):
+    """`No kernel of the library uses scratch` checked on the shipped binary itself: the gfx950 code objects are
+    cut out of the library's .hip_fatbin section (clang offload bundles) and every kernel's metadata must say
+    .private_segment_fixed_size: 0 and no dynamic stack.  (Round 5: the three-pass mixed-radix kernel first shipped with 52-68
+    reserved bytes per lane -- scalar spills hipcc planned for memory and then kept in vector lanes after all; nothing in
+    tests/ saw it, `make resources` did.)"""
+    import re
+    import shutil
+    import struct
+    import subprocess
+    import basic_dsp_amd._lib as L
+    llvm = "/opt/rocm/lib/llvm/bin"
+    objcopy, readelf = os.path.join(llvm, "llvm-objcopy"), os.path.join(llvm, "llvm-readelf")
+    if not (os.path.exists(objcopy) and os.path.exists(readelf)):
+        pytest.skip("llvm-objcopy / llvm-readelf not found")
+    if os.path.basename(L.LIB_PATH) != "libbasic_dsp_hip.so":
+        pytest.skip("a library override is loaded")
+    fat = tmp_path / "fat.bin"
+    subprocess.run([objcopy, "--dump-section", ".hip_fatbin=%s" % fat, L.LIB_PATH, str(tmp_path / "copy.so")], check=True)
+    blob = fat.read_bytes()
+    kernels, offenders = 0, []
+    for m in re.finditer(b"__CLANG_OFFLOAD_BUNDLE__", blob):
+        p = m.start()
+        count = struct.unpack_from("<Q", blob, p + 24)[0]
+        off = p + 32
+        for _ in range(count):
+            o, size, tl = struct.unpack_from("<QQQ", blob, off)
+            off += 24
+            triple = blob[off:off + tl].decode()
+            off += tl
+            if "gfx950" not in triple or size == 0:
+                continue
+            co = tmp_path / ("co%d.elf" % kernels)
+            co.write_bytes(blob[p + o:p + o + size])
+            notes = subprocess.run([readelf, "--notes", str(co)], capture_output=True, text=True, check=True).stdout
+            names = re.findall(r"\.name:\s+(\S+)", notes)
+            sizes = re.findall(r"\.private_segment_fixed_size:\s+(\d+)", notes)
+            stacks = re.findall(r"\.uses_dynamic_stack:\s+(\w+)", notes)
+            kernels += len(sizes)
+            kn = [n for n in names if n.startswith("_Z")]
+            for i, sz in enumerate(sizes):
+                if int(sz) != 0:
+                    offenders.append((kn[i] if i < len(kn) else "?", int(sz)))
+            assert "true" not in stacks
+    assert kernels >= 600, kernels
+    assert not offenders, offenders[:10]
