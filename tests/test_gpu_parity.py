@@ -233,9 +233,9 @@ def test_fft_any_length_bluestein(n, dtype):
     ref = np.fft.fft(x.astype(np.float64).view(np.complex128))
     v = DspVec(x, is_complex=True)
     assert v.plain_fft() == 0
-    assert rel_l2(v.datac(), ref) < 2 * tol_for(dtype), n
+    assert rel_l2(v.datac(), ref) < tol_for(dtype), n  # (north_star: 1e-6 rel for one f32 transform; measured 1.5e-7 ... 7e-7)
     assert v.plain_ifft() == 0
-    assert rel_l2(v.data().astype(np.float64) / n, x) < 4 * tol_for(dtype)
+    assert rel_l2(v.data().astype(np.float64) / n, x) < 2 * tol_for(dtype)  # (two transforms)
 
 
 def test_golden_fft_vector64_on_gpu():
@@ -268,15 +268,15 @@ def test_fft_ifft_with_fused_shift_window_scale(n, dtype):
     v = DspVec(x, is_complex=True)
     assert v.fft() == 0
     ref = orc.swap_halves(orc.fft(xd), True, True)
-    assert rel_l2(v.data(), ref) < 2 * tol_for(dtype)
+    assert rel_l2(v.data(), ref) < tol_for(dtype)
     # ifft = scale(1/n) -> ifft_shift -> plain_ifft (freq_to_time.rs:160-168); round trip
     assert v.ifft() == 0
-    assert rel_l2(v.data(), xd) < 4 * tol_for(dtype)
+    assert rel_l2(v.data(), xd) < 2 * tol_for(dtype)
     # windowed_fft (Hann) then windowed_ifft restores the signal except where the window is ~0
     v = DspVec(x, is_complex=True)
     assert v.windowed_fft(V.WINDOW_HANN) == 0
     ref = orc.swap_halves(orc.fft(orc.apply_window(xd, True, 1, 0.5)), True, True)
-    assert rel_l2(v.data(), ref) < 2 * tol_for(dtype)
+    assert rel_l2(v.data(), ref) < tol_for(dtype)
     v = DspVec(x, is_complex=True)
     assert v.windowed_fft(V.WINDOW_HAMMING) == 0 and v.windowed_ifft(V.WINDOW_HAMMING) == 0
     assert rel_l2(v.data(), xd) < (2e-5 if dtype == np.float32 else 1e-10)
@@ -296,9 +296,9 @@ def test_b1_fft_host_slices(dtype):
         x = orc.fill_uniform(2 * n, n, -10, 10, dtype)
         got = V.gpu_fft(x.copy())
         ref = np.fft.fft(x.astype(np.float64).view(np.complex128)).view(np.float64)
-        assert rel_l2(got, ref) < 2 * tol_for(dtype)
+        assert rel_l2(got, ref) < tol_for(dtype)
         back = V.gpu_fft(got.copy(), inverse=True)
-        assert rel_l2(back.astype(np.float64) / n, x) < 4 * tol_for(dtype)
+        assert rel_l2(back.astype(np.float64) / n, x) < 2 * tol_for(dtype)
 
 
 # ------------------------------------------------------------------ convolution
