@@ -20,7 +20,15 @@ convolve_signal -> plain_fft.  `value` is the compute-only rate with the shards 
 line carries the end-to-end scatter + compute + gather time from rank 0 (chunked, pipelined:
 basic_dsp_amd/batch.py) under `c5_end_to_end`.
 
+Whenever the ranks form a process group (N > 1, or --init-dist) the DEFAULT mode also runs and VERIFIES the path's one
+multi-GPU exchange after the timed region: a C5-shaped batch goes out from rank 0 in chunks over grouped point-to-point
+sends, every rank convolves + transforms, the spectra come back, and rank 0 compares the first and last chunk of every
+peer bit for bit with its own computation (`c5_end_to_end`: ms, Msamples_s, verified_rows, peers; a mismatch exits 3; a
+leg that hangs is given up after --e2e-timeout and reported in the line).
+
 Extra objects on the JSON line:
+  value_windows the noise floor: window 0 is the contract's timed region (`value`), nine more windows of the same K steps
+                follow back to back; min / median / max of the ten values and per-window kernel times, clock and power.
   roofline      the dominant kernel (the fused overlap-save launch): algorithmic bytes per launch
                 (16 B per complex f32 sample) / mean launch duration measured with HIP
                 events on the launch stream inside the timed region, against the 8 TB/s HBM peak.
