@@ -499,14 +499,15 @@ template <typename T> static int mr_tile() { return sizeof(T) == 4 ? 8 : 4; }   
 // longest sub-transform a tile of W lanes can hold: 2 ping-pong buffers of len * W points + the table
 template <typename T> static size_t mr_pass_max(int W) { return MR_LDS_BYTES / (sizeof(cpx<T>) * (2 * W + 1)); }
 
-// Four-step or three Stockham passes?  *Measured* (round 5, tools/plan_probe.py --points, cold / hot, LAB switch BDSP_MR_PLAN;
-// profiles/r05_plan_probe_valid.txt runs 8-10): while the four-step's tile is 4 or 8 wide it wins (f32 10^6 points 34 / 31 us
-// against 49 / 48, f64 37 / 34 against 65 / 60; 64 x 10^5 126 / 110 against 184 / 168); at 2-wide tiles it depends on the
-// factors (f32 3 * 10^6 82 against 116, 10^7 376 against 404, 1.296 * 10^7 448 against 496 -- but 1.2 * 10^7 559 against 462;
-// f64 2 * 10^6 112 against 89, 3.24 * 10^6 155 against 193): the four-step keeps them; where it would need single columns
-// or has no split at all, three passes take over: f64 3 * 10^6 152 / 143 us (single columns 236, chirp-z 400), 3 * 2^20 126
-// (214, 411), 6 * 10^6 315 (450, 861), 10^7 500 (chirp-z 1822); f32 2 * 10^7 724 / 692 (1115, 2019), 3 * 10^7 1004 (1613, 2083).
-template <typename T> static int mr_plan2_min_tile() { return 2; }
+// Four-step or three Stockham passes?  *Measured* (round 5, tools/plan_probe.py --points, cold us, LAB switch BDSP_MR_PLAN;
+// profiles/r05_plan_probe_valid.txt run 13, after the index arithmetic lost its divisions): while the four-step's tile is 8
+// wide it wins (10^6 points f32 32 against 49 us, f64 34 against 65 at its widest tile of 4; 64 x 10^5 f32 126 against 184);
+// at 4-wide f32 tiles it depends on the factors (3 * 10^6 79 against 87, 1.5 * 10^6 60 against 54) and the four-step keeps
+// them; at 2-wide tiles three passes win or tie everywhere -- f32 6 * 10^6 210 -> 180, 10^7 356 -> 280, 1.296 * 10^7 426 -> 307;
+// f64 1.2 * 10^6 64.7 -> 64.1, 1.5 * 10^6 78.8 -> 75.2, 2 * 10^6 103 -> 84, 2.4 * 10^6 117 -> 105, 3.24 * 10^6 147 -> 140 -- and where the
+// four-step would need single columns or has no split at all they are the only global form: f64 3 * 10^6 130 us (single
+// columns 236, chirp-z 400), 6 * 10^6 255 (450, 861), 10^7 424 (chirp-z 1822); f32 2 * 10^7 541 (1115, 2019), 3 * 10^7 825 (1613, 2083).
+template <typename T> static int mr_plan2_min_tile() { return 4; }
 constexpr size_t MR_PLAN3_MIN = 100000;
 
 // n1 * n2 = n with both factors smooth: the most balanced split, at the widest tile (W_max, W_max/2, ... 2) whose

@@ -323,7 +323,7 @@ def test_c2_batch_of_40_fft_magnitude_in_one_call():
 
 @pytest.mark.gpu
 def test_mixed_radix_three_million_points():
-    """3 000 000 = 2^6 3 5^6 points: the four-step mixed-radix form with 2-wide tiles (factors 1500 x 2000), against
+    """3 000 000 = 2^6 3 5^6 points: the four-step mixed-radix form with 4-wide tiles (factors 1500 x 2000), against
     the oracle's f64 transform of the same f32 input; round trip."""
     n = 3_000_000
     x = orc.fill_uniform(2 * n, 424242, -10, 10, np.float32)
@@ -337,11 +337,11 @@ def test_mixed_radix_three_million_points():
     assert np.linalg.norm(back - x) / np.linalg.norm(x) < 2e-6
 
 
-@pytest.mark.parametrize("n,dtype", [(3_000_000, np.float64), (3 * (1 << 20), np.float64), (10_000_000, np.float64), (16_000_000, np.float32)])
+@pytest.mark.parametrize("n,dtype", [(2_000_000, np.float64), (3_000_000, np.float64), (3 * (1 << 20), np.float64), (10_000_000, np.float64), (6_000_000, np.float32), (16_000_000, np.float32)])
 def test_mixed_radix_three_stockham_passes(n, dtype):
-    """Round 5: smooth lengths whose four-step form would need single-column tiles (f64 beyond factors of 1843 points:
-    3 000 000 = 1500 x 2000 does not fit; f32 beyond 3686: about 13M points) or has no two-factor split at all (10^7 in f64)
-    run as THREE global Stockham passes with any smooth super-radix (k_mr_gpass: n = r0 r1 r2, tiles 8 ... 16 columns wide;
+    """Round 5: smooth lengths whose four-step form would need tiles narrower than four columns (f64 beyond factors of 1024
+    points, i.e. above 10^6; f32 beyond 2048, about 4.2M points) or has no two-factor split at all (10^7 in f64) run as
+    THREE global Stockham passes with any smooth super-radix (k_mr_gpass: n = r0 r1 r2, tiles 8 ... 16 columns wide;
     the result ends in the trade buffer).  Until round 5 the chirp-z path served them at 2.6 ... 3.6 times the time and twice
     the error.  plain_fft against the oracle's f64 transform, fft -> ifft round trip with the shifts fused, and a
     Hann-windowed transform."""
