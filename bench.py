@@ -828,7 +828,7 @@ def c5_end_to_end(args, bd, torch, dist, dev, rank, world, n, m, nvec, use_dist)
             "Msamples_s": total * n / best / 1e6, "runs_ms": [t * 1e3 for t in times]}
 
 
-def verified_scatter_gather(args, torch, dist, dev, rank, world, m, share_gpu):
+def verified_scatter_gather(args, torch, dist, dev, rank, world, m, share_gpu, compute=None, points=None, corrupt=False):
     """The path's multi-GPU exchange, run AND verified from the headline mode whenever the ranks form a process group
     (`--gpus N` with N > 1, or `--init-dist`): a C5-shaped batch of `--e2e-vectors-per-gpu` vectors of 2^20 points per
     rank lives in rank 0's HBM, goes out in chunks of `--e2e-chunk-vectors` over grouped point-to-point sends (RCCL over
@@ -838,9 +838,17 @@ def verified_scatter_gather(args, torch, dist, dev, rank, world, m, share_gpu):
     chunk of every peer itself and compares the gathered rows BIT FOR BIT (same kernels, same chunk shape, same data ->
     the same bits on every GPU); at world size 1 it does so for its own shard.  A mismatch ends every rank non-zero.
     Under the one-GPU test hook the ranks talk gloo, so the chunks travel as host tensors and the compute step copies
-    them to GPU 0 and back."""
-    from basic_dsp_amd.batch import process_shard_gpu, scatter_process_gather_chunked, shard_bounds
-    n, per, chunk = C5_POINTS, args.e2e_vectors_per_gpu, args.e2e_chunk_vectors
+    them to GPU 0 and back.
+    `compute` / `points` / `corrupt`: for the CPU tier of the tests only (tests/test_batch_gloo.py) -- a stand-in for the
+    compute step on host tensors, so that the leg's control logic (which rows are verified, the exit on a mismatch) runs at
+    world sizes 2 and 3 over gloo without a GPU; the product path never passes them."""
+    from basic_dsp_amd.batch import scatter_process_gather_chunked, shard_bounds
+    if compute is None:
+        from basic_dsp_amd.batch import process_shard_gpu
+    else:
+        process_shard_gpu = compute
+    sync = torch.cuda.synchronize if torch.device(dev).type == "cuda" else (lambda: None)
+    n, per, chunk = points or C5_POINTS, args.e2e_vectors_per_gpu, args.e2e_chunk_vectors
     total = per * world
     comm_dev = torch.device("cpu") if share_gpu else dev
     batch = taps = None
@@ -860,16 +868,16 @@ def verified_scatter_gather(args, torch, dist, dev, rank, world, m, share_gpu):
     times, out = [], None
     for it in range(4):
         out = None
-        torch.cuda.synchronize()
+        sync()
         dist.barrier()
         t0 = time.perf_counter()
         out = scatter_process_gather_chunked(cbatch, ctaps, n, fn, chunk_vectors=chunk, device=comm_dev)
-        torch.cuda.synchronize()
+        sync()
         dist.barrier()
         times.append(time.perf_counter() - t0)
     ok, rows, bad = 1, 0, []
-    if rank == 0 and share_gpu and os.environ.get("BDSP_BENCH_CORRUPT_E2E") == "1":
-        out[total - 1, 12345] += 1.0  # TEST HOOK (with --test-share-gpu only): the verification below must catch this
+    if rank == 0 and (corrupt or (share_gpu and os.environ.get("BDSP_BENCH_CORRUPT_E2E") == "1")):
+        out[total - 1, min(12345, 2 * n - 1)] += 1.0  # TEST HOOK (with --test-share-gpu only): the verification below must catch this
     if rank == 0:
         for peer in (range(1, world) if world > 1 else [0]):
             f, l = shard_bounds(total, world, peer)

@@ -181,3 +181,54 @@ def test_shard_bounds_contiguous_cover():
             for a, b in zip(spans, spans[1:]):
                 assert a[1] == b[0]
     assert shard_bounds(512, 8, 3) == (192, 256)  # 64 vectors per GPU, contiguous (config C5)
+
+
+def _bench_leg_worker(rank, world, port, corrupt, result_path):
+    """bench.py's verified scatter / compute / gather leg (verified_scatter_gather) with a host stand-in for the compute step."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import argparse
+    import bench
+    calls = []
+
+    def compute(shard, taps, points):  # deterministic, row-wise, depends on the taps: what a mix-up of rows or chunks would break
+        calls.append(int(shard.shape[0]))
+        return shard * 2.0 + taps[:1] + torch.arange(shard.shape[1], dtype=shard.dtype) * 1e-3
+
+    args = argparse.Namespace(e2e_vectors_per_gpu=5, e2e_chunk_vectors=2)
+    try:
+        res = bench.verified_scatter_gather(args, torch, dist, torch.device("cpu"), rank, world, 16, True, compute=compute, points=64, corrupt=corrupt)
+        code = 0
+    except SystemExit as e:
+        res, code = None, e.code
+    with open(result_path + ".%d" % rank, "w") as fh:
+        import json
+        json.dump({"code": code, "res": res, "calls": calls}, fh)
+    if dist.is_initialized():
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_bench_verified_scatter_gather_leg_over_gloo(world, tmp_path):
+    """The leg `bench.py --gpus N` runs after its timed region (round 5), at world sizes 2 and 3 on CPU: 5 vectors per rank in
+    chunks of 2 (a ragged last chunk), four passes of the chunked pipeline, then rank 0 recomputes the FIRST and the LAST
+    chunk of every peer and compares -- 3 rows per peer (2 + 1) -- and a corrupted gathered row ends EVERY rank with exit
+    code 3."""
+    import json
+    for corrupt in (False, True):
+        path = str(tmp_path / ("leg%d" % corrupt))
+        mp.spawn(_bench_leg_worker, args=(world, _free_port(), corrupt, path), nprocs=world, join=True)
+        rs = [json.load(open(path + ".%d" % r)) for r in range(world)]
+        if corrupt:
+            assert all(r["code"] == 3 for r in rs), rs
+            continue
+        assert all(r["code"] == 0 for r in rs)
+        e = rs[0]["res"]
+        assert e["peers"] == world - 1 and e["verified_rows"] == 3 * (world - 1) and e["vectors"] == 5 * world
+        assert e["chunk_vectors"] == 2 and e["ms"] > 0 and len(e["runs_ms"]) == 4
+        # every rank ran its 3 chunks (2 + 2 + 1 vectors) in each of the four passes; rank 0 also the 2 verification chunks per peer
+        for r in range(1, world):
+            assert rs[r]["calls"] == [2, 2, 1] * 4, rs[r]["calls"]
+        assert rs[0]["calls"] == [2, 2, 1] * 4 + [2, 1] * (world - 1), rs[0]["calls"]
