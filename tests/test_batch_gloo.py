@@ -210,9 +210,9 @@ def _bench_leg_worker(rank, world, port, corrupt, result_path):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_bench_verified_scatter_gather_leg_over_gloo(world, tmp_path):
-    """The leg `bench.py --gpus N` runs after its timed region (round 5), at world sizes 2 and 3 on CPU: 5 vectors per rank in
+    """The leg `bench.py --gpus N` runs after its timed region (round 5), at world sizes 2, 3 and 8 (the node's) on CPU: 5 vectors per rank in
     chunks of 2 (a ragged last chunk), four passes of the chunked pipeline, then rank 0 recomputes the FIRST and the LAST
     chunk of every peer and compares -- 3 rows per peer (2 + 1) -- and a corrupted gathered row ends EVERY rank with exit
     code 3."""
