@@ -62,7 +62,7 @@ def parse(argv=None):
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--mode", choices=("headline", "c5"), default="headline")
-    ap.add_argument("--prewarm", type=float, default=0.15, help="seconds of untimed load before the warm-up steps (clock ramp)")
+    ap.add_argument("--prewarm", type=float, default=0.3, help="seconds of untimed load before the warm-up steps (clock ramp; round 5: 0.15 -> 0.3 s, the ten 20-step windows of a run still climbed by 2 % after 0.15 s)")
     ap.add_argument("--points", type=int, default=None)
     ap.add_argument("--taps", type=int, default=TAPS)
     ap.add_argument("--buffers", type=int, default=3, help="distinct input vectors rotated per step")
