@@ -115,6 +115,11 @@ for _s, _t in (("f32", _F), ("f64", _D)):
            C.POINTER(_SZ), C.POINTER(_SZ))
     _proto("bdsp_hip_overlap_discard_" + _s, _SZ, _P, _SZ, _P, _SZ, _P, _SZ, _P, _SZ, _SZ, _SZ)
 
+# the B1 size policy (include/basic_dsp_hip.h): keys and accessors
+B1_FFT_MIN_LEN_F32, B1_FFT_MIN_LEN_F64, B1_CONV_MIN_WORK_F32, B1_CONV_MIN_WORK_F64 = 0, 1, 2, 3
+_proto("bdsp_hip_b1_policy_get", _SZ, _I)
+_proto("bdsp_hip_b1_policy_set", _I, _I, _SZ)
+
 for _s, _t, _R in (("32", _F, VectorInteropResult32), ("64", _D, VectorInteropResult64)):
     _proto("new" + _s, _P, C.c_int32, C.c_int32, _t, _SZ, _t)
     _proto("new_with_performance_options" + _s, _P, C.c_int32, C.c_int32, _t, _SZ, _t, _SZ, _I)

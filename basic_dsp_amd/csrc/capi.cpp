@@ -231,6 +231,59 @@ int check_device()
 // ----------------------------------------------------------------------------------------------
 // B1 implementations
 // ----------------------------------------------------------------------------------------------
+// Small host slices travel through a per-thread PINNED staging buffer (hipHostMalloc, grown geometrically, at most
+// B1_STAGE_MAX), and the shortest ones are not copied by the GPU at all: the kernels read and write the staging buffer over
+// PCIe themselves.  *Measured* (tools/b1_crossover.py, profiles/r06_b1_crossover.txt; wall time of one call, f32):
+//   * a pageable hipMemcpyAsync pair + one kernel + hipStreamSynchronize has a floor of 34-44 us from 4096 to 16384 points --
+//     launch, two copy packets and the completion wait, not the pinning of the caller's pages: pinned copies (mode 1) save
+//     0-5 us on a complex vector and 15-40 us on the larger real / f64 ones up to 1 MiB, and LOSE from 2 MiB on, where
+//     the runtime pins the caller's pages itself and two host memcpys cost more than that (2^18 points: 120 -> 245 us);
+//   * kernels reading the stage directly (mode 2) save another 2-4 us up to 256 KiB and lose above;
+//   * no copy packet at all (mode 3) is what moves the floor: 4096 points 34 -> 21 us, convolve_vector 5001 x 5 taps
+//     44 -> 27 us, 16384 x 1024 taps 54 -> 36 us, 131072 x 1024 taps 142 -> 104 us.
+// B1_STAGE (LAB builds: BDSP_B1_STAGE overrides): 0 pageable copies (rounds 1-5), 1 pinned copies, 2 kernels read the
+// stage / copy down, 3 kernels read and write the stage.
+namespace {
+constexpr size_t B1_STAGE_MAX = size_t(1) << 20;        // pinned staging up to here (bytes per call), pageable copies above
+constexpr size_t B1_ZERO_COPY_FFT_MAX = size_t(256) << 10; // power-of-two transforms read / write the stage themselves up to here
+struct B1Stage {
+    char* p = nullptr;
+    size_t cap = 0;
+    int dev = -1;
+    // no destructor work: at thread exit the HIP runtime may already be gone
+    char* get(size_t bytes)
+    {
+        int device = 0;
+        if (hipGetDevice(&device) != hipSuccess) return nullptr;
+        if (p && dev == device && bytes <= cap) return p;
+        if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; } // every B1 call ends synchronised: nothing reads it any more
+        size_t ncap = size_t(64) << 10;
+        while (ncap < bytes) ncap <<= 1;
+        if (hipHostMalloc((void**)&p, ncap, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); p = nullptr; return nullptr; }
+        cap = ncap;
+        dev = device;
+        return p;
+    }
+};
+thread_local B1Stage t_b1stage;
+
+// The size policy of the B1 boundary (bdsp_hip_b1_policy_get/_set, include/basic_dsp_hip.h).  Defaults: the crossovers
+// measured on the MI355X box against one host core (profiles/r06_b1_crossover.txt); 0 = accept everything.
+constexpr size_t B1_DEFAULT_FFT_MIN_LEN_F32 = 0, B1_DEFAULT_FFT_MIN_LEN_F64 = 0;     // scalars (TODO r06 measurement)
+constexpr size_t B1_DEFAULT_CONV_MIN_WORK_F32 = 0, B1_DEFAULT_CONV_MIN_WORK_F64 = 0; // points x taps
+constexpr int B1_POLICY_KEYS = 4;
+std::atomic<size_t> g_b1_policy[B1_POLICY_KEYS] = {
+    {B1_DEFAULT_FFT_MIN_LEN_F32}, {B1_DEFAULT_FFT_MIN_LEN_F64}, {B1_DEFAULT_CONV_MIN_WORK_F32}, {B1_DEFAULT_CONV_MIN_WORK_F64}};
+
+int b1_stage_mode(size_t bytes, bool zero_copy_ok)
+{
+    static const char* force = lab_env("BDSP_B1_STAGE");
+    if (force) return bytes <= (size_t(64) << 20) ? atoi(force) : 0;
+    if (bytes > B1_STAGE_MAX) return 0;
+    return zero_copy_ok ? 3 : 1;
+}
+} // namespace
+
 template <typename T>
 int b1_fft(int is_complex, T* signal, size_t len, int inverse)
 {
@@ -239,14 +292,39 @@ int b1_fft(int is_complex, T* signal, size_t len, int inverse)
     size_t points = len / 2;
     if (points == 0) return BDSP_OK;
     hipStream_t s = lib_stream();
+    const size_t bytes = sizeof(T) * len;
+    const bool pow2 = is_pow2(points);
+    const int trips = pow2 ? fft_pow2_plain_trips<T>(points) : 0; // 1 = one workgroup-resident kernel
+    int mode = b1_stage_mode(bytes, pow2 && bytes <= B1_ZERO_COPY_FFT_MAX);
+    char* stage = mode ? t_b1stage.get(bytes) : nullptr;
+    if (!stage) mode = 0;
+    if (mode >= 2 && !pow2) mode = 1; // only the power-of-two plans take separate input / output pointers
     WsBlock a, b;
-    BDSP_TRY(a.alloc(sizeof(T) * len, s));
-    BDSP_TRY(b.alloc(sizeof(T) * len, s));
-    BDSP_HIP_TRY(hipMemcpyAsync(a.p, signal, sizeof(T) * len, hipMemcpyHostToDevice, s));
+    if (mode >= 2) {
+        // the first pass reads the pinned stage over PCIe; with mode 3 the last pass writes it: stage -> a [-> b] -> stage
+        memcpy(stage, signal, bytes);
+        if (trips >= 2 || points > 4096) BDSP_TRY(a.alloc(bytes, s)); // (8192 f32: one kernel, but the two-pass plan is its fallback)
+        if (trips >= 3 || mode == 2) BDSP_TRY(b.alloc(bytes, s));
+        FftIo<T> io{};
+        io.n = points; io.flags = 0; io.in_scale = (T)1; io.window_id = -1; io.window_alpha = (T)0;
+        io.in_stride = points; io.out_stride = points;
+        io.in = stage;
+        io.out = mode == 3 ? (void*)stage : b.p;
+        BDSP_TRY(fft_pow2<T>(io, a.as<T>(), trips >= 3 ? b.as<T>() : nullptr, 1, inverse != 0, s));
+        if (mode == 2) BDSP_HIP_TRY(hipMemcpyAsync(stage, b.p, bytes, hipMemcpyDeviceToHost, s));
+        BDSP_HIP_TRY(hipStreamSynchronize(s));
+        memcpy(signal, stage, bytes);
+        return BDSP_OK;
+    }
+    BDSP_TRY(a.alloc(bytes, s));
+    if (trips != 1) BDSP_TRY(b.alloc(bytes, s)); // (a single-kernel length runs in place: no second block)
     bool in_b = false;
+    if (mode == 1) memcpy(stage, signal, bytes);
+    BDSP_HIP_TRY(hipMemcpyAsync(a.p, mode == 1 ? (const void*)stage : (const void*)signal, bytes, hipMemcpyHostToDevice, s));
     BDSP_TRY(fft_two_buffers<T>(a.as<T>(), b.as<T>(), points, 1, inverse != 0, 0, (T)1, -1, (T)0, &in_b, s));
-    BDSP_HIP_TRY(hipMemcpyAsync(signal, in_b ? b.p : a.p, sizeof(T) * len, hipMemcpyDeviceToHost, s));
+    BDSP_HIP_TRY(hipMemcpyAsync(mode ? (void*)stage : (void*)signal, in_b ? b.p : a.p, bytes, hipMemcpyDeviceToHost, s));
     BDSP_HIP_TRY(hipStreamSynchronize(s));
+    if (mode) memcpy(signal, stage, bytes);
     return BDSP_OK;
 }
 
@@ -505,6 +583,13 @@ int b1_convolve(int is_complex, const T* src, size_t src_len, T* dst, size_t dst
     const size_t elem = is_complex ? 2 : 1;
     const size_t points = src_len / elem, ntaps = imp_len / elem;
     if (points == 0 || ntaps == 0 || ntaps > points || dst_len < src_len) return 0; // None
+    // Size policy: None where the host round trip loses to what the reference runs next.  That is only ever its direct
+    // form, convolve_signal_scalar -- real data, at most 15 tap scalars, or a vector no longer than ten impulse responses
+    // (convolution.rs:530-541) -- and only below the measured points x taps product.  A complex vector the reference
+    // would send into its own overlap_discard (with the O(N M / 2) scalar tail, :388-399) is never declined.
+    const bool falls_to_scalar = !is_complex || imp_len <= 15 || src_len <= 10 * imp_len;
+    if (falls_to_scalar && points * ntaps < g_b1_policy[sizeof(T) == 8 ? BDSP_B1_CONV_MIN_WORK_F64 : BDSP_B1_CONV_MIN_WORK_F32].load())
+        return 0;
     int c = check_device();
     if (c != BDSP_OK) return c;
     hipStream_t s = lib_stream();
@@ -515,16 +600,34 @@ int b1_convolve(int is_complex, const T* src, size_t src_len, T* dst, size_t dst
         if (range_end) *range_end = src_len;
         return 1;
     }
-    WsBlock dx, dy, dh;
-    BDSP_TRY(dx.alloc(sizeof(T) * src_len, s));
-    BDSP_TRY(dy.alloc(sizeof(T) * src_len, s));
-    BDSP_TRY(dh.alloc(sizeof(T) * imp_len, s));
-    BDSP_HIP_TRY(hipMemcpyAsync(dx.p, src, sizeof(T) * src_len, hipMemcpyHostToDevice, s));
-    BDSP_HIP_TRY(hipMemcpyAsync(dh.p, imp, sizeof(T) * imp_len, hipMemcpyHostToDevice, s));
-    if (is_complex) BDSP_TRY(conv_complex_dev<T>(dx.as<T>(), dy.as<T>(), points, 1, dh.as<T>(), ntaps, s));
-    else BDSP_TRY(conv_real_dev<T>(dx.as<T>(), dy.as<T>(), points, dh.as<T>(), ntaps, s));
-    BDSP_HIP_TRY(hipMemcpyAsync(dst, dy.p, sizeof(T) * src_len, hipMemcpyDeviceToHost, s));
+    // signal and taps travel as ONE upload: [src | pad to 256 B | taps] in the staging buffer and in the device block
+    const size_t sbytes = sizeof(T) * src_len, ibytes = sizeof(T) * imp_len;
+    const size_t ioff = (sbytes + 255) & ~(size_t)255;
+    const bool block_kernel = ntaps <= FUSED_MAX_TAPS; // the fused kernel reads every input point ~1.3 times: fit for PCIe reads
+    int mode = b1_stage_mode(ioff + ibytes, block_kernel);
+    if (mode >= 2 && !block_kernel) mode = 1;
+    char* stage = mode ? t_b1stage.get(mode == 3 ? 2 * ioff + ibytes + 256 : ioff + ibytes) : nullptr;
+    if (!stage) mode = 0;
+    WsBlock dx, dy;
+    if (mode < 2) BDSP_TRY(dx.alloc(ioff + ibytes, s));
+    if (mode < 3) BDSP_TRY(dy.alloc(sbytes, s));
+    if (mode) {
+        memcpy(stage, src, sbytes);
+        memcpy(stage + ioff, imp, ibytes);
+    }
+    if (mode == 1) BDSP_HIP_TRY(hipMemcpyAsync(dx.p, stage, ioff + ibytes, hipMemcpyHostToDevice, s));
+    else if (mode == 0) {
+        BDSP_HIP_TRY(hipMemcpyAsync(dx.p, src, sbytes, hipMemcpyHostToDevice, s));
+        BDSP_HIP_TRY(hipMemcpyAsync((char*)dx.p + ioff, imp, ibytes, hipMemcpyHostToDevice, s));
+    }
+    const T* din = mode >= 2 ? (const T*)stage : dx.as<T>();
+    const T* dtaps = (const T*)((const char*)din + ioff);
+    T* dout = mode == 3 ? (T*)(stage + ioff + ((ibytes + 255) & ~(size_t)255)) : dy.as<T>();
+    if (is_complex) BDSP_TRY(conv_complex_dev<T>(din, dout, points, 1, dtaps, ntaps, s));
+    else BDSP_TRY(conv_real_dev<T>(din, dout, points, dtaps, ntaps, s));
+    if (mode < 3) BDSP_HIP_TRY(hipMemcpyAsync(mode ? (void*)stage : (void*)dst, dy.p, sbytes, hipMemcpyDeviceToHost, s));
     BDSP_HIP_TRY(hipStreamSynchronize(s));
+    if (mode) memcpy(dst, mode == 3 ? (const char*)dout : stage, sbytes);
     if (range_start) *range_start = 0;
     if (range_end) *range_end = src_len;
     return 1; // Some(0..src_len)
@@ -1836,13 +1939,23 @@ extern "C" {
 int bdsp_hip_has_gpu_support_f32(void) { return device_ready() == BDSP_OK; }
 int bdsp_hip_has_gpu_support_f64(void) { return device_ready() == BDSP_OK; }
 
-static int supported_len(int is_complex, size_t len)
+static int supported_len(int is_complex, size_t len, int f64)
 {
+    // below the measured crossover the caller's rustfft is faster than a host round trip: the trait's own mechanism
+    // (time_freq/mod.rs:41-44 falls back to rustfft when this answers false)
+    if (len < g_b1_policy[f64 ? BDSP_B1_FFT_MIN_LEN_F64 : BDSP_B1_FFT_MIN_LEN_F32].load()) return 0;
     // complex only (like ocl/mod.rs:277-281), at least one point, interleaved length even
     return is_complex && len >= 2 && len % 2 == 0 && (len / 2) <= (size_t(1) << 29);
 }
-int bdsp_hip_is_supported_fft_len_f32(int is_complex, size_t len) { return supported_len(is_complex, len); }
-int bdsp_hip_is_supported_fft_len_f64(int is_complex, size_t len) { return supported_len(is_complex, len); }
+int bdsp_hip_is_supported_fft_len_f32(int is_complex, size_t len) { return supported_len(is_complex, len, 0); }
+int bdsp_hip_is_supported_fft_len_f64(int is_complex, size_t len) { return supported_len(is_complex, len, 1); }
+size_t bdsp_hip_b1_policy_get(int key) { return key >= 0 && key < B1_POLICY_KEYS ? g_b1_policy[key].load() : 0; }
+int bdsp_hip_b1_policy_set(int key, size_t value)
+{
+    if (key < 0 || key >= B1_POLICY_KEYS) return BDSP_ERR_UNSUPPORTED;
+    g_b1_policy[key].store(value);
+    return BDSP_OK;
+}
 
 int bdsp_hip_fft_f32(int is_complex, float* signal, size_t len, int inverse) { return b1_fft<float>(is_complex, signal, len, inverse); }
 int bdsp_hip_fft_f64(int is_complex, double* signal, size_t len, int inverse) { return b1_fft<double>(is_complex, signal, len, inverse); }

@@ -76,6 +76,12 @@ def parse(argv=None):
     ap.add_argument("--e2e-chunk-vectors", type=int, default=2, help="vectors per pipelined chunk of that leg")
     ap.add_argument("--e2e-timeout", type=float, default=300.0,
                     help="seconds before a scatter/compute/gather leg that hangs is given up: the line is printed with an error in its place")
+    ap.add_argument("--no-self-check", action="store_true",
+                    help="skip the self-check of the timed step's output (for runs under rocprofv3: it launches torch kernels and "
+                         "one more step)")
+    ap.add_argument("--test-corrupt-self-check", action="store_true",
+                    help="TEST HOOK, needs BDSP_BENCH_CORRUPT_SELF_CHECK=1 as well: one value of the checked convolution output is "
+                         "changed before the self-check, which must then fail (exit code 5)")
     ap.add_argument("--no-first-call", action="store_true", help="skip the fresh-process first-call measurement (config.first_call_ms)")
     ap.add_argument("--cpu-sample-points", type=int, default=1 << 23)
     ap.add_argument("--dry-run-launch", action="store_true", help="print the per-rank child launches of --gpus N and exit")
@@ -146,6 +152,11 @@ def supervise(procs, timeout_s):
         bad = [r for r, c in enumerate(codes) if c not in (None, 0)]
         if bad:
             failed = "rank %d exited with code %d" % (bad[0], codes[bad[0]])
+            # a peer that left because the multi-GPU leg failed on it (EXIT_E2E): rank 0 still owes the JSON line -- its own
+            # collective fails or its watchdog fires within --e2e-timeout -- so it alone is waited for, up to the deadline
+            if codes[0] is None and all(codes[r] == EXIT_E2E for r in bad) and time.monotonic() < deadline:
+                time.sleep(0.05)
+                continue
             break
         if all(c == 0 for c in codes):
             break
@@ -439,6 +450,75 @@ def first_call_cost(points, taps):
     except (OSError, subprocess.SubprocessError, ValueError) as e:
         return {"error": str(e)[-300:]}
 
+# ------------------------------------------------------------------------------------------ self-check of the timed output
+EXIT_SELF_CHECK, EXIT_E2E = 5, 4  # after the JSON line is out: the step's output is wrong / the multi-GPU leg hung or failed
+
+
+def dft_bins(yc, ks):
+    """X[k] = sum_n y[n] exp(-2 pi i n k / N) for a few k, from the definition, in f64 on the host: n = a B + b splits the
+    phase into two small tables of EXACT phases (integer k n mod N), the sum into one matrix product -- 16M points x 6 bins
+    cost 0.1 s instead of 16M complex exponentials per bin (the arithmetic of tests/test_gpu_full_size.py:85-91)."""
+    import numpy as np
+    n = yc.shape[0]
+    b = 1
+    while b * b < n:
+        b <<= 1
+    while n % b:
+        b >>= 1
+    a = n // b
+    ks = np.asarray(ks, dtype=np.int64)
+    ib, ia = np.arange(b, dtype=np.int64), np.arange(a, dtype=np.int64)
+    tb = np.exp(-2j * np.pi * ((ib[:, None] * ks[None, :]) % n) / n)                 # (b, K)
+    ta = np.exp(-2j * np.pi * (((ia[:, None] * b) % n * ks[None, :]) % n) / n)       # (a, K)
+    return np.sum((yc.reshape(a, b) @ tb) * ta, axis=0)
+
+
+def self_check(torch, np, orc, x, y_t, spec_t, n, m, taps_t, corrupt=False):
+    """Checks ONE vector of the last timed step: x (input), y_t (its convolve_signal output, recomputed bit-identically
+    after the timed region because the 3-pass transform overwrites it), spec_t (the TIMED step's spectrum).  The checker is
+    the CPU oracle (tests/oracle_lib.py, f64) and numpy -- never the library under test.
+      conv_rel_l2_max  three 4 096-output windows of y (vector start and end -- both read across the wrap-around -- and the
+                       middle) against orc.convolve_direct in f64 (time_freq/mod.rs:455-473)
+      fft_bin_err_max  six bins of the spectrum against the DFT definition of y in f64, relative to sqrt(N) rms|y|
+      parseval_rel     | sum|X|^2 / N - sum|y|^2 | / sum|y|^2 in f64
+    Tolerances: north_star's 1e-6 (2e-6 for a single bin, as in tests/test_gpu_full_size.py)."""
+    t0 = time.perf_counter()
+    W, pad = 4096, ((m + 1) // 2 + 63) // 64 * 64 + 64
+    h64 = taps_t.cpu().numpy().astype(np.float64)
+    if corrupt:
+        y_t[2 * (n // 2) + 200] += 1.0
+    conv_err = 0.0
+    firsts = sorted({0, max(0, n // 2 - W // 2), max(0, n - W)}) if n >= W + 2 * pad else [None]
+    for first in firsts:
+        if first is None:  # a vector shorter than a window + margins: the whole of it
+            ref = orc.convolve_direct(x.cpu().numpy().astype(np.float64), h64, True)
+            got = y_t.cpu().numpy()
+        else:
+            idx = (torch.arange(first - pad, first + W + pad, device=x.device) % n)
+            xs = x.view(-1, 2)[idx].reshape(-1).cpu().numpy().astype(np.float64)
+            # the oracle convolves circularly over what it is given; outputs `pad` away from the ends of this excerpt never
+            # see its seam, so they are the outputs first .. first + W of the whole vector
+            ref = orc.convolve_direct(xs, h64, True, pad, W)
+            got = y_t[2 * first:2 * (first + W)].cpu().numpy()
+        conv_err = max(conv_err, float(np.linalg.norm(got - ref) / max(np.linalg.norm(ref), 1e-300)))
+    yc = y_t.cpu().numpy().view(np.complex64).astype(np.complex128)
+    X = spec_t.cpu().numpy().view(np.complex64)
+    ks = sorted({0, 1, min(4097, n - 1), n // 2, n - 1, 12_345_678 % n})
+    ref = dft_bins(yc, ks)
+    e_t = float(np.vdot(yc, yc).real)
+    scale = np.sqrt(e_t)  # = sqrt(N) * rms|y|: the typical magnitude of a bin
+    bin_err = float(np.max(np.abs(X[ks].astype(np.complex128) - ref)) / max(scale, 1e-300))
+    Xr = X.view(np.float32).astype(np.float64)
+    e_f = float(np.dot(Xr, Xr)) / n
+    parseval = abs(e_f - e_t) / max(e_t, 1e-300)
+    ok = bool(conv_err < 1e-6 and bin_err < 2e-6 and parseval < 1e-6)
+    return {"ok": ok, "conv_rel_l2_max": conv_err, "fft_bin_err_max": bin_err, "parseval_rel": parseval,
+            "conv_windows": ["whole vector"] if firsts == [None] else [[f, f + W] for f in firsts], "fft_bins": [int(k) for k in ks],
+            "tolerances": {"conv_rel_l2": 1e-6, "fft_bin": 2e-6, "parseval": 1e-6},
+            "checker": "CPU oracle orc.convolve_direct (f64) + DFT definition / Parseval in numpy f64; product library not involved",
+            "seconds": time.perf_counter() - t0}
+
+
 # ------------------------------------------------------------------------------------------ one rank
 def run_rank(args):
     rank = int(os.environ.get("RANK", "0"))
@@ -583,9 +663,14 @@ def run_rank(args):
     # the headline by -2.9 % on identical kernel sources and the record could not say whether that was noise.
     more = [timed_window() for _ in range(max(0, args.windows))]
     win_elapsed = [elapsed] + [w[0] for w in more]
+    own_elapsed = [elapsed]  # every rank's OWN window-0 time (value_by_rank: a straggling GPU must be visible in a weak-scaling sum)
     if use_dist:
         t = torch.tensor(win_elapsed, device=cdev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        own = torch.zeros(world, device=cdev, dtype=torch.float64)
+        own[rank] = elapsed
+        dist.all_reduce(own, op=dist.ReduceOp.SUM)
+        own_elapsed = [float(v) for v in own.tolist()]
         win_elapsed = [float(v) for v in t.tolist()]
         elapsed = win_elapsed[0]
     steps_with_events = len(conv_ms)
@@ -609,6 +694,36 @@ def run_rank(args):
     conv_raw = sum(conv_ms) / len(conv_ms)
     conv_avg = max(conv_raw - event_overhead, 1e-6)
     fft_avg = max(sum(fft_ms) / len(fft_ms) - event_overhead, 1e-6)
+
+    # ---- the self-check (round 6): the line certifies the output of the step it timed.  The last step of the last window
+    # read xs[(K-1) % buffers]; its spectrum is still in y / scratch.  The convolution result it transformed is gone (the
+    # passes ping-pong through y), so that step runs ONCE more, untimed, on the same input: its spectrum must equal the
+    # timed one bit for bit (same kernels, same data), and its y is what the checker sees.
+    check = None
+    if rank == 0 and not args.no_self_check:
+        import numpy as np
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle_lib as orc
+        t_sc = time.perf_counter()
+        last = args.steps - 1
+        torch.cuda.synchronize()
+        spec_timed = (scratch if in_scratch.value else y).clone()
+        x_last = xs[last % len(xs)]
+        bd._lib.check(lib.bdsp_hip_dev_convolve(0, x_last.data_ptr(), y.data_ptr(), n, nvec, taps.data_ptr(), m, sp))
+        torch.cuda.synchronize()
+        y_keep = y.clone()
+        bd._lib.check(lib.bdsp_hip_dev_fft(0, y.data_ptr(), scratch.data_ptr(), n, nvec, 0, 1.0, -1, 0.0, C.byref(in_scratch), sp))
+        torch.cuda.synchronize()
+        same = bool(torch.equal(spec_timed, scratch if in_scratch.value else y))
+        vsel = nvec - 1  # the batch's last vector
+        sl = slice(2 * n * vsel, 2 * n * (vsel + 1))
+        corrupt = args.test_corrupt_self_check and os.environ.get("BDSP_BENCH_CORRUPT_SELF_CHECK") == "1"
+        check = self_check(torch, np, orc, x_last[sl], y_keep[sl], spec_timed[sl], n, m, taps, corrupt)
+        check["rerun_spectrum_bit_identical_to_timed"] = same
+        check["ok"] = bool(check["ok"] and same)
+        check["vector_checked"] = vsel
+        check["seconds"] = time.perf_counter() - t_sc
+        del spec_timed, y_keep
 
     out = None
     if rank == 0:
@@ -666,6 +781,9 @@ def run_rank(args):
             "unit": "Msamples/s",
             "n_gpus": world,
             "ranks_seen": ranks_seen,
+            # each rank's own rate over window 0 (its own clock between the same two barriers); `value` divides ALL ranks'
+            # samples by the slowest rank's time
+            "value_by_rank": None if share_gpu else [n * nvec * args.steps / e / 1e6 for e in own_elapsed],
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
@@ -750,6 +868,7 @@ def run_rank(args):
             "clock_power_samples": [w["samples"] for w in wclk],
             "sampler_period_ms": 0.5,
         }
+        out["self_check"] = check
         if share_gpu:
             out["test_hook"] = True
             out["test_hook_value"] = samples / elapsed / 1e6
@@ -765,26 +884,7 @@ def run_rank(args):
             return verified_scatter_gather(args, torch, dist, dev, rank, world, m, share_gpu)
         return None
 
-    def e2e_timed_out():
-        if rank == 0:
-            out["c5_end_to_end"] = {"error": "no result after %.0f s (--e2e-timeout): the scatter / compute / gather leg hung; every other "
-                                             "figure of this line was final before the leg started" % args.e2e_timeout}
-            print(json.dumps(out))
-            sys.stdout.flush()
-        else:
-            time.sleep(5)
-        os._exit(0)
-
-    import threading
-    e2e_done = threading.Event()
-    threading.Thread(target=lambda: e2e_done.wait(args.e2e_timeout) or e2e_timed_out(), daemon=True).start()
-    group_ok = True
-    try:
-        e2e = e2e_leg()
-    except Exception as exc:  # noqa: BLE001  (a failed collective: say so in the line; a verification MISMATCH is a SystemExit and ends the run)
-        e2e, group_ok = {"error": "%s: %s" % (type(exc).__name__, str(exc)[-400:])}, False
-    finally:
-        e2e_done.set()
+    e2e, group_ok = guarded_leg(e2e_leg, args.e2e_timeout, rank, out)
 
     if rank == 0:
         if e2e is not None:
@@ -796,6 +896,76 @@ def run_rank(args):
     if use_dist and group_ok:
         dist.barrier()
         dist.destroy_process_group()
+    # exit codes, all AFTER the line: 4 = the scatter / compute / gather leg failed, 5 = the timed step's output is wrong
+    code = final_exit_code(group_ok, check if rank == 0 else None)
+    if code == EXIT_E2E:
+        sys.stdout.flush()
+        if rank != 0:
+            time.sleep(2)  # (rank 0's line first)
+        os._exit(code)  # (not sys.exit: a broken process group can hang interpreter shutdown in its destructor)
+    if code:
+        sys.stderr.write("bench.py: self-check FAILED: %s\n" % json.dumps(check))
+        sys.exit(code)
+
+
+def guarded_leg(leg, timeout_s, rank, out):
+    """Runs the multi-GPU leg under a watchdog.  Returns (its result, True), or ({"error": ...}, False) when it raised (a
+    failed collective; a verification MISMATCH is a SystemExit(3) and passes through).  A leg that HANGS is given up after
+    `timeout_s`: rank 0 prints the line -- every other figure in `out` was final before the leg started -- with the error in
+    the leg's place, and EVERY rank leaves with exit code 4, so that the launcher, torchrun and the driver see that the
+    path's one exchange did not complete (round 5 exited 0 here).  The process ends itself; nothing is re-executed."""
+    import threading
+
+    def timed_out():
+        if rank == 0:
+            out["c5_end_to_end"] = {"error": "no result after %.0f s (--e2e-timeout): the scatter / compute / gather leg hung; every other "
+                                             "figure of this line was final before the leg started" % timeout_s}
+            print(json.dumps(out))
+            sys.stdout.flush()
+        else:
+            time.sleep(5)
+        os._exit(EXIT_E2E)
+
+    done = threading.Event()
+    threading.Thread(target=lambda: done.wait(timeout_s) or timed_out(), daemon=True).start()
+    try:
+        return leg(), True
+    except Exception as exc:  # noqa: BLE001
+        return {"error": "%s: %s" % (type(exc).__name__, str(exc)[-400:])}, False
+    finally:
+        done.set()
+
+
+def final_exit_code(group_ok, check):
+    """0, or -- after the JSON line is out -- 4 when the multi-GPU leg failed, 5 when the self-check of the timed output did."""
+    if not group_ok:
+        return EXIT_E2E
+    if check is not None and not check["ok"]:
+        return EXIT_SELF_CHECK
+    return 0
+
+
+XGMI_LINK_GBS = 153.0  # per direction per link; rank 0 has one link to each of its 7 peers (SURVEY.md 5 / 8e, MI355X guide)
+
+
+def link_model(world, vectors_per_gpu, points, chunk_vectors, elem_bytes=8):
+    """What the chunked scatter / compute / gather should cost if only the wires counted (xGMI is point to
+    point, every peer's shard travels on its own link, 153 GB/s per direction): the pipeline runs ceil(per / chunk) + 2
+    lock-step rounds (basic_dsp_amd/batch.py), each moving at most one chunk up and one chunk down per link, full duplex.
+    Rank 0's HBM serves all links at once: (world - 1) chunks read and written per round.  `ms` well above `expected_ms`
+    on the first N > 1 record means launch / rendezvous latency per round, not bandwidth; `bound` names the larger term."""
+    if world <= 1:
+        return {"expected_ms": None, "note": "world size 1: no peer, nothing travels"}
+    chunks = -(-vectors_per_gpu // chunk_vectors)
+    chunk_bytes = chunk_vectors * points * elem_bytes
+    round_link_ms = chunk_bytes / (XGMI_LINK_GBS * 1e9) * 1e3
+    round_hbm_ms = 2 * (world - 1) * chunk_bytes / (HBM_ACHIEVABLE_GBS * 1e9) * 1e3
+    rounds = chunks + 2
+    link_ms, hbm_ms = rounds * round_link_ms, rounds * round_hbm_ms
+    return {"expected_ms": max(link_ms, hbm_ms), "bound": "xgmi link" if link_ms >= hbm_ms else "rank 0 HBM",
+            "link_ms": link_ms, "rank0_hbm_ms": hbm_ms, "rounds": rounds, "bytes_per_peer_per_direction": vectors_per_gpu * points * elem_bytes,
+            "link_GBs_per_direction": XGMI_LINK_GBS, "hbm_GBs": HBM_ACHIEVABLE_GBS,
+            "not_modelled": "compute (overlapped on a side stream), per-round launch / rendezvous latency"}
 
 
 def c5_end_to_end(args, bd, torch, dist, dev, rank, world, n, m, nvec, use_dist):
@@ -824,7 +994,8 @@ def c5_end_to_end(args, bd, torch, dist, dev, rank, world, n, m, nvec, use_dist)
         times.append(time.perf_counter() - t0)
         del out
     best = min(times[1:])
-    return {"vectors": total, "chunk_vectors": args.chunk_vectors, "ms": best * 1e3,
+    model = link_model(world, nvec, n, args.chunk_vectors)
+    return {"vectors": total, "chunk_vectors": args.chunk_vectors, "ms": best * 1e3, "expected_ms": model["expected_ms"], "link_model": model,
             "Msamples_s": total * n / best / 1e6, "runs_ms": [t * 1e3 for t in times]}
 
 
@@ -899,7 +1070,9 @@ def verified_scatter_gather(args, torch, dist, dev, rank, world, m, share_gpu, c
         dist.destroy_process_group()
         raise SystemExit(3)
     best = min(times[1:])
-    return {"ms": best * 1e3, "Msamples_s": total * n / best / 1e6, "verified_rows": rows, "peers": world - 1,
+    model = link_model(world, per, n, chunk)
+    return {"ms": best * 1e3, "expected_ms": model["expected_ms"], "link_model": model,
+            "Msamples_s": total * n / best / 1e6, "verified_rows": rows, "peers": world - 1,
             "verified": "bit-identical to rank 0's own convolve_signal -> plain_fft of the same chunks" +
                         (" (world size 1: rank 0's own shard)" if world == 1 else ""),
             "vectors": total, "points": n, "vectors_per_gpu": per, "chunk_vectors": chunk, "taps": m,

@@ -73,10 +73,32 @@ int bdsp_hip_has_gpu_support_f64(void);
 
 /* fn is_supported_fft_len(is_complex, len) -> bool      (gpu_support/mod.rs:32)
  * `len` in scalars.  Like the OpenCL backend (ocl/mod.rs:277-299) real input is refused; unlike
- * it, EVERY complex length >= 2 points is supported (powers of two natively, all other lengths
- * through Bluestein on the same kernels), matching what rustfft accepts on the CPU path. */
+ * it, EVERY complex length is supported (powers of two and 2,3,5,7-smooth lengths natively, all other
+ * lengths through Bluestein on the same kernels), matching what rustfft accepts on the CPU path --
+ * from the B1 size policy's FFT_MIN_LEN (below) up: shorter vectors are answered 0 so that the caller
+ * keeps them on rustfft, which is faster than a host round trip there. */
 int bdsp_hip_is_supported_fft_len_f32(int is_complex, size_t len);
 int bdsp_hip_is_supported_fft_len_f64(int is_complex, size_t len);
+
+/* The size policy of B1.  Every B1 call is a host round trip (upload, kernels, download, one synchronisation); below some
+ * length the CPU code the reference runs when the plug-in declines is faster.  The reference's OpenCL backend picked its
+ * device by data length for the same reason (gpu_support/ocl/mod.rs:69-80).  The trait offers two ways to decline:
+ *   is_supported_fft_len -> false   sends fft() to rustfft          (time_freq/mod.rs:41-44)
+ *   gpu_convolve_vector  -> None    sends convolve_signal on       (convolution.rs:504-541)
+ * and this library uses them below these thresholds:
+ *   FFT_MIN_LEN   is_supported_fft_len answers 0 for len (scalars) below it.  bdsp_hip_fft_* itself still transforms ANY
+ *                 length it is handed.
+ *   CONV_MIN_WORK gpu_convolve_vector answers 0 (None) when points x taps is below it AND the reference's next choice is
+ *                 its direct form convolve_signal_scalar (real data, imp_len <= 15 scalars, or src_len <= 10 imp_len); a
+ *                 complex vector the reference would send into its own overlap_discard is never declined.
+ * Defaults: the crossovers measured on an MI355X box against one host core (profiles/r06_b1_crossover.txt,
+ * tools/b1_crossover.py -- which a deployment can rerun on its own host).  0 = never decline.  Process-wide, thread-safe. */
+#define BDSP_B1_FFT_MIN_LEN_F32 0
+#define BDSP_B1_FFT_MIN_LEN_F64 1
+#define BDSP_B1_CONV_MIN_WORK_F32 2
+#define BDSP_B1_CONV_MIN_WORK_F64 3
+size_t bdsp_hip_b1_policy_get(int key);
+int bdsp_hip_b1_policy_set(int key, size_t value); /* BDSP_OK, or BDSP_ERR_UNSUPPORTED for an unknown key */
 
 /* fn fft(is_complex, signal: &mut [T], direction)       (gpu_support/mod.rs:35)
  * In place on `len` scalars (= len/2 complex points), UNNORMALISED in both directions

@@ -232,3 +232,103 @@ def test_bench_verified_scatter_gather_leg_over_gloo(world, tmp_path):
         for r in range(1, world):
             assert rs[r]["calls"] == [2, 2, 1] * 4, rs[r]["calls"]
         assert rs[0]["calls"] == [2, 2, 1] * 4 + [2, 1] * (world - 1), rs[0]["calls"]
+
+
+_GUARDED_LEG_RANK = r"""
+import json, os, sys, time
+import torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+import argparse, bench
+rank, world, mode = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), sys.argv[2]
+dist.init_process_group("gloo", rank=rank, world_size=world)
+out = {"value": 123.0, "value_by_rank": [1.0] * world}  # "every other figure of the line was final before the leg started"
+
+def compute(shard, taps, points):
+    return shard * 2.0 + taps[:1]
+
+def leg():
+    if mode == "hang" and rank == world - 1:
+        time.sleep(3600)       # a rank that never joins the leg
+    if mode == "raise" and rank == world - 1:
+        raise RuntimeError("collective failed on this rank")
+    args = argparse.Namespace(e2e_vectors_per_gpu=5, e2e_chunk_vectors=2)
+    return bench.verified_scatter_gather(args, torch, dist, torch.device("cpu"), rank, world, 16, True, compute=compute, points=64)
+
+e2e, ok = bench.guarded_leg(leg, 6.0 if mode == "hang" else 60.0, rank, out)
+if rank == 0:
+    out["c5_end_to_end"] = e2e
+    print(json.dumps(out), flush=True)
+code = bench.final_exit_code(ok, None)
+if code:
+    os._exit(code)
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_a_hung_or_failed_leg_ends_with_exit_code_4_after_the_line(world, tmp_path):
+    """Round 6 (VERDICT r5 item 4a / ADVICE): bench.py's watchdog around the scatter / compute / gather leg.  A leg that hangs
+    (the last rank never joins it) is given up after the timeout: rank 0 prints the line, whose other figures were final,
+    with an error in the leg's place, and EVERY rank leaves with exit code 4 -- no rank exits 0, nothing is re-executed.
+    A leg that completes carries the link model's `expected_ms` next to `ms`.  bench.supervise (the launcher's side) keeps
+    waiting for rank 0's line when a PEER leaves with code 4 first."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+
+    def run(mode, supervised):
+        port = _free_port()
+        procs = []
+        for r in range(world):
+            env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+            procs.append(subprocess.Popen([sys.executable, "-c", _GUARDED_LEG_RANK, root, mode], env=env,
+                                          stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, stderr=subprocess.DEVNULL))
+        if supervised:
+            failed, out0 = bench.supervise(procs, 120.0)
+        else:  # every rank is left to end by itself
+            out0 = procs[0].communicate(timeout=120)[0]
+            for p in procs[1:]:
+                p.wait(timeout=120)
+            failed = None
+        lines = [l for l in out0.decode().splitlines() if l.startswith("{")]
+        return failed, [p.returncode for p in procs], [json.loads(l) for l in lines]
+
+    failed, codes, lines = run("ok", True)
+    assert failed is None and codes == [0] * world and len(lines) == 1
+    e = lines[0]["c5_end_to_end"]
+    assert e["verified_rows"] == 3 * (world - 1) and e["ms"] > 0
+    # 5 vectors of 64 points in chunks of 2: 3 + 2 lock-step rounds of 2 * 64 * 8 bytes per link at 153 GB/s
+    assert abs(e["expected_ms"] - 5 * (2 * 64 * 8) / 153e9 * 1e3) < 1e-12 and e["link_model"]["rounds"] == 5 and e["link_model"]["bound"] == "xgmi link"
+    # a hang: every rank ends ITSELF with code 4, rank 0 after printing the line
+    failed, codes, lines = run("hang", False)
+    assert codes == [4] * world, codes
+    assert len(lines) == 1 and "hung" in lines[0]["c5_end_to_end"]["error"] and lines[0]["value"] == 123.0
+    # a collective that fails on a peer: the peer leaves with code 4 at once, the launcher's supervisor keeps waiting for
+    # rank 0, whose own collective then fails -- its line still arrives, with the error in the leg's place, and it exits 4 too
+    failed, codes, lines = run("raise", True)
+    assert failed and "code 4" in failed and codes[0] == 4 and codes[world - 1] == 4 and all(c != 0 for c in codes), (failed, codes)
+    assert len(lines) == 1 and "error" in lines[0]["c5_end_to_end"] and lines[0]["value"] == 123.0
+
+
+def test_exit_codes_and_link_model_of_the_bench_line():
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    assert bench.final_exit_code(True, None) == 0 and bench.final_exit_code(True, {"ok": True}) == 0
+    assert bench.final_exit_code(True, {"ok": False}) == bench.EXIT_SELF_CHECK == 5
+    assert bench.final_exit_code(False, {"ok": False}) == bench.EXIT_E2E == 4
+    # config C5 on the node: 64 vectors of 2^20 points per GPU in chunks of 8 -> 8 + 2 rounds of 64 MiB per link
+    m = bench.link_model(8, 64, 1 << 20, 8)
+    assert m["rounds"] == 10 and abs(m["expected_ms"] - 10 * (8 << 23) / 153e9 * 1e3) < 1e-9 and m["bound"] == "xgmi link"
+    assert m["bytes_per_peer_per_direction"] == 512 << 20 and 0 < m["rank0_hbm_ms"] < m["link_ms"]
+    assert bench.link_model(1, 8, 1 << 20, 2)["expected_ms"] is None
+    # the self-check's DFT-by-definition helper against numpy's transform
+    import numpy as np
+    rng = np.random.default_rng(5)
+    for n in (1 << 12, 3000, 1 << 15):
+        y = rng.standard_normal(n) + 1j * rng.standard_normal(n)
+        ks = sorted({0, 1, n // 2, n - 1, 12345678 % n})
+        assert np.max(np.abs(bench.dft_bins(y, ks) - np.fft.fft(y)[ks])) < 1e-9 * np.sqrt(n)

@@ -453,12 +453,33 @@ def test_bench_py_runs_both_modes_and_prints_the_contract_fields():
     assert abs(vw["conv_ms"][0] - k["conv_ms"]) < 1e-12 and abs(vw["fft_ms"][0] - k["fft_ms"]) < 1e-12
     assert all(0.5 * k["conv_ms"] < c < 2 * k["conv_ms"] for c in vw["conv_ms"]) and vw["spread_pct"] >= 0
     assert "c5_end_to_end" not in d  # (no process group at a plain N = 1: nothing changes)
+    # round 6: the line certifies the output of the step it timed -- the last step's convolution result against the f64 direct
+    # form on three windows, six bins of its spectrum against the DFT definition, Parseval; and each rank's own rate
+    sc = d["self_check"]
+    assert sc["ok"] is True and sc["rerun_spectrum_bit_identical_to_timed"] is True, sc
+    assert 0 < sc["conv_rel_l2_max"] < 1e-6 and 0 < sc["fft_bin_err_max"] < 2e-6 and sc["parseval_rel"] < 1e-6, sc
+    assert len(sc["conv_windows"]) == 3 and sc["conv_windows"][0][0] == 0 and sc["conv_windows"][-1][1] == 1 << 24 and len(sc["fft_bins"]) == 6
+    assert sc["seconds"] < 5.0, sc["seconds"]
+    assert d["value_by_rank"] == [d["value"]]
+    # ... and a wrong output makes the run fail AFTER the line is printed (test hook: one value of the checked y is changed)
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "4", "--warmup", "1", "--prewarm", "0.02", "--windows", "0",
+                        "--no-cpu-baseline", "--no-first-call", "--test-corrupt-self-check"], env=dict(env, BDSP_BENCH_CORRUPT_SELF_CHECK="1"),
+                       capture_output=True, text=True, timeout=600)
+    assert p.returncode == 5 and "self-check FAILED" in p.stderr, (p.returncode, p.stderr[-1500:])
+    bad = json.loads(p.stdout.strip().splitlines()[-1])["self_check"]
+    assert bad["ok"] is False and bad["conv_rel_l2_max"] > 1e-3 and bad["rerun_spectrum_bit_identical_to_timed"] is True
+    # (the flag alone, without the environment variable, changes nothing; --no-self-check leaves the key null)
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "4", "--warmup", "1", "--prewarm", "0.02", "--windows", "0",
+                        "--no-cpu-baseline", "--no-first-call", "--no-self-check"], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and json.loads(p.stdout.strip().splitlines()[-1])["self_check"] is None
     p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--mode", "c5", "--steps", "4", "--warmup", "1",
                         "--prewarm", "0.02", "--vectors-per-gpu", "16", "--no-cpu-baseline"], env=env, capture_output=True,
                        text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-2000:]
     d = json.loads(p.stdout.strip().splitlines()[-1])
     assert d["config"]["vectors_per_gpu"] == 16 and d["c5_end_to_end"]["vectors"] == 16 and d["c5_end_to_end"]["ms"] > 0
+    assert d["c5_end_to_end"]["expected_ms"] is None  # (world size 1: nothing travels)
+    assert d["self_check"]["ok"] is True and d["self_check"]["vector_checked"] == 15, d["self_check"]
 
 
 def test_bench_py_two_and_three_ranks_through_its_own_launcher_on_one_gpu():
@@ -505,6 +526,9 @@ def test_bench_py_two_and_three_ranks_through_its_own_launcher_on_one_gpu():
             e = d["c5_end_to_end"]
             assert e["peers"] == ranks - 1 and e["verified_rows"] == 4 * (ranks - 1) and e["vectors"] == 4 * ranks
             assert e["ms"] > 0 and e["Msamples_s"] > 0 and e["chunk_vectors"] == 2 and "gloo" in e["transport"]
+            # round 6: what the wires alone would cost (4 vectors in chunks of 2: 2 + 2 rounds of 16 MiB per link at 153 GB/s)
+            assert abs(e["expected_ms"] - 4 * (2 << 23) / 153e9 * 1e3) < 1e-9 and e["link_model"]["bound"] == "xgmi link" and e["link_model"]["rounds"] == 4
+            assert d["value_by_rank"] is None and d["self_check"]["ok"] is True
             assert d["value_windows"]["values"] is None and len(d["value_windows"]["ms_per_step"]) == 10
     # ... and a gathered row that differs from rank 0's own computation ends every rank non-zero
     p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--prewarm", "0.02",
@@ -517,7 +541,8 @@ def test_bench_py_two_and_three_ranks_through_its_own_launcher_on_one_gpu():
                         "--no-cpu-baseline", "--test-share-gpu", "--e2e-vectors-per-gpu", "4", "--windows", "1", "--e2e-timeout", "20"],
                        env=dict(env, BDSP_BENCH_HANG_E2E="1"), capture_output=True, text=True, timeout=600)
     lines = [l for l in p.stdout.strip().splitlines() if l.startswith("{")]
-    assert p.returncode == 0 and len(lines) == 1, (p.returncode, p.stdout[-500:], p.stderr[-1500:])
+    # (round 6: the ranks leave with exit code 4 AFTER the line, so the launcher -- and the driver -- see the failure)
+    assert p.returncode != 0 and "exited with code 4" in p.stderr and len(lines) == 1, (p.returncode, p.stdout[-500:], p.stderr[-1500:])
     d = json.loads(lines[0])
     assert "hung" in d["c5_end_to_end"]["error"] and d["ranks_seen"] == 2 and d["test_hook_value"] > 0 and len(d["value_windows"]["ms_per_step"]) == 2
     # the same two ranks under torch.distributed.run, as the driver launches them
