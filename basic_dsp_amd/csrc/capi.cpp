@@ -231,21 +231,23 @@ int check_device()
 // ----------------------------------------------------------------------------------------------
 // B1 implementations
 // ----------------------------------------------------------------------------------------------
-// Small host slices travel through a per-thread PINNED staging buffer (hipHostMalloc, grown geometrically, at most
-// B1_STAGE_MAX), and the shortest ones are not copied by the GPU at all: the kernels read and write the staging buffer over
-// PCIe themselves.  *Measured* (tools/b1_crossover.py, profiles/r06_b1_crossover.txt; wall time of one call, f32):
-//   * a pageable hipMemcpyAsync pair + one kernel + hipStreamSynchronize has a floor of 34-44 us from 4096 to 16384 points --
-//     launch, two copy packets and the completion wait, not the pinning of the caller's pages: pinned copies (mode 1) save
-//     0-5 us on a complex vector and 15-40 us on the larger real / f64 ones up to 1 MiB, and LOSE from 2 MiB on, where
-//     the runtime pins the caller's pages itself and two host memcpys cost more than that (2^18 points: 120 -> 245 us);
-//   * kernels reading the stage directly (mode 2) save another 2-4 us up to 256 KiB and lose above;
-//   * no copy packet at all (mode 3) is what moves the floor: 4096 points 34 -> 21 us, convolve_vector 5001 x 5 taps
-//     44 -> 27 us, 16384 x 1024 taps 54 -> 36 us, 131072 x 1024 taps 142 -> 104 us.
-// B1_STAGE (LAB builds: BDSP_B1_STAGE overrides): 0 pageable copies (rounds 1-5), 1 pinned copies, 2 kernels read the
-// stage / copy down, 3 kernels read and write the stage.
+// Small host slices travel through a per-thread PINNED staging buffer (hipHostMalloc, grown geometrically; signals of at
+// most B1_STAGE_MAX bytes), and where the kernels allow it they are not copied by the GPU at all: the first kernel reads the
+// staging buffer over PCIe and the last one writes it.  *Measured* (tools/b1_crossover.py, profiles/r06_b1_crossover.txt; wall
+// time of one call, f32; "stage k" = LAB build with BDSP_B1_STAGE=k):
+//   * stage 0, pageable copies (rounds 1-5): a floor of 34-47 us from 4096 to 16384 points -- launch, two copy packets and the
+//     completion wait, not the pinning of the caller's pages;
+//   * stage 1, pinned copies: 0-5 us better on a complex vector, 15-40 us on real / f64 ones up to 1 MiB, and WORSE from
+//     2 MiB on, where the runtime pins the caller's pages itself and two host memcpys cost more than that (2^18 points
+//     122 -> 272 us);
+//   * stage 2, kernels read the stage, the result is copied down: another 2-7 us;
+//   * stage 3, no copy packet at all, is what moves the floor: fft 4096 points 36 -> 20 us, 8192 41 -> 26, 16384 47 -> 29,
+//     65536 81 -> 58, 131072 (1 MiB) 147 -> 137; convolve_vector 5001 x 5 taps 45 -> 29, 16384 x 1024 56 -> 39, 131072 x 1024
+//     166 -> 122; real data 131072 x 5 taps 96 -> 71.  Above 1 MiB every staged form loses to the pageable path.
+// The product: stage 3 for power-of-two and smooth (mixed-radix, up to two passes) transforms and for the fused block kernel,
+// stage 1 for the rest (chirp-z lengths, long or direct-form filters), stage 0 above B1_STAGE_MAX.
 namespace {
 constexpr size_t B1_STAGE_MAX = size_t(1) << 20;        // pinned staging up to here (bytes per call), pageable copies above
-constexpr size_t B1_ZERO_COPY_FFT_MAX = size_t(256) << 10; // power-of-two transforms read / write the stage themselves up to here
 struct B1Stage {
     char* p = nullptr;
     size_t cap = 0;
@@ -269,8 +271,14 @@ thread_local B1Stage t_b1stage;
 
 // The size policy of the B1 boundary (bdsp_hip_b1_policy_get/_set, include/basic_dsp_hip.h).  Defaults: the crossovers
 // measured on the MI355X box against one host core (profiles/r06_b1_crossover.txt); 0 = accept everything.
-constexpr size_t B1_DEFAULT_FFT_MIN_LEN_F32 = 0, B1_DEFAULT_FFT_MIN_LEN_F64 = 0;     // scalars (TODO r06 measurement)
-constexpr size_t B1_DEFAULT_CONV_MIN_WORK_F32 = 0, B1_DEFAULT_CONV_MIN_WORK_F64 = 0; // points x taps
+// profiles/r06_b1_crossover.txt, one host core against the MI355X round trip:
+//   fft: the shortest power of two whose B1 call takes at most HALF the faster CPU row's time (numpy / pocketfft; the factor
+//   of two is the allowance for rustfft's SIMD butterflies, which this image cannot run) -- f32 8192 points (27 against 92 us;
+//   4096: 21 against 23), f64 16384 points (43 against 88 us; 8192: 33 against 43);
+//   convolution: where the reference's direct form (the port's scalar loop, 0.45-0.95 ns per point and tap) ties with the
+//   round trip (26-34 us + 0.3-0.9 ns per point) -- f32 16384 points x 3-5 taps (38-56 against 36-39 us), f64 about twice that.
+constexpr size_t B1_DEFAULT_FFT_MIN_LEN_F32 = 2 * 8192, B1_DEFAULT_FFT_MIN_LEN_F64 = 2 * 16384; // scalars
+constexpr size_t B1_DEFAULT_CONV_MIN_WORK_F32 = 65536, B1_DEFAULT_CONV_MIN_WORK_F64 = 131072;   // points x taps
 constexpr int B1_POLICY_KEYS = 4;
 std::atomic<size_t> g_b1_policy[B1_POLICY_KEYS] = {
     {B1_DEFAULT_FFT_MIN_LEN_F32}, {B1_DEFAULT_FFT_MIN_LEN_F64}, {B1_DEFAULT_CONV_MIN_WORK_F32}, {B1_DEFAULT_CONV_MIN_WORK_F64}};
@@ -295,23 +303,34 @@ int b1_fft(int is_complex, T* signal, size_t len, int inverse)
     const size_t bytes = sizeof(T) * len;
     const bool pow2 = is_pow2(points);
     const int trips = pow2 ? fft_pow2_plain_trips<T>(points) : 0; // 1 = one workgroup-resident kernel
-    int mode = b1_stage_mode(bytes, pow2 && bytes <= B1_ZERO_COPY_FFT_MAX);
+    // smooth lengths (mixed radix, resident or four-step) take separate input / output pointers too; chirp-z lengths and
+    // the three-pass smooth ones work in their device buffers
+    const bool smooth = !pow2 && mr_supported<T>(points) && mr_passes<T>(points) < 3;
+    int mode = b1_stage_mode(bytes, pow2 || smooth);
     char* stage = mode ? t_b1stage.get(bytes) : nullptr;
     if (!stage) mode = 0;
-    if (mode >= 2 && !pow2) mode = 1; // only the power-of-two plans take separate input / output pointers
+    if (mode >= 2 && !(pow2 || smooth)) mode = 1;
     WsBlock a, b;
     if (mode >= 2) {
         // the first pass reads the pinned stage over PCIe; with mode 3 the last pass writes it: stage -> a [-> b] -> stage
         memcpy(stage, signal, bytes);
-        if (trips >= 2 || points > 4096) BDSP_TRY(a.alloc(bytes, s)); // (8192 f32: one kernel, but the two-pass plan is its fallback)
-        if (trips >= 3 || mode == 2) BDSP_TRY(b.alloc(bytes, s));
-        FftIo<T> io{};
-        io.n = points; io.flags = 0; io.in_scale = (T)1; io.window_id = -1; io.window_alpha = (T)0;
-        io.in_stride = points; io.out_stride = points;
-        io.in = stage;
-        io.out = mode == 3 ? (void*)stage : b.p;
-        BDSP_TRY(fft_pow2<T>(io, a.as<T>(), trips >= 3 ? b.as<T>() : nullptr, 1, inverse != 0, s));
-        if (mode == 2) BDSP_HIP_TRY(hipMemcpyAsync(stage, b.p, bytes, hipMemcpyDeviceToHost, s));
+        if (smooth) {
+            if (mode == 2 || !mr_resident<T>(points)) BDSP_TRY(a.alloc(bytes, s));
+            T* dst = mode == 3 ? (T*)stage : a.as<T>();
+            if (mode == 2 && !mr_resident<T>(points)) BDSP_TRY(b.alloc(bytes, s));
+            BDSP_TRY(mr_fft<T>((const T*)stage, dst, mode == 3 ? a.as<T>() : b.as<T>(), points, 1, inverse != 0, 0, (T)1, -1, (T)0, s));
+            if (mode == 2) BDSP_HIP_TRY(hipMemcpyAsync(stage, a.p, bytes, hipMemcpyDeviceToHost, s));
+        } else {
+            if (trips >= 2 || points > 4096) BDSP_TRY(a.alloc(bytes, s)); // (8192 f32: one kernel, but the two-pass plan is its fallback)
+            if (trips >= 3 || mode == 2) BDSP_TRY(b.alloc(bytes, s));
+            FftIo<T> io{};
+            io.n = points; io.flags = 0; io.in_scale = (T)1; io.window_id = -1; io.window_alpha = (T)0;
+            io.in_stride = points; io.out_stride = points;
+            io.in = stage;
+            io.out = mode == 3 ? (void*)stage : b.p;
+            BDSP_TRY(fft_pow2<T>(io, a.as<T>(), trips >= 3 ? b.as<T>() : nullptr, 1, inverse != 0, s));
+            if (mode == 2) BDSP_HIP_TRY(hipMemcpyAsync(stage, b.p, bytes, hipMemcpyDeviceToHost, s));
+        }
         BDSP_HIP_TRY(hipStreamSynchronize(s));
         memcpy(signal, stage, bytes);
         return BDSP_OK;
@@ -604,7 +623,7 @@ int b1_convolve(int is_complex, const T* src, size_t src_len, T* dst, size_t dst
     const size_t sbytes = sizeof(T) * src_len, ibytes = sizeof(T) * imp_len;
     const size_t ioff = (sbytes + 255) & ~(size_t)255;
     const bool block_kernel = ntaps <= FUSED_MAX_TAPS; // the fused kernel reads every input point ~1.3 times: fit for PCIe reads
-    int mode = b1_stage_mode(ioff + ibytes, block_kernel);
+    int mode = b1_stage_mode(sbytes, block_kernel); // (the limit counts the signal; the taps ride along)
     if (mode >= 2 && !block_kernel) mode = 1;
     char* stage = mode ? t_b1stage.get(mode == 3 ? 2 * ioff + ibytes + 256 : ioff + ibytes) : nullptr;
     if (!stage) mode = 0;
@@ -2655,19 +2674,20 @@ int bdsp_hip_capture_begin(void* stream)
             return BDSP_ERR_UNSUPPORTED;
         }
         BDSP_TRY(ws_capture_begin(st));
+        // the stream capture starts UNDER the lock and the bookkeeping is published only once it has: another thread's
+        // capture_abort between the two would otherwise see "open" on a stream that is not recording yet, tear the
+        // bookkeeping down, and leave the owner's stream in capture mode with nobody able to end it
+        hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed);
+        if (e != hipSuccess) {
+            ws_capture_end(st, nullptr);
+            set_last_error(hipGetErrorString(e));
+            return BDSP_ERR_HIP;
+        }
         g_capture_open = 1;
         g_capture_thread = std::this_thread::get_id();
         g_capture_stream = st;
         g_capture_plans.clear();
         g_capture_moves = t_buffer_moves;
-    }
-    hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed);
-    if (e != hipSuccess) {
-        std::lock_guard<std::mutex> lk(g_bs_mu);
-        g_capture_open = 0;
-        ws_capture_end(st, nullptr);
-        set_last_error(hipGetErrorString(e));
-        return BDSP_ERR_HIP;
     }
     return BDSP_OK;
 }

@@ -196,17 +196,22 @@ def usable_cores():
     return n
 
 
-def cpu_baseline(points, taps, sample_points, vectors=1):
-    """The oracle on the host cores, on a bounded sample of the workload (~10-20 s in all):
+def cpu_baseline(points, taps, sample_points, vectors=1, reps=3):
+    """The oracle on the host cores, on a bounded sample of the workload (~15 s in all):
       reference_schedule_1core  overlap_discard exactly as the reference schedules it (scalar head, O(N*M/2) scalar
                                 tail, blocks; convolution.rs:304-461) + the FFT, one thread = the reference's default
                                 MultiCoreSettings (threading.rs:210-217)
       fair_1core                overlap-save with every output from a block (no scalar tail) + FFT, one thread
       fair_allcores             the same with blocks / butterflies spread over all host cores (OpenMP in the oracle;
                                 the reference's `parallel()` setting would use half of them, threading.rs:220-231)
+      numpy_sanity              scipy.signal.oaconvolve + numpy.fft.fft (pocketfft) on the same sample: NOT the reference --
+                                it shows what a tuned CPU FFT does next to the port's radix-2 loop
     Headline: one `sample_points`-point prefix of the vector.  --mode c5 (vectors > 1): as many WHOLE vectors of
     `points` points as fit in `sample_points`, one after the other like the matrix crate's row loop
-    (matrix/src/lib.rs:195-208).  `value` is the all-cores figure, `cores` the threads it used."""
+    (matrix/src/lib.rs:195-208).  Every leg runs `reps` times; the rates come from the MEDIAN time of a leg, the
+    fastest repetition is reported next to it (`*_best`): the all-cores figure moved 57.9 -> 47.7 -> 42.9 Msamples/s over
+    rounds 3-5 on unchanged code -- 16 granted cores of a shared 256-thread host -- and one sample could not bound that.
+    `value` is the all-cores figure, `cores` the threads it used."""
     import numpy as np
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as orc
@@ -217,40 +222,66 @@ def cpu_baseline(points, taps, sample_points, vectors=1):
     cores = usable_cores()
     h = orc.fill_uniform(2 * taps, 201601172, -1, 1, np.float32) / np.float32(taps)
     l = orc.next_power_of_two(taps)
-    sec = {"reference_overlap_discard_1core": 0.0, "fft_1core": 0.0, "fair_overlap_save_1core": 0.0,
-           "fair_overlap_save_allcores": 0.0, "fft_allcores": 0.0}
-    for v in range(k):
-        x = orc.fill_uniform(2 * n, 201601171 + v, -10, 10, np.float32)
-        t0 = time.perf_counter()
-        code, y = orc.overlap_discard(x, h, l, fair=False)
-        t1 = time.perf_counter()
-        orc.fft(y)
-        t2 = time.perf_counter()
-        code2, y2 = orc.overlap_discard(x, h, l, fair=True)
-        t3 = time.perf_counter()
-        code3, y3 = orc.overlap_save_mt(x, h, l, cores)
-        t4 = time.perf_counter()
-        orc.fft_pow2_mt(y3, False, cores)
-        t5 = time.perf_counter()
-        assert code == 0 and code2 == 0 and code3 == 0 and np.array_equal(y2, y3)
-        for key, dt in zip(sec, (t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4)):
-            sec[key] += dt
+    legs = ("reference_overlap_discard_1core", "fft_1core", "fair_overlap_save_1core", "fair_overlap_save_allcores", "fft_allcores",
+            "numpy_oaconvolve", "numpy_fft")
+    runs = {key: [] for key in legs}
+    xs = [orc.fill_uniform(2 * n, 201601171 + v, -10, 10, np.float32) for v in range(k)]
+    try:
+        import scipy.signal as ss
+    except ImportError:
+        ss = None
+    hc = h.view(np.complex64)
+    for rep in range(max(1, reps)):
+        sec = {key: 0.0 for key in legs}
+        for x in xs:
+            t0 = time.perf_counter()
+            code, y = orc.overlap_discard(x, h, l, fair=False)
+            t1 = time.perf_counter()
+            orc.fft(y)
+            t2 = time.perf_counter()
+            code2, y2 = orc.overlap_discard(x, h, l, fair=True)
+            t3 = time.perf_counter()
+            code3, y3 = orc.overlap_save_mt(x, h, l, cores)
+            t4 = time.perf_counter()
+            orc.fft_pow2_mt(y3, False, cores)
+            t5 = time.perf_counter()
+            assert code == 0 and code2 == 0 and code3 == 0 and np.array_equal(y2, y3)
+            t6 = t7 = t5
+            if ss is not None:
+                yn = ss.oaconvolve(x.view(np.complex64), hc, "same")
+                t6 = time.perf_counter()
+                np.fft.fft(yn)
+                t7 = time.perf_counter()
+            for key, dt in zip(legs, (t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4, t6 - t5, t7 - t6)):
+                sec[key] += dt
+        for key in legs:
+            runs[key].append(sec[key])
+    med = {key: sorted(v)[len(v) // 2] for key, v in runs.items()}
+    best = {key: min(v) for key, v in runs.items()}
     tot = n * k
-    ref1 = tot / (sec["reference_overlap_discard_1core"] + sec["fft_1core"]) / 1e6
-    fair1 = tot / (sec["fair_overlap_save_1core"] + sec["fft_1core"]) / 1e6
-    fair_all = tot / (sec["fair_overlap_save_allcores"] + sec["fft_allcores"]) / 1e6
+
+    def rate(t, a, b):
+        return tot / (t[a] + t[b]) / 1e6 if t[a] + t[b] > 0 else None
     if vectors > 1:
         sample = "%d whole vectors of %d points of the batch (convolve_signal with %d taps -> FFT each), f32" % (k, n, taps)
     else:
         sample = "%d-point prefix of the workload (convolve_signal with %d taps -> FFT), f32" % (n, taps)
+    fair_all = rate(med, "fair_overlap_save_allcores", "fft_allcores")
     return {
         "value": fair_all, "unit": "Msamples/s", "cores": cores, "kind": "port",
         "sample": sample,
         "machine_logical_cores": os.cpu_count(),
-        "reference_schedule_1core_Msamples_s": ref1,
-        "fair_1core_Msamples_s": fair1,
+        "reps": max(1, reps), "statistic": "median of the repetitions (fastest repetition: *_best)",
+        "reference_schedule_1core_Msamples_s": rate(med, "reference_overlap_discard_1core", "fft_1core"),
+        "fair_1core_Msamples_s": rate(med, "fair_overlap_save_1core", "fft_1core"),
         "fair_allcores_Msamples_s": fair_all,
-        "seconds": sec,
+        "reference_schedule_1core_Msamples_s_best": rate(best, "reference_overlap_discard_1core", "fft_1core"),
+        "fair_1core_Msamples_s_best": rate(best, "fair_overlap_save_1core", "fft_1core"),
+        "fair_allcores_Msamples_s_best": rate(best, "fair_overlap_save_allcores", "fft_allcores"),
+        # pocketfft / scipy on one thread: a sanity row, not the reference and not the port
+        "numpy_sanity_Msamples_s": rate(med, "numpy_oaconvolve", "numpy_fft") if ss is not None else None,
+        "numpy_sanity": "scipy.signal.oaconvolve + numpy.fft.fft (pocketfft), library default threading -- NOT the reference",
+        "seconds": med, "seconds_runs": runs,
     }
 
 

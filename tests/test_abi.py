@@ -58,11 +58,30 @@ def test_version_and_no_gpu_reporting():
 
 
 def test_is_supported_fft_len_contract():
+    """GpuSupport::is_supported_fft_len with the B1 size policy (round 6): real input refused like ocl/mod.rs:277-281; complex
+    lengths answered 0 below the measured crossover with the caller's rustfft (the trait's own way to decline,
+    time_freq/mod.rs:41-44), 1 above it for ANY length; the thresholds are readable and settable (0 = never decline)."""
     import basic_dsp_amd as b
-    f = b.lib.bdsp_hip_is_supported_fft_len_f32
-    assert f(0, 1024) == 0        # real input refused, like ocl/mod.rs:277-281
-    assert f(1, 1) == 0 and f(1, 3) == 0
-    assert f(1, 2) == 1 and f(1, 2 * 4096) == 1 and f(1, 2 * 1000) == 1 and f(1, 2 * 12289) == 1
+    L = b._lib
+    f32, f64 = b.lib.bdsp_hip_is_supported_fft_len_f32, b.lib.bdsp_hip_is_supported_fft_len_f64
+    get, put = b.lib.bdsp_hip_b1_policy_get, b.lib.bdsp_hip_b1_policy_set
+    defaults = [get(k) for k in range(4)]
+    try:
+        # the shipped defaults: profiles/r06_b1_crossover.txt (f32 8192 points, f64 16384 points; 65 536 / 131 072 points x taps)
+        assert defaults == [2 * 8192, 2 * 16384, 65536, 131072]
+        assert f32(0, 1 << 20) == 0 and f64(0, 1 << 20) == 0                 # real input
+        assert f32(1, 2 * 8192) == 1 and f32(1, 2 * 8192 - 2) == 0 and f32(1, 2 * 5000) == 0 and f32(1, 2 * 10000) == 1
+        assert f64(1, 2 * 16384) == 1 and f64(1, 2 * 10000) == 0 and f64(1, 2 * 100003) == 1
+        assert f32(1, 2 * 12289) == 1 and f32(1, 2 * 12289 + 1) == 0         # any length above; odd scalar counts never
+        for k in range(4):
+            assert put(k, 0) == 0
+        assert f32(1, 1) == 0 and f32(1, 3) == 0
+        assert f32(1, 2) == 1 and f32(1, 2 * 4096) == 1 and f32(1, 2 * 1000) == 1 and f64(1, 2 * 7) == 1
+        assert put(L.B1_FFT_MIN_LEN_F64, 100) == 0 and get(L.B1_FFT_MIN_LEN_F64) == 100 and f64(1, 98) == 0 and f64(1, 100) == 1
+        assert put(7, 1) != 0 and get(7) == 0                               # unknown key
+    finally:
+        for k, v in enumerate(defaults):
+            put(k, v)
 
 
 def test_the_product_library_reads_no_environment_variable():

@@ -126,6 +126,13 @@ def test_cpu_baseline_fields_are_numeric():
     assert b["kind"] == "port" and b["cores"] >= 1 and b["unit"] == "Msamples/s"
     for k in ("value", "reference_schedule_1core_Msamples_s", "fair_1core_Msamples_s", "fair_allcores_Msamples_s"):
         assert isinstance(b[k], float) and b[k] > 0
+    # round 6: every leg runs three times (median -> the rates, fastest -> *_best), and a pocketfft / scipy sanity row
+    # stands next to the port ("not the reference")
+    assert b["reps"] == 3 and all(len(v) == 3 for v in b["seconds_runs"].values())
+    for k in ("reference_schedule_1core_Msamples_s", "fair_1core_Msamples_s", "fair_allcores_Msamples_s"):
+        assert b[k + "_best"] >= b[k] > 0
+    assert b["numpy_sanity_Msamples_s"] > 0 and "NOT the reference" in b["numpy_sanity"]
+    assert bench.cpu_baseline(1 << 12, 64, 1 << 12, reps=1)["reps"] == 1
     # --mode c5: whole vectors, one after the other
     b = bench.cpu_baseline(1 << 13, 64, 1 << 15, vectors=64)
     assert "4 whole vectors of 8192 points" in b["sample"] and b["value"] > 0

@@ -341,7 +341,7 @@ def test_mixed_radix_three_million_points():
 def test_mixed_radix_three_stockham_passes(n, dtype):
     """Round 5: smooth lengths whose four-step form would need tiles narrower than four columns (f64 beyond factors of 1024
     points, i.e. above 10^6; f32 beyond 2048, about 4.2M points) or has no two-factor split at all (10^7 in f64) run as
-    THREE global Stockham passes with any smooth super-radix (k_mr_gpass: n = r0 r1 r2, tiles 8 ... 16 columns wide;
+    THREE global Stockham passes with any smooth super-radix (k_mr_gpass: n = r0 r1 r2, tiles at most 8 columns wide in f32 and 4 in f64 (64-byte runs);
     the result ends in the trade buffer).  Until round 5 the chirp-z path served them at 2.6 ... 3.6 times the time and twice
     the error.  plain_fft against the oracle's f64 transform, fft -> ifft round trip with the shifts fused, and a
     Hann-windowed transform."""

@@ -424,6 +424,92 @@ def test_b1_gpu_convolve_vector(dtype):
     assert V.gpu_convolve_vector(h, x, True) == (None, None)  # declines taps longer than the signal
 
 
+def _min_time(fn, reset=None, reps=25):
+    import time
+    best = 1e9
+    for _ in range(reps):
+        if reset is not None:
+            reset()
+        t0 = time.perf_counter()
+        fn()
+        best = min(best, time.perf_counter() - t0)
+    return best
+
+
+def test_b1_size_policy_declines_small_jobs_and_matches_a_fresh_measurement():
+    """Round 6: the B1 boundary declines what the caller's CPU does faster than a host round trip -- is_supported_fft_len below
+    FFT_MIN_LEN (-> rustfft, time_freq/mod.rs:41-44), gpu_convolve_vector -> None below CONV_MIN_WORK where the reference's next
+    choice is its direct form (convolution.rs:530-541).  The shipped thresholds (profiles/r06_b1_crossover.txt) must be within a
+    factor of two of a fresh measurement on THIS box, by the rule they were set with: fft -- the shortest power of two whose B1
+    call takes at most half of numpy's (pocketfft's) time; convolution -- where the round trip ties with the oracle's scalar
+    loop on one core.  bdsp_hip_fft_* itself still transforms any length, and a declined convolution is computed once the
+    policy is lifted."""
+    import ctypes as C
+    L = bd._lib
+    get, put = bd.lib.bdsp_hip_b1_policy_get, bd.lib.bdsp_hip_b1_policy_set
+    defaults = [get(k) for k in range(4)]
+    P = lambda a: a.ctypes.data_as(C.c_void_p)
+    try:
+        # --- what is declined, what never is
+        x = orc.fill_uniform(2 * 6000, 5, -10, 10, np.float32)
+        h3 = orc.fill_uniform(2 * 3, 6, -1, 1, np.float32)
+        assert V.gpu_convolve_vector(x, h3, True) == (None, None)                      # 6000 x 3 complex taps: the scalar loop wins
+        assert V.gpu_convolve_vector(x[:11000], h3[:3], False) == (None, None)          # real data, 3 taps
+        h200 = orc.fill_uniform(2 * 200, 7, -1, 1, np.float32) / 200
+        y, rng = V.gpu_convolve_vector(x, h200, True)                                   # the reference would run overlap_discard: never declined
+        assert rng == (0, x.size) and rel_l2(y, orc.convolve_direct(x.astype(np.float64), h200.astype(np.float64), True)) < 1e-6
+        assert put(L.B1_CONV_MIN_WORK_F32, 0) == 0
+        y, rng = V.gpu_convolve_vector(x, h3, True)
+        assert rng == (0, x.size) and rel_l2(y, orc.convolve_direct(x.astype(np.float64), h3.astype(np.float64), True)) < 1e-6
+        assert bd.lib.bdsp_hip_is_supported_fft_len_f32(1, 2 * 4096) == 0
+        assert rel_l2(V.gpu_fft(x[:2 * 4096].copy()), orc.fft(x[:2 * 4096].astype(np.float64))) < 1e-6   # ... but fft() works at any length
+        # --- the thresholds against a fresh measurement
+        for k in range(4):
+            put(k, 0)
+        for dtype, sfx, key in ((np.float32, "f32", L.B1_FFT_MIN_LEN_F32), (np.float64, "f64", L.B1_FFT_MIN_LEN_F64)):
+            cdt = np.complex64 if dtype == np.float32 else np.complex128
+            fft = getattr(bd.lib, "bdsp_hip_fft_" + sfx)
+            wins = {}
+            for n in (1024, 2048, 4096, 8192, 16384, 32768, 65536, 131072):
+                x0 = orc.fill_uniform(2 * n, n, -1, 1, dtype)
+                xg = x0.copy()
+                xc, out = x0.view(cdt), np.empty(n, cdt)
+                fft(1, P(xg), xg.size, 0)
+                tg = _min_time(lambda: fft(1, P(xg), xg.size, 0), lambda: np.copyto(xg, x0))
+                tc = _min_time(lambda: np.fft.fft(xc, out=out))
+                wins[n] = tg <= 0.5 * tc
+            cross = None
+            for n in sorted(wins, reverse=True):
+                if not wins[n]:
+                    break
+                cross = n
+            assert cross is not None, (sfx, wins)
+            assert defaults[key] // 2 <= 2 * cross <= defaults[key] * 2, (sfx, "measured crossover %d points" % cross, defaults[key], wins)
+        for dtype, sfx, key in ((np.float32, "f32", L.B1_CONV_MIN_WORK_F32), (np.float64, "f64", L.B1_CONV_MIN_WORK_F64)):
+            conv = getattr(bd.lib, "bdsp_hip_convolve_vector_" + sfx)
+            oconv = orc._fn("orc_convolve_signal", dtype)
+            oconv.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.POINTER(C.c_int)]
+            oconv.restype = C.c_int
+            rs, re, path = C.c_size_t(0), C.c_size_t(0), C.c_int(0)
+            m = 4
+            h = orc.fill_uniform(2 * m, 9, -1, 1, dtype)
+            cross = None
+            for n in (4096, 8192, 16384, 32768, 65536, 131072):
+                x = orc.fill_uniform(2 * n, n + 1, -1, 1, dtype)
+                y = np.zeros_like(x)
+                assert conv(1, P(x), x.size, P(y), y.size, P(h), h.size, C.byref(rs), C.byref(re)) == 1
+                tg = _min_time(lambda: conv(1, P(x), x.size, P(y), y.size, P(h), h.size, C.byref(rs), C.byref(re)))
+                tc = _min_time(lambda: oconv(P(x), x.size, P(h), h.size, 1, P(y), C.byref(path)), reps=10)
+                assert path.value == 4  # the reference's scalar loop
+                if tg <= tc and cross is None:
+                    cross = n * m
+            assert cross is not None
+            assert defaults[key] // 2 <= cross <= defaults[key] * 2, (sfx, "measured crossover %d points x taps" % cross, defaults[key])
+    finally:
+        for k, v in enumerate(defaults):
+            put(k, v)
+
+
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 @pytest.mark.parametrize("n,m", [(20000, 100), (50000, 1024), (12345, 17)])
 def test_b1_overlap_discard_drop_in(n, m, dtype):
@@ -518,6 +604,50 @@ def test_interpolatef_fractional_factor_kernel_singularities_and_fallback(cplx, 
         # (f32: the reference -- and the oracle -- take sin(pi * j) of a ROUNDED product; at |j| ~ 3000 that argument is off by
         # 1e-4 rad, which the kernel's exact sinpi does not reproduce: 6201 such taps add up to a few 1e-6 of the result)
         assert rel_l2(v.data(), ref) < (2e-5 if dtype == np.float32 else 1e-12), (fid, big, rel_l2(v.data(), ref))
+
+
+@pytest.mark.parametrize("cplx", [True, False])
+def test_interpolatef_fractional_factor_packed_f32_kernel(cplx):
+    """Round 6: k_interp_frac_pk, the f32 fractional path with two taps per packed instruction.  Its three shortcuts each get
+    the case that would break them: (a) the per-launch mask of tap pairs that may hold j == 0 or a tap near / at the raised
+    cosine's second singularity -- delays that move those taps to other pairs, roll-offs whose near range spans many taps (0.02)
+    or none; (b) the no-wrap fast path -- a vector so short that most waves cross its end, and the 127-tap limit of the mask
+    (conv_len 63 packed, 64 the round-4 kernel); (c) z * (w, w) instead of the reference's spelled-out complex product -- inf and
+    NaN in the data must reach exactly the outputs and components they reach in the oracle (interpolation.rs:92-131)."""
+    e = 2 if cplx else 1
+    dtype, tol = np.float32, 2e-6
+    x = orc.fill_uniform(e * 5000, 201606001, -10, 10, dtype)
+    for fid, rolloff, factor, delay, conv_len in [(1, 0.35, 2.5, 7.25, 12), (1, 0.35, 2.5, -5.5, 12), (1, 0.02, 2.5, 0.0, 30), (1, 0.9, 1.7, 0.1, 9),
+                                                  (1, 0.35, 1.088, 0.0, 63), (1, 0.35, 1.088, 0.0, 64), (0, 0.0, 2.5, 11.0, 12), (0, 0.0, 0.75, 0.5, 63),
+                                                  (1, 0.25, 0.6, 2.0, 1), (0, 0.0, 3.3, 0.0, 0)]:
+        v = DspVec(x, is_complex=cplx, delta=1.0)
+        assert v.interpolatef(fid, factor, delay, conv_len, rolloff) == 0
+        with orc.exact_weights():
+            ref, path = orc.interpolatef(x, cplx, fid, rolloff, dtype(factor), delay, conv_len)
+        assert path == 0 and len(v) == ref.size
+        assert rel_l2(v.data(), ref) < tol, (fid, rolloff, factor, delay, conv_len, rel_l2(v.data(), ref))
+    # a short vector: 300 points, 81 taps -- most outputs read across the end of the vector
+    xs = orc.fill_uniform(e * 300, 201606002, -10, 10, dtype)
+    for fid, rolloff in [(0, 0.0), (1, 0.35)]:
+        v = DspVec(xs, is_complex=cplx, delta=1.0)
+        assert v.interpolatef(fid, 2.5, 0.3, 40, rolloff) == 0
+        ref, path = orc.interpolatef(xs, cplx, fid, rolloff, dtype(2.5), 0.3, 40)
+        assert path == 0 and rel_l2(v.data(), ref) < tol
+    # inf / NaN in the data
+    xn = x.copy()
+    xn[e * 1000] = np.inf
+    xn[e * 2000 + (e - 1)] = np.nan
+    xn[e * 3000] = -np.inf
+    v = DspVec(xn, is_complex=cplx, delta=1.0)
+    assert v.interpolatef(1, 2.5, 0.0, 12, 0.35) == 0
+    with np.errstate(all="ignore"):
+        ref, _ = orc.interpolatef(xn, cplx, 1, 0.35, dtype(2.5), 0.0, 12)
+    got = v.data()
+    # (WHICH non-finite value an output holds is not compared: on outputs whose tap arguments are integers the kernel's exact sinpi
+    # makes the weights exactly 0 where the reference's sin(pi * j) of a rounded product leaves 1e-8 -- inf * 0 is NaN, inf * 1e-8 inf)
+    assert np.array_equal(np.isfinite(got), np.isfinite(ref))
+    fin = np.isfinite(ref)
+    assert 0 < np.count_nonzero(~fin) < 400 and rel_l2(got[fin], ref[fin]) < tol
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
@@ -1573,6 +1703,46 @@ def test_mixed_radix_fft_lengths_and_options(dtype):
         got = m.data()
         for k in (0, rows // 2, rows - 1):
             assert rel_l2(got[k], orc.fft(xs[k].astype(np.float64))) < tol, (rows, n, k)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_register_resident_three_stage_batches(dtype):
+    """Round 6: k_mr_reg3 -- plain batched transforms of n = R0 R1 R2 (1000 = 10 10 10, 360 = 10 6 6, 2000 = 20 10 10, 3600 = 16 15
+    15 ...) in registers, persistent workgroups, two LDS exchanges.  Batches of a thousand or two rows (a ragged count, so that
+    the last workgroup's second transform is empty), forward and inverse, every built length; rows against the f64
+    oracle, and the whole batch against the same rows transformed ONE AT A TIME (the general kernel k_mr_wg), which pins every row
+    and the row order.  Matches time_freq/mod.rs:47-58 (any length)."""
+    tol = 1e-6 if dtype == np.float32 else 1e-12
+    # every built length: the table of basic_dsp_amd/csrc/mixed_radix_reg3.h (tools/gen_reg3_table.py), restated
+    import itertools
+    best = {}
+    for t in itertools.combinations_with_replacement([4, 5, 6, 8, 9, 10, 12, 15, 16, 20, 25], 3):
+        n = t[0] * t[1] * t[2]
+        if n > 4096 or n < 300 or n & (n - 1) == 0 or n // min(t) > 256:
+            continue
+        if n not in best or (min(t), -max(t)) > best[n]:
+            best[n] = (min(t), -max(t))
+    lengths = [n for n in sorted(best) if dtype == np.float32 or n <= 2048]
+    assert len(lengths) == (62 if dtype == np.float32 else 50) and 1000 in lengths and 360 in lengths and 2000 in lengths
+    for n in lengths:
+        rows = 2051 if n <= 1200 else 1027
+        xs = orc.fill_uniform(2 * n * rows, 600 + n, -10, 10, dtype).reshape(rows, 2 * n)
+        m = DspMat(xs, is_complex=True)
+        assert m.plain_fft() == 0
+        got = m.data()
+        for k in (0, 1, rows // 2, rows - 2, rows - 1):
+            assert rel_l2(got[k], orc.fft(xs[k].astype(np.float64))) < tol, (n, k, rel_l2(got[k], orc.fft(xs[k].astype(np.float64))))
+        # REAL rows take the general kernel k_mr_wg (real input is a fused option); the same rows as complex data with zero
+        # imaginary parts take k_mr_reg3: same values to rounding, row for row -- which pins every row and the row order
+        xr = np.ascontiguousarray(xs[:, :n])
+        zc = np.zeros_like(xs)
+        zc[:, 0::2] = xr
+        a, b = DspMat(zc, is_complex=True), DspMat(xr, is_complex=False)
+        assert a.plain_fft() == 0 and b.plain_fft() == 0
+        assert rel_l2(a.data().ravel(), b.data().ravel()) < 4 * tol, n
+        assert m.plain_ifft() == 0
+        back = m.data() / n
+        assert rel_l2(back.ravel(), xs.ravel()) < 4 * tol, (n, "round trip")
 
 
 def test_b1_convolve_vector_from_concurrent_threads():

@@ -9,11 +9,98 @@ import basic_dsp_amd as bd
 from basic_dsp_amd._lib import FFT_SHIFT_OUT, FFT_MAGNITUDE
 lib = bd.lib
 dev = torch.device("cuda", 0)
-sp = bd._lib.torch_stream_arg()
+sp = bd._lib.torch_stream_arg() if "--cpu-only" not in sys.argv else None
 flag = C.c_int(0)
 PEAK = 8000.0
 
 QUICK = "--quick" in sys.argv  # a few launches per config only: for the rocprofv3 --pmc passes (tools/profile_round.sh)
+NO_CPU = QUICK or "--no-cpu" in sys.argv  # the CPU column (round 6) costs ~1 minute of host time: not under the profiler
+
+
+def cpu_rows():
+    """The CPU baseline beside every BASELINE config, on THIS box's host cores, in this run:
+      reference_1core  the oracle (kind "port": the C restatement of the reference algorithm, tests/oracle_lib.py) on one
+                       thread, in the reference's own schedule -- separate passes, plan per call; one thread is the
+                       reference's default MultiCoreSettings (multicore_support/threading.rs:210-217)
+      fair_allcores    the same work with the FFT butterflies / convolution blocks spread over all granted cores (OpenMP in
+                       the oracle; `parallel()` would use half of them, threading.rs:220-231); null where the oracle has no
+                       threaded form of the operation
+      numpy_sanity     numpy / scipy (pocketfft) doing the same job: NOT the reference and not the port -- it shows that the
+                       port's radix-2 loop is not a straw man
+    Every leg runs three times: `us` is the median, `us_min` the fastest.  Units per second use the config's own unit."""
+    import time as _t
+    import numpy as np
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+    import oracle_lib as orc
+    import bench
+    import scipy.signal as ss
+    cores = bench.usable_cores()
+
+    def t3(fn, reps=3):
+        v = []
+        for _ in range(reps):
+            t0 = _t.perf_counter(); fn(); v.append((_t.perf_counter() - t0) * 1e6)
+        v.sort()
+        return {"us": round(v[len(v) // 2], 1), "us_min": round(v[0], 1)}
+
+    def obj(units, unit_name, ref, allc, npy, sample, scale=1.0):
+        """scale: the sample is 1/scale of the config (a prefix): microseconds are scaled up to the whole config"""
+        def leg(d):
+            if d is None:
+                return None
+            us = d["us"] * scale
+            return {"us": round(us, 1), "us_min": round(d["us_min"] * scale, 1), "M%s_per_s" % unit_name: round(units / us, 3)}
+        return {"kind": "port", "cores": cores, "reference_1core": leg(ref), "fair_allcores": leg(allc),
+                "numpy_sanity": dict(leg(npy), note="numpy / scipy (pocketfft), NOT the reference") if npy else None,
+                "sample": sample, "reps": 3, "statistic": "median (us) and fastest (us_min) of three runs"}
+    rows = {}
+    # C1: scale() then offset(), two passes over 65 536 real f32 (general/elementary.rs:283-640)
+    x = orc.fill_uniform(65536, 201601171, -10, 10, np.float32)
+    rows["C1 "] = obj(65536, "samples", t3(lambda: orc.real_offset(orc.real_scale(x, 2.5), -1.25), 5), None,
+                      t3(lambda: x * np.float32(2.5) + np.float32(-1.25), 5), "the whole config")
+    # C2: fft -> magnitude, 1M complex f32, two passes (time_freq/time_to_freq.rs:126-144, complex_to_real.rs:365-478)
+    n = 1 << 20
+    x = orc.fill_uniform(2 * n, 201601172, -10, 10, np.float32)
+    xc = x.view(np.complex64)
+    rows["C2 "] = obj(n, "points", t3(lambda: orc.magnitude(orc.fft(x))), t3(lambda: orc.magnitude(orc.fft_pow2_mt(x, False, cores))),
+                      t3(lambda: np.abs(np.fft.fft(xc))), "the whole config")
+    # C3 / FFT16M: bench.py's CPU baseline on a 2^22-point prefix of the 16M-point vector, split into its two halves
+    n, m, sp_ = 1 << 24, 1024, 1 << 22
+    b = bench.cpu_baseline(n, m, sp_)
+    def mk(b_, *legs):
+        return {"us": sum(b_["seconds"][l] for l in legs) * 1e6, "us_min": sum(min(b_["seconds_runs"][l]) for l in legs) * 1e6}
+    rows["C3 complex f32 16M"] = obj(n, "samples", mk(b, "reference_overlap_discard_1core"), mk(b, "fair_overlap_save_allcores"), mk(b, "numpy_oaconvolve"),
+                                     "%d-point prefix, scaled to 16M points; reference_1core = the reference's overlap_discard schedule incl. its scalar tail, "
+                                     "fair_allcores = tail-free overlap-save on all cores" % sp_, n / sp_)
+    rows["C3 as ONE"] = rows["C3 complex f32 16M"]
+    rows["FFT complex f32 16M"] = obj(n, "points", mk(b, "fft_1core"), mk(b, "fft_allcores"), mk(b, "numpy_fft"),
+                                      "%d-point transform, scaled to 16M points by N log N" % sp_, n / sp_ * 24.0 / 22.0)
+    # C4a: apply_window(Hann) -> fft -> swap_halves, three separate passes like time_to_freq.rs:167-175; 4M complex f64
+    n = 1 << 22
+    x = orc.fill_uniform(2 * n, 201601174, -10, 10, np.float64)
+    xc = x.view(np.complex128)
+    rows["C4a "] = obj(n, "points", t3(lambda: orc.swap_halves(orc.fft(orc.apply_window(x, True, 4, 0.5)), True)),
+                       t3(lambda: orc.swap_halves(orc.fft_pow2_mt(orc.apply_window(x, True, 4, 0.5), False, cores), True)),
+                       t3(lambda: np.fft.fftshift(np.fft.fft(xc * np.hanning(n)))), "the whole config")
+    # C4b: interpolatef(RC 0.35, x4, conv_len 12) on a 2^18-point prefix, scaled (time_freq/interpolation.rs:387-482)
+    pre = 1 << 18
+    xp = x[:2 * pre].copy()
+    taps_rc = np.array([orc.conv_time(1, 0.35, j / 4.0, np.float64) for j in range(-12 * 4, 12 * 4 + 1)])
+    rows["C4b "] = obj(n, "input_points", t3(lambda: orc.interpolatef(xp, True, 1, 0.35, 4.0, 0.0, 12)), None,
+                       t3(lambda: ss.upfirdn(taps_rc, xp.view(np.complex128), up=4)),
+                       "%d-point prefix, scaled to 4M points" % pre, n / pre)
+    # C5: 8 whole vectors of the 64 per GPU, one after the other like the matrix crate's row loop, scaled to 64
+    b = bench.cpu_baseline(1 << 20, 1024, 8 << 20, vectors=64)
+    rows["C5/GPU"] = obj(64 << 20, "samples", mk(b, "reference_overlap_discard_1core", "fft_1core"), mk(b, "fair_overlap_save_allcores", "fft_allcores"),
+                         mk(b, "numpy_oaconvolve", "numpy_fft"), "8 whole vectors of the 64, scaled; convolve_signal -> fft each", 8.0)
+    return rows
+
+
+CPU = {} if NO_CPU else cpu_rows()
+if "--cpu-only" in sys.argv:  # (runs without a GPU)
+    for k_, v_ in CPU.items():
+        print(json.dumps({"config": k_.strip(), "cpu_baseline": v_}))
+    sys.exit(0)
 
 def timeit(fn, iters=20):
     # untimed pre-warm: the clock needs tens of milliseconds of load to settle (see bench.py)
@@ -109,7 +196,10 @@ def report(name, us, units, bytes_per_unit, unit_name, us_hot=None):
     if us_hot is not None:
         row["us_input_in_cache"] = round(us_hot, 2)
         row["roofline_frac_input_in_cache"] = round(units * bytes_per_unit / us_hot / 1e3 / PEAK, 4)
-    print(json.dumps(row))
+    for prefix, cb in CPU.items():
+        if name.startswith(prefix):
+            row["cpu_baseline"] = cb
+    print(json.dumps(row), flush=True)
 
 def rnd(n, dt, k=3):
     return [torch.rand(n, device=dev, dtype=dt) * 20 - 10 for _ in range(k)]
