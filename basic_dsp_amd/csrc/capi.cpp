@@ -273,12 +273,13 @@ thread_local B1Stage t_b1stage;
 // measured on the MI355X box against one host core (profiles/r06_b1_crossover.txt); 0 = accept everything.
 // profiles/r06_b1_crossover.txt, one host core against the MI355X round trip:
 //   fft: the shortest power of two whose B1 call takes at most HALF the faster CPU row's time (numpy / pocketfft; the factor
-//   of two is the allowance for rustfft's SIMD butterflies, which this image cannot run) -- f32 8192 points (27 against 92 us;
-//   4096: 21 against 23), f64 16384 points (43 against 88 us; 8192: 33 against 43);
-//   convolution: where the reference's direct form (the port's scalar loop, 0.45-0.95 ns per point and tap) ties with the
-//   round trip (26-34 us + 0.3-0.9 ns per point) -- f32 16384 points x 3-5 taps (38-56 against 36-39 us), f64 about twice that.
+//   of two is the allowance for rustfft's SIMD butterflies, which this image cannot run) -- f32 8192 points (25.5 against 92 us;
+//   4096: 19.9 against 22.8), f64 16384 points (38 against 88 us; 8192: 30 against 43.5);
+//   convolution: where the reference's direct form (the port's scalar loop: 0.45-0.95 ns per point and tap) ties with the round
+//   trip (27-34 us + 0.3-0.8 ns per point) -- complex f32 16384 points x 3 taps (37.6 against 36.2 us) or 8000 x 5, real f32
+//   20000 x 3; complex f64 21000 x 3 (work 63k), real f64 45000 x 3 (135k): one figure per precision, between the two.
 constexpr size_t B1_DEFAULT_FFT_MIN_LEN_F32 = 2 * 8192, B1_DEFAULT_FFT_MIN_LEN_F64 = 2 * 16384; // scalars
-constexpr size_t B1_DEFAULT_CONV_MIN_WORK_F32 = 65536, B1_DEFAULT_CONV_MIN_WORK_F64 = 131072;   // points x taps
+constexpr size_t B1_DEFAULT_CONV_MIN_WORK_F32 = 65536, B1_DEFAULT_CONV_MIN_WORK_F64 = 98304;    // points x taps
 constexpr int B1_POLICY_KEYS = 4;
 std::atomic<size_t> g_b1_policy[B1_POLICY_KEYS] = {
     {B1_DEFAULT_FFT_MIN_LEN_F32}, {B1_DEFAULT_FFT_MIN_LEN_F64}, {B1_DEFAULT_CONV_MIN_WORK_F32}, {B1_DEFAULT_CONV_MIN_WORK_F64}};

@@ -1,4 +1,6 @@
-// conv_v2.hip -- the fused overlap-save block kernel for complex f32 vectors, second generation.
+// conv_v2_impl.h -- the fused overlap-save block kernel, second generation; included by conv_v2_f32.hip and conv_v2_f64.hip with
+// BDSP_CONV_T set (round 6: one code object per precision -- a process's first f32 convolve_signal no longer loads the f64
+// instantiations, 3.5 MB of code for the two together).
 //
 // Same mathematics as conv.hip's k_overlap_save (reference: overlap_discard, convolution.rs:304-461; result
 // y[i] = sum_k x[(i + ceil(M/2) - 1 - k) mod N] h[k], time_freq/mod.rs:455-473): per 4096-point block
@@ -537,6 +539,11 @@ static bool conv_v2_streams_result(size_t points, size_t batch)
     return sizeof(T) == 8 && (double)points * (double)batch * 2.0 * sizeof(T) > 192.0 * 1024 * 1024;
 }
 
+// Per-CALL override of the dispatch-group shares (bdsp_hip_dev_convolve_ex sets it around its own launch): the
+// calling thread's, so that no other thread's launches see it and the pair can never be read torn.
+extern thread_local int t_conv_share_a, t_conv_share_b;
+#ifdef BDSP_CONV_F32_TU // (the precision-independent pieces live in the f32 TU)
+thread_local int t_conv_share_a = -1, t_conv_share_b = -1;
 // block step of the second-generation kernel: V = 4096 - 256 ceil((M-1)/256)
 size_t conv_v2_block_step(size_t taps)
 {
@@ -544,13 +551,10 @@ size_t conv_v2_block_step(size_t taps)
     return (size_t)L2 - 256 * r0;
 }
 
-// Per-CALL override of the dispatch-group shares (bdsp_hip_dev_convolve_ex sets it around its own launch): the
-// calling thread's, so that no other thread's launches see it and the pair can never be read torn.
-static thread_local int t_share_a = -1, t_share_b = -1;
 void conv_v2_set_shares(int first_pct, int second_pct)
 {
-    t_share_a = first_pct;
-    t_share_b = second_pct;
+    t_conv_share_a = first_pct;
+    t_conv_share_b = second_pct;
 }
 
 bool conv_v2_applies(size_t points, size_t taps)
@@ -558,6 +562,7 @@ bool conv_v2_applies(size_t points, size_t taps)
     static const bool off = lab_flag("BDSP_CONV_V1");
     return !off && taps >= 1 && taps - 1 <= 3 * (size_t)L2 / 4 && points >= 1 && points < (size_t(1) << 31);
 }
+#endif
 
 // Blocks [first_block, first_block + nblocks) (nblocks = 0: all from first_block on) of every vector of the batch.
 // real: `points` REAL samples per vector and real taps (hs_is_taps); blocks are then PAIRS of real blocks.
@@ -621,7 +626,7 @@ int conv_v2_run(const T* in, T* out, size_t points, size_t batch, const T* hs, s
     // 21.3); two groups: ~55 % / rest (12 of 21.3 rounds measured best for two workgroups per CU)
     const unsigned long long rounds = (interior + gs - 1) / gs;
     // (bdsp_hip_dev_convolve_ex overrides the percentages for its own call: the guard test times equal shares against these)
-    const int sa = t_share_a, sb = t_share_b;
+    const int sa = t_conv_share_a, sb = t_conv_share_b;
     const unsigned long long pa = sa > 0 ? (unsigned long long)sa : (GROUPS == 3 ? 43 : 55);
     const unsigned long long pb = GROUPS == 3 ? (sa > 0 ? (unsigned long long)sb : 37) : 0;
     unsigned long long ra = (rounds * pa + 50) / 100, rb = (rounds * pb + 50) / 100;
@@ -656,7 +661,6 @@ int conv_v2_run(const T* in, T* out, size_t points, size_t batch, const T* hs, s
     return BDSP_ERR_UNSUPPORTED;
 }
 
-template int conv_v2_run<float>(const float*, float*, size_t, size_t, const float*, size_t, size_t, size_t, bool, hipStream_t, bool);
-template int conv_v2_run<double>(const double*, double*, size_t, size_t, const double*, size_t, size_t, size_t, bool, hipStream_t, bool);
+template int conv_v2_run<BDSP_CONV_T>(const BDSP_CONV_T*, BDSP_CONV_T*, size_t, size_t, const BDSP_CONV_T*, size_t, size_t, size_t, bool, hipStream_t, bool);
 
 } // namespace bdsp

@@ -1,4 +1,5 @@
-// f32 instantiation of the FFT kernels (split from f64 so the two compile in parallel)
+// f32 FFT kernels, the "plain" unit (fft_impl.h, BDSP_FFT_PART): plan selection + every kernel a plain transform launches
 #define BDSP_FFT_T float
 #define BDSP_FFT_F32_TU 1
+#define BDSP_FFT_PART 1
 #include "fft_impl.h"

@@ -23,7 +23,25 @@
 #include "bdsp_internal.h"
 #include "dsp_funcs.h"
 
+// BDSP_FFT_PART (round 6).  A process's first transform loads the code object of the translation unit its first kernel lives
+// in (HIP loads per unit: *measured*, tools/first_call_probe.py -- 4.2 ms for the 2.7 MB of all f32 kernels), and two thirds
+// of that code serves fused options and generic I/O that a plain transform never launches.  So each precision is TWO units:
+//   1  "plain" (fft_f32.hip / fft_f64.hip): plan selection, fft_pow2, and every kernel a plain transform can launch -- the
+//      SIMPLE pass instantiations, k_fft_wg without generic I/O, k_fft_wg_batch, k_fft_wg4, k_fft_tiny;
+//   2  "options" (fft_f32_opts.hip / fft_f64_opts.hip): the pass kernels with fused shift / scale / window / real input /
+//      magnitude / real-part output and the generic-I/O (GEN) kernels, reached through launch_pass_opts_rp / launch_wg_gen.
+//   0  everything in one unit.
+#ifndef BDSP_FFT_PART
+#define BDSP_FFT_PART 0
+#endif
+
 namespace bdsp {
+
+template <typename T>
+int launch_pass_opts_rp(int rp, int w, const FftIo<T>& io, const cpx<T>* src, cpx<T>* dst, size_t n, size_t nsg, size_t batch,
+                        bool inverse, bool first, bool last, hipStream_t s, int tl, int aux);
+template <typename T>
+int launch_wg_gen(int n, const FftIo<T>& io, size_t batch, bool inverse, hipStream_t s);
 
 // ------------------------------------------------------------------------------ fused I/O
 template <typename T>
@@ -937,7 +955,10 @@ static int launch_wg(const FftIo<T>& io, size_t batch, bool inverse, hipStream_t
     constexpr bool WGBATCH = N >= 1024 && sizeof(T) == 4;
     const bool wgbatch_on = true;
 #endif
-    if constexpr (WGBATCH) {
+#if BDSP_FFT_PART == 1
+    if (gen) return launch_wg_gen<T>(N, io, batch, inverse, s); // the options unit
+#endif
+    if constexpr (WGBATCH && BDSP_FFT_PART != 2) {
         // enough transforms to keep persistent workgroups busy for several rounds
         // resident workgroups per CU as the runtime computes it (registers and LDS), once per kernel
         size_t lds2 = lds + 16 * 17 * sizeof(cpx<T>);
@@ -968,8 +989,15 @@ static int launch_wg(const FftIo<T>& io, size_t batch, bool inverse, hipStream_t
         hipLaunchKernelGGL((k_fft_wg<T, N, DIRV, GENV>), dim3(grid), dim3(256), lds, s, io, wtab,  \
                            batch);                                                                 \
     } while (0)
+#if BDSP_FFT_PART == 1
+    if (inverse) BDSP_WG(1, false); else BDSP_WG(-1, false);
+#elif BDSP_FFT_PART == 2
+    if (!gen) { set_last_error("plain transform in the options unit"); return BDSP_ERR_UNSUPPORTED; }
+    if (inverse) BDSP_WG(1, true); else BDSP_WG(-1, true);
+#else
     if (inverse) { if (gen) BDSP_WG(1, true); else BDSP_WG(1, false); }
     else { if (gen) BDSP_WG(-1, true); else BDSP_WG(-1, false); }
+#endif
 #undef BDSP_WG
     BDSP_LAUNCH_CHECK();
     return BDSP_OK;
@@ -1020,6 +1048,9 @@ static int launch_pass(const FftIo<T>& io_in, const cpx<T>* src, cpx<T>* dst, si
                        size_t batch, bool inverse, bool first, bool last, hipStream_t s, int tl = 0, int aux = 0)
 {
     FftIo<T> io = io_in;
+    const cpx<T>* const src0 = src;
+    cpx<T>* const dst0 = dst;
+    (void)src0; (void)dst0; // (used by the plain unit only, BDSP_FFT_PART == 1)
     if ((first || last) && (io.window_id == 1 || io.window_id == 2) && n > 1) {
         // the window constants of k_fft_pass: cos / sin of q * 2 pi (n/16) / (n-1), q = 0..7, from double precision
         const double step = 2.0 * (double)(n / 16) / ((double)n - 1.0); // in units of pi
@@ -1038,11 +1069,15 @@ static int launch_pass(const FftIo<T>& io_in, const cpx<T>* src, cpx<T>* dst, si
     // (triangular / Blackman-Harris on a split-exchange f64 tile: the kernel instantiated for that window, see k_fft_pass)
     const bool win_here = io.window_id >= 0 && ((first && !(io.flags & FFT_WINDOW_OUT_DIV)) || (last && (io.flags & FFT_WINDOW_OUT_DIV)));
     const int win_fixed = (!gen && win_here && pass_split_exchange<T, RP, W, false>() && (io.window_id == 0 || io.window_id == 2)) ? io.window_id : -1;
+    (void)win_fixed; // (the plain unit sends every windowed pass to the options unit)
     if (first && !gen) src = reinterpret_cast<const cpx<T>*>(io.in);
     if (last && !gen) dst = reinterpret_cast<cpx<T>*>(io.out);
     // plain first / last pass?  (then no option is looked at inside the kernel)
     const bool simple = !gen && (rowmap ? ((io.flags & (FFT_IN_REAL | BDSP_FFT_SHIFT_IN)) == 0 && io.in_scale == (T)1 && io.window_id < 0)
                                         : (!last || (io.flags & (BDSP_FFT_SHIFT_OUT | BDSP_FFT_MAGNITUDE | FFT_OUT_REAL | FFT_WINDOW_OUT_DIV)) == 0));
+#if BDSP_FFT_PART == 1
+    if (!simple) return launch_pass_opts_rp<T>(RP, W, io_in, src0, dst0, n, nsg, batch, inverse, first, last, s, tl, aux); // the options unit
+#endif
     // Non-temporal loads in the FIRST pass of an f64 transform whose tile reads whole 128-byte lines (W >= 8: the 3-pass plans'
     // 256 x 16 / 128 x 32 tiles, the 1024 x 8 / 512 x 8 tiles of batches and of 2^18 points).  *Measured* (round 5, LAB build with
     // -DBDSP_FFT_NTLOAD=2, cold / input in the caches, profiles/r05_plan_probe_valid.txt runs 4-5): 16 x 2^20 214 -> 185 / 205 -> 185 us,
@@ -1068,10 +1103,18 @@ static int launch_pass(const FftIo<T>& io_in, const cpx<T>* src, cpx<T>* dst, si
         }                                                                                          \
         BDSP_PASS_K(DIRV, RM, GENV, SV, TLV, WINV, false);                                         \
     } while (0)
+#if BDSP_FFT_PART == 1
+#define BDSP_PASS_V(DIRV, RM, TLV) BDSP_PASS(DIRV, RM, false, true, TLV, -1) /* (everything else went to the options unit above) */
+#else
+#if BDSP_FFT_PART == 2
+#define BDSP_PASS_SIMPLE(DIRV, RM, TLV) do { set_last_error("plain pass in the options unit"); return BDSP_ERR_UNSUPPORTED; } while (0)
+#else
+#define BDSP_PASS_SIMPLE(DIRV, RM, TLV) BDSP_PASS(DIRV, RM, false, true, TLV, -1)
+#endif
 #define BDSP_PASS_V(DIRV, RM, TLV)                                                                 \
     do {                                                                                           \
         if (gen) BDSP_PASS(DIRV, RM, true, false, TLV, -1);                                        \
-        else if (simple) BDSP_PASS(DIRV, RM, false, true, TLV, -1);                                \
+        else if (simple) BDSP_PASS_SIMPLE(DIRV, RM, TLV);                                          \
         else {                                                                                     \
             if constexpr (pass_split_exchange<T, RP, W, false>() && TLV == 0) {                    \
                 if (win_fixed == 0) { BDSP_PASS(DIRV, RM, false, false, TLV, 0); break; }          \
@@ -1080,6 +1123,7 @@ static int launch_pass(const FftIo<T>& io_in, const cpx<T>* src, cpx<T>* dst, si
             BDSP_PASS(DIRV, RM, false, false, TLV, -1);                                            \
         }                                                                                          \
     } while (0)
+#endif
 #define BDSP_PASS_D(DIRV)                                                                          \
     do {                                                                                           \
         if constexpr (pass_tiled_pair<RP>()) {                                                     \
@@ -1095,6 +1139,9 @@ static int launch_pass(const FftIo<T>& io_in, const cpx<T>* src, cpx<T>* dst, si
 #undef BDSP_PASS_V
 #undef BDSP_PASS
 #undef BDSP_PASS_K
+#if BDSP_FFT_PART != 1
+#undef BDSP_PASS_SIMPLE
+#endif
     BDSP_LAUNCH_CHECK();
     return BDSP_OK;
 }
@@ -1309,8 +1356,41 @@ int fft_pow2_plain_trips(size_t n)
     return wg4_serves<T>(n) ? 1 : fft_pow2_passes<T>(n);
 }
 
+#if BDSP_FFT_PART != 1
+// the options unit's two entry points (with BDSP_FFT_PART == 0 they are defined here too and simply never called)
+template <typename T>
+int launch_pass_opts_rp(int rp, int w, const FftIo<T>& io, const cpx<T>* src, cpx<T>* dst, size_t n, size_t nsg, size_t batch,
+                        bool inverse, bool first, bool last, hipStream_t s, int tl, int aux)
+{
+    return launch_pass_rp<T>(rp, w, io, src, dst, n, nsg, batch, inverse, first, last, s, tl, aux);
+}
+template <typename T>
+int launch_wg_gen(int n, const FftIo<T>& io, size_t batch, bool inverse, hipStream_t s)
+{
+    switch (n) {
+    case 16: return launch_wg<T, 16>(io, batch, inverse, s);
+    case 32: return launch_wg<T, 32>(io, batch, inverse, s);
+    case 64: return launch_wg<T, 64>(io, batch, inverse, s);
+    case 128: return launch_wg<T, 128>(io, batch, inverse, s);
+    case 256: return launch_wg<T, 256>(io, batch, inverse, s);
+    case 512: return launch_wg<T, 512>(io, batch, inverse, s);
+    case 1024: return launch_wg<T, 1024>(io, batch, inverse, s);
+    case 2048: return launch_wg<T, 2048>(io, batch, inverse, s);
+    case 4096: return launch_wg<T, 4096>(io, batch, inverse, s);
+    default: break;
+    }
+    set_last_error("launch_wg_gen: unsupported length");
+    return BDSP_ERR_UNSUPPORTED;
+}
+#endif
+#if BDSP_FFT_PART == 2
+template int launch_pass_opts_rp<BDSP_FFT_T>(int, int, const FftIo<BDSP_FFT_T>&, const cpx<BDSP_FFT_T>*, cpx<BDSP_FFT_T>*, size_t, size_t, size_t, bool, bool,
+                                             bool, hipStream_t, int, int);
+template int launch_wg_gen<BDSP_FFT_T>(int, const FftIo<BDSP_FFT_T>&, size_t, bool, hipStream_t);
+#else
 template int fft_pow2<BDSP_FFT_T>(const FftIo<BDSP_FFT_T>&, BDSP_FFT_T*, BDSP_FFT_T*, size_t, bool, hipStream_t);
 template int fft_pow2_passes<BDSP_FFT_T>(size_t);
 template int fft_pow2_plain_trips<BDSP_FFT_T>(size_t);
+#endif
 
 } // namespace bdsp

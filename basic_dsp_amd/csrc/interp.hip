@@ -444,7 +444,8 @@ __global__ __launch_bounds__(256) void k_interp_scalar_v2(const T* __restrict__ 
     }
 }
 
-// Round 6: the f32 fractional path with TWO TAPS PER PACKED INSTRUCTION (v_pk_mul_f32 / v_pk_add_f32 on (tap k, tap k+1)).
+// Round 6: the fractional path with TWO TAPS PER PACKED INSTRUCTION (f32: v_pk_mul_f32 / v_pk_add_f32 on (tap k, tap k+1); f64
+// has no packed arithmetic and takes the same structure on pairs of scalar operations -- what it gains is everything else).
 // k_interp_scalar_v2 is bound by its instruction count -- ~35 wave instructions per tap in its ISA: position wrap (3) and
 // 64-bit address arithmetic (2) per tap, two LDS reads with an immediate wait, the near-singularity test and its divergent
 // branch, two selects, the (w, 0) complex product spelled out.  Here
@@ -463,88 +464,90 @@ __global__ __launch_bounds__(256) void k_interp_scalar_v2(const T* __restrict__ 
 // What stays the reference's (interpolation.rs:92-131, conv_types.rs:406-424): j accumulated tap by tap in f32, the sum taken
 // tap by tap in the reference's order, each weight the same expression as in k_interp_scalar_v2 (bit-identical results on
 // finite data up to the sign of a zero).  *Measured*: profiles/r06_interp_frac.txt, DESIGN.md 4.4.
+template <typename T>
 struct FracCtx {
-    const float *tabc, *tabs;
-    float cb0, sb0, tworo, jsing, wsing;
+    const T *tabc, *tabs;
+    T cb0, sb0, tworo, jsing, wsing;
     int fid;
 };
 
-__device__ __forceinline__ float frac_tap_weight(const FracCtx& c, float j, float sjk, int k)
+template <typename T>
+__device__ __forceinline__ T frac_tap_weight(const FracCtx<T>& c, T j, T sjk, int k)
 {
-    const float one = 1.0f, two = 2.0f, pi = 3.14159265358979323846f;
-    const float pi_x = pi * j;
-    float w;
+    const T one = (T)1, two = (T)2, pi = (T)3.14159265358979323846;
+    const T pi_x = pi * j;
+    T w;
     if (c.fid == 0) {
-        w = quot<float>(sjk, pi_x);
+        w = quot<T>(sjk, pi_x);
     } else {
-        const float arg = c.tworo * j;
-        const float t = one - dev_abs(arg);
-        if (dev_abs(t) < 0.25f) w = quot<float>(sjk * rc_near_num<float>(t), pi_x * (two - t));
+        const T arg = c.tworo * j;
+        const T t = one - dev_abs(arg);
+        if (dev_abs(t) < (T)0.25) w = quot<T>(sjk * rc_near_num<T>(t), pi_x * (two - t));
         else {
-            const float cc = c.cb0 * c.tabc[k] - c.sb0 * c.tabs[k];
-            w = quot<float>(sjk * cc, pi_x * (one - arg * arg));
+            const T cc = c.cb0 * c.tabc[k] - c.sb0 * c.tabs[k];
+            w = quot<T>(sjk * cc, pi_x * (one - arg * arg));
         }
         w = dev_abs(j) == c.jsing ? c.wsing : w;
     }
-    return j == 0.0f ? one : w;
+    return j == (T)0 ? one : w;
 }
 
-template <bool CPLX>
-__global__ __launch_bounds__(256) void k_interp_frac_pk(const float* __restrict__ x, float* __restrict__ y,
+template <typename T, bool CPLX>
+__global__ __launch_bounds__(256) void k_interp_frac_pk(const T* __restrict__ x, T* __restrict__ y,
                                                          long long points_, long long new_points, int conv_len,
-                                                         float factor, float delay, int fid, float rolloff,
+                                                         T factor, T delay, int fid, T rolloff,
                                                          unsigned long long slow_pairs)
 {
-    typedef float v2f __attribute__((ext_vector_type(2)));
+    typedef T v2f __attribute__((ext_vector_type(2))); // (f64: the same structure on pairs of scalar operations)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int ntaps = 2 * conv_len + 1;
     const int npairs = ntaps >> 1; // ntaps is odd: the last tap goes alone
-    float* tabc = reinterpret_cast<float*>(smem_raw);
-    float* tabs = tabc + ((ntaps + 3) & ~3);
+    T* tabc = reinterpret_cast<T*>(smem_raw);
+    T* tabs = tabc + ((ntaps + 3) & ~3);
     if (fid != 0) {
         for (int k = threadIdx.x; k < ntaps; k += 256) {
             double sk, ck;
             sincospi((double)rolloff * (double)k, &sk, &ck);
-            tabc[k] = (float)ck;
-            tabs[k] = (float)sk;
+            tabc[k] = (T)ck;
+            tabs[k] = (T)sk;
         }
         __syncthreads();
     }
     const int points = (int)points_;
-    const float one = 1.0f, two = 2.0f, pi = 3.14159265358979323846f;
-    FracCtx c;
+    const T one = (T)1, two = (T)2, pi = (T)3.14159265358979323846;
+    FracCtx<T> c;
     c.tabc = tabc; c.tabs = tabs; c.fid = fid;
     c.wsing = one;
-    c.jsing = fid != 0 ? one / (two * rolloff) : -1.0f;
+    c.jsing = fid != 0 ? one / (two * rolloff) : (T)-1;
     if (fid != 0) {
-        const float arg = pi / two / rolloff;
+        const T arg = pi / two / rolloff;
         c.wsing = dev_sin(arg) / arg * pi / (two * two);
     }
     c.tworo = two * rolloff;
     const v2f pi2 = v2f{pi, pi}, tworo2 = v2f{c.tworo, c.tworo}, one2 = v2f{one, one};
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < new_points; i += (long long)gridDim.x * blockDim.x) {
-        const float center = (float)i / factor;
-        const float rounded = dev_floor<float>(center);
+        const T center = (T)i / factor;
+        const T rounded = dev_floor<T>(center);
         long long p0 = ((long long)rounded - conv_len - 1) % points_;
         if (p0 < 0) p0 += points_;
-        const float j0 = -(float)conv_len - (center - rounded) + delay;
-        float sj, cdummy;
-        dev_sincospi<float>(j0, &sj, &cdummy);
-        c.cb0 = one; c.sb0 = 0.0f;
-        if (fid != 0) dev_sincospi<float>(rolloff * j0, &c.sb0, &c.cb0);
+        const T j0 = -(T)conv_len - (center - rounded) + delay;
+        T sj, cdummy;
+        dev_sincospi<T>(j0, &sj, &cdummy);
+        c.cb0 = one; c.sb0 = (T)0;
+        if (fid != 0) dev_sincospi<T>(rolloff * j0, &c.sb0, &c.cb0);
         // the faithful tap loop (k_interp_scalar_v2's): waves that cross the end of the vector, non-finite outputs
-        auto faithful = [&](v2f& acc_out, float& sr_out) {
+        auto faithful = [&](v2f& acc_out, T& sr_out) {
             int pos = (int)p0;
-            float j = j0, sjk = sj;
-            v2f acc = v2f{0.0f, 0.0f};
-            float sr = 0.0f;
+            T j = j0, sjk = sj;
+            v2f acc = v2f{(T)0, (T)0};
+            T sr = (T)0;
             for (int k = 0; k < ntaps; ++k) {
                 pos = pos + 1 < points ? pos + 1 : 0;
-                const float w = frac_tap_weight(c, j, sjk, k);
+                const T w = frac_tap_weight<T>(c, j, sjk, k);
                 sjk = -sjk;
                 if (CPLX) {
                     const v2f z = reinterpret_cast<const v2f*>(x)[pos];
-                    const v2f zw = z * v2f{w, w}, z0 = v2f{z.y, z.x} * v2f{0.0f, 0.0f};
+                    const v2f zw = z * v2f{w, w}, z0 = v2f{z.y, z.x} * v2f{(T)0, (T)0};
                     acc = acc + v2f{zw.x - z0.x, zw.y + z0.y};
                 } else sr = sr + x[pos] * w;
                 j = j + one;
@@ -552,36 +555,36 @@ __global__ __launch_bounds__(256) void k_interp_frac_pk(const float* __restrict_
             acc_out = acc;
             sr_out = sr;
         };
-        v2f acc = v2f{0.0f, 0.0f};
-        float sr = 0.0f;
+        v2f acc = v2f{(T)0, (T)0};
+        T sr = (T)0;
         const bool wraps = p0 + ntaps >= points_;
         if (__builtin_amdgcn_ballot_w64(wraps) != 0ull) {
             faithful(acc, sr);
         } else {
             const v2f* xc = reinterpret_cast<const v2f*>(x) + (p0 + 1);
-            const float* xr = x + (p0 + 1);
+            const T* xr = x + (p0 + 1);
             const v2f sjj = v2f{sj, -sj};
             const v2f cb2 = v2f{c.cb0, c.cb0}, sb2 = v2f{c.sb0, c.sb0};
-            float ja = j0;
+            T ja = j0;
 #pragma unroll 2
             for (int p = 0; p < npairs; ++p) {
-                const float jb = ja + one;
+                const T jb = ja + one;
                 v2f w;
                 if ((slow_pairs >> p) & 1ull) { // wave-uniform: a pair that CAN hold j == 0 or a tap near / at the second singularity
-                    w.x = frac_tap_weight(c, ja, sj, 2 * p);
-                    w.y = frac_tap_weight(c, jb, -sj, 2 * p + 1);
+                    w.x = frac_tap_weight<T>(c, ja, sj, 2 * p);
+                    w.y = frac_tap_weight<T>(c, jb, -sj, 2 * p + 1);
                 } else {
                     const v2f jj = v2f{ja, jb};
                     const v2f pix = pi2 * jj;
                     if (fid == 0) {
-                        w = sjj * v2f{__builtin_amdgcn_rcpf(pix.x), __builtin_amdgcn_rcpf(pix.y)};
+                        w = v2f{quot<T>(sjj.x, pix.x), quot<T>(sjj.y, pix.y)};
                     } else {
                         const v2f arg = tworo2 * jj;
                         const v2f tc = *reinterpret_cast<const v2f*>(tabc + 2 * p), ts = *reinterpret_cast<const v2f*>(tabs + 2 * p);
                         const v2f cc = cb2 * tc - sb2 * ts;
                         const v2f den = pix * (one2 - arg * arg);
                         const v2f num = sjj * cc;
-                        w = num * v2f{__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
+                        w = v2f{quot<T>(num.x, den.x), quot<T>(num.y, den.y)};
                     }
                 }
                 if (CPLX) {
@@ -595,11 +598,12 @@ __global__ __launch_bounds__(256) void k_interp_frac_pk(const float* __restrict_
                 ja = jb + one;
             }
             { // the last tap (k = 2 L, even: sign +)
-                const float w = frac_tap_weight(c, ja, sj, ntaps - 1);
+                const T w = frac_tap_weight<T>(c, ja, sj, ntaps - 1);
                 if (CPLX) acc = acc + xc[ntaps - 1] * v2f{w, w};
                 else sr = sr + xr[ntaps - 1] * w;
             }
-            const bool finite = CPLX ? (dev_abs(acc.x) <= 3.4028234e38f && dev_abs(acc.y) <= 3.4028234e38f) : dev_abs(sr) <= 3.4028234e38f;
+            const T big = sizeof(T) == 4 ? (T)3.4028234e38f : (T)1.7976931348623157e308;
+            const bool finite = CPLX ? (dev_abs(acc.x) <= big && dev_abs(acc.y) <= big) : dev_abs(sr) <= big;
             if (!finite) faithful(acc, sr); // inf / NaN in the data: the reference's product decides which components they reach
         }
         if (CPLX) reinterpret_cast<v2f*>(y)[i] = acc;
@@ -837,20 +841,18 @@ int interpolatef_dev(const T* in, T* out, size_t len, bool is_complex, int fid, 
         // up to 3071 taps a side in f32, 1535 in f64) and positions fit 32 bits; otherwise the first-generation kernel
         // (tests/test_gpu_parity.py::test_interpolatef_fractional_factor_kernel_singularities_and_fallback runs both)
         static const bool no_pk = lab_flag("BDSP_INTERP_NO_PK"); // (LAB: A/B against k_interp_scalar_v2)
-        if constexpr (sizeof(T) == 4) {
-            // f32, at most 127 taps (the slow-pair mask is one 64-bit word; above: k_interp_scalar_v2)
-            if (!no_pk && 2 * conv_len + 1 <= 127 && points < ((size_t)1 << 31)) {
-                const unsigned long long slow = frac_slow_pairs(conv_len, (double)delay, fid, (double)rolloff);
-                const size_t lds = sizeof(float) * 2 * ((2 * conv_len + 1 + 3) & ~(size_t)3);
-                if (is_complex)
-                    hipLaunchKernelGGL((k_interp_frac_pk<true>), dim3((unsigned)blocks), dim3(256), lds, s, in, out, (long long)points,
-                                       (long long)new_points, (int)conv_len, factor, delay, fid, rolloff, slow);
-                else
-                    hipLaunchKernelGGL((k_interp_frac_pk<false>), dim3((unsigned)blocks), dim3(256), lds, s, in, out, (long long)points,
-                                       (long long)new_points, (int)conv_len, factor, delay, fid, rolloff, slow);
-                BDSP_LAUNCH_CHECK();
-                return BDSP_OK;
-            }
+        // at most 127 taps (the slow-pair mask is one 64-bit word; above: k_interp_scalar_v2)
+        if (!no_pk && 2 * conv_len + 1 <= 127 && points < ((size_t)1 << 31)) {
+            const unsigned long long slow = frac_slow_pairs(conv_len, (double)delay, fid, (double)rolloff);
+            const size_t lds = sizeof(T) * 2 * ((2 * conv_len + 1 + 3) & ~(size_t)3);
+            if (is_complex)
+                hipLaunchKernelGGL((k_interp_frac_pk<T, true>), dim3((unsigned)blocks), dim3(256), lds, s, in, out, (long long)points,
+                                   (long long)new_points, (int)conv_len, factor, delay, fid, rolloff, slow);
+            else
+                hipLaunchKernelGGL((k_interp_frac_pk<T, false>), dim3((unsigned)blocks), dim3(256), lds, s, in, out, (long long)points,
+                                   (long long)new_points, (int)conv_len, factor, delay, fid, rolloff, slow);
+            BDSP_LAUNCH_CHECK();
+            return BDSP_OK;
         }
         if (tab_bytes <= 48 * 1024 && points < ((size_t)1 << 31)) {
             if (is_complex)

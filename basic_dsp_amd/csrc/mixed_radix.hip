@@ -498,7 +498,15 @@ static int mr_set_lds(K kern, size_t lds)
 // length has no instantiation (the caller then takes k_mr_wg)
 constexpr int MR_REG3_NOT_BUILT = 1 << 20;
 template <typename T>
-int mr_reg3_launch(const cpx<T>* in, cpx<T>* out, size_t n, size_t batch, bool inverse, hipStream_t s);
+struct MrReg3Io { // (layout: mixed_radix_reg3.h)
+    const T* in;
+    T* out;
+    unsigned rot_in, rot_out;
+    T in_scale;
+    int in_real, out_kind, plain;
+};
+template <typename T>
+int mr_reg3_launch(const MrReg3Io<T>& io, size_t n, size_t batch, bool inverse, hipStream_t s);
 
 // in -> out (may alias for the workgroup-resident path; the four-step path needs `scratch` of n * batch complex)
 template <typename T>
@@ -517,9 +525,14 @@ int mr_fft(const T* in, T* out, T* scratch, size_t n, size_t batch, bool inverse
     io.alpha = window_alpha;
     if (batch == 0) return BDSP_OK;
     if (n <= mr_wg_max<T>()) {
-        // plain transforms in large batches of the lengths k_mr_reg3 is built for: register-resident, persistent workgroups
-        if (flags == 0 && in_scale == (T)1 && window_id < 0) {
-            const int c = mr_reg3_launch<T>(reinterpret_cast<const cpx<T>*>(in), reinterpret_cast<cpx<T>*>(out), n, batch, inverse, s);
+        // the lengths k_mr_reg3 is built for, any batch, every fused option but a window: register-resident, persistent
+        if (window_id < 0) {
+            MrReg3Io<T> r{};
+            r.in = in; r.out = out;
+            r.rot_in = (unsigned)io.rot_in; r.rot_out = (unsigned)io.rot_out;
+            r.in_scale = in_scale; r.in_real = io.in_real; r.out_kind = io.out_kind;
+            r.plain = (io.rot_in == 0 && io.rot_out == 0 && in_scale == (T)1 && !io.in_real && io.out_kind == 0) ? 1 : 0;
+            const int c = mr_reg3_launch<T>(r, n, batch, inverse, s);
             if (c != MR_REG3_NOT_BUILT) return c;
         }
         MrStages st;

@@ -22,23 +22,45 @@ namespace bdsp {
 //   Exchange B (stage 1 -> 2): thread j writes (j / R0) R0 R1 + j mod R0 + r R0; groups are SB = R0 R1 + pad apart with
 //       SB = R0 (mod 32), so the runs of R0 lanes tile the banks; stage 2 reads r SB + j.
 //   Every LDS address is a per-thread base plus a compile-time offset.  Two buffers, two barriers per transform.
+// *Measured* (tools/plan_probe.py, valid data, cold / hot us, against k_mr_wg; profiles/r06_plan_probe_valid.txt): f32 16384 x 1000
+// points 136 / 115 -> 57 / 56 (0.24 -> 0.59 of the HBM roofline), 8192 x 2000 195 / 159 -> 57 / 53, 4096 x 3600 348 / 311 -> 51 / 49,
+// 4096 x 3000 (512 threads) 173 / 146 -> 45 / 46, ONE 1000-point transform 7.5 / 4.8 -> 3.8 / 2.7; f64 16384 x 1000 257 / 252 -> 102 / 85,
+// 8192 x 2000 498 / 489 -> 104 / 93.
 template <int R0, int R1, int R2>
 struct MrReg3 {
     static constexpr int N = R0 * R1 * R2;
     static constexpr int RMIN = R0 < R1 ? (R0 < R2 ? R0 : R2) : (R1 < R2 ? R1 : R2);
     static constexpr int RMAX = R0 > R1 ? (R0 > R2 ? R0 : R2) : (R1 > R2 ? R1 : R2);
-    static constexpr int NT = N / RMIN;        // threads per transform
-    static constexpr int B = 256 / NT;         // transforms per workgroup
+    static constexpr int NT = N / RMIN;                  // threads per transform
+    static constexpr int THREADS = NT <= 256 ? 256 : 512; // (3000 = 20 15 10 and four more lengths need 300 ... 400 threads)
+    static constexpr int B = THREADS / NT;               // transforms per workgroup
     static constexpr int SA = R0 | 1;
     static constexpr int LA = (N / R0) * SA;
     static constexpr int SB = R0 * R1 + ((R0 - R0 * R1) % 32 + 32) % 32;
     static constexpr int LB = R2 * SB;
-    static_assert(NT <= 256 && B >= 1, "a transform fits a 256-thread workgroup");
+    static_assert(NT <= 512 && B >= 1, "a transform fits a workgroup");
+};
+
+// What the kernel fuses besides the transform (everything but windows, which stay with k_mr_wg): input rotation (ifft_shift),
+// input scale, real input, output rotation (fft_shift), real-part / magnitude output.  `plain` = none of them: stage 0 loads
+// from HBM and stage 2 stores to it straight from registers.  Otherwise the workgroup stages its transforms' inputs and outputs
+// through the two LDS buffers in natural order, in rolled loops that carry the index arithmetic (with it in the unrolled
+// register code the plain path's f32 kernels went from 84 to 139 VGPRs and the f64 ones lost a wave per SIMD): three more
+// barriers and two more LDS trips per transform for the calls that use an option, nothing for the ones that do not.
+template <typename T>
+struct MrReg3Io {
+    const T* in;
+    T* out;
+    unsigned rot_in, rot_out; // input element i is x[(i + rot_in) mod n]; output element i is X[(i + rot_out) mod n]
+    T in_scale;
+    int in_real;              // the input holds n reals per vector
+    int out_kind;             // 0 complex, 1 real part, 2 magnitude
+    int plain;
 };
 
 template <typename T, int DIR, int R0, int R1, int R2>
-__global__ __launch_bounds__(256) void k_mr_reg3(const cpx<T>* __restrict__ in, cpx<T>* __restrict__ out,
-                                                  const cpx<T>* __restrict__ wtab, unsigned long long batch)
+__global__ __launch_bounds__((MrReg3<R0, R1, R2>::THREADS)) void k_mr_reg3(MrReg3Io<T> io, const cpx<T>* __restrict__ wtab,
+                                                                            unsigned long long batch)
 {
     using P = MrReg3<R0, R1, R2>;
     constexpr int N = P::N, NB0 = N / R0, NB1 = N / R1, NB2 = N / R2;
@@ -55,14 +77,39 @@ __global__ __launch_bounds__(256) void k_mr_reg3(const cpx<T>* __restrict__ in, 
 #pragma unroll
     for (int r = 1; r < R2; ++r) tw2[r - 1] = (lane && j < NB2) ? wtab[r * j] : cpx<T>{(T)1, (T)0};
     const unsigned long long groups = (batch + P::B - 1) / P::B;
+    cpx<T>* const lds0 = reinterpret_cast<cpx<T>*>(smem_raw);
     for (unsigned long long gi = blockIdx.x; gi < groups; gi += gridDim.x) {
         const unsigned long long vec = gi * P::B + c;
         const bool active = lane && vec < batch;
+        if (!io.plain) {
+            // fused input options: the workgroup brings its transforms' inputs into the B buffers in natural order (rotation,
+            // real input, scale applied on the way), so that stage 0 below finds them at compile-time offsets -- the index
+            // arithmetic lives in this rolled loop, not in the R0 registers of every thread
+            __syncthreads(); // (the previous iteration's stage 2 / output loop is done with both buffers)
+            for (int e = tid; e < N * P::B; e += P::THREADS) {
+                const int c2 = e / N, i0 = e - c2 * N;
+                const unsigned long long v2 = gi * P::B + c2;
+                unsigned i = (unsigned)i0 + io.rot_in;
+                if (i >= (unsigned)N) i -= (unsigned)N;
+                cpx<T> z{(T)0, (T)0};
+                if (v2 < batch) {
+                    if (io.in_real) z.x = io.in[v2 * N + i];
+                    else z = reinterpret_cast<const cpx<T>*>(io.in)[v2 * N + i];
+                }
+                lds0[(size_t)c2 * (P::LA + P::LB) + P::LA + i0] = cpx<T>{z.x * io.in_scale, z.y * io.in_scale};
+            }
+            __syncthreads();
+        }
         if (lane && j < NB0) {
             cpx<T> v[R0];
-            const cpx<T>* src = in + vec * N + j;
+            if (io.plain) {
+                const cpx<T>* src = reinterpret_cast<const cpx<T>*>(io.in) + vec * N + j;
 #pragma unroll
-            for (int r = 0; r < R0; ++r) v[r] = active ? src[r * NB0] : cpx<T>{(T)0, (T)0};
+                for (int r = 0; r < R0; ++r) v[r] = active ? src[r * NB0] : cpx<T>{(T)0, (T)0};
+            } else {
+#pragma unroll
+                for (int r = 0; r < R0; ++r) v[r] = lb[j + r * NB0];
+            }
             mr_dft<R0, DIR>(v);
 #pragma unroll
             for (int r = 0; r < R0; ++r) la[j * P::SA + r] = v[r];
@@ -86,10 +133,29 @@ __global__ __launch_bounds__(256) void k_mr_reg3(const cpx<T>* __restrict__ in, 
 #pragma unroll
             for (int r = 1; r < R2; ++r) v[r] = twmul<DIR>(v[r], tw2[r - 1]);
             mr_dft<R2, DIR>(v);
-            if (active) {
-                cpx<T>* dst = out + vec * N + j;
+            if (io.plain) {
+                if (active) {
+                    cpx<T>* dst = reinterpret_cast<cpx<T>*>(io.out) + vec * N + j;
 #pragma unroll
-                for (int r = 0; r < R2; ++r) dst[r * NB2] = v[r];
+                    for (int r = 0; r < R2; ++r) dst[r * NB2] = v[r];
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < R2; ++r) la[j + r * NB2] = v[r]; // (everybody read the A buffer before the last barrier)
+            }
+        }
+        if (!io.plain) {
+            // fused output options, the same way: the spectrum in natural order out of the A buffers
+            __syncthreads();
+            for (int e = tid; e < N * P::B; e += P::THREADS) {
+                const int c2 = e / N, k = e - c2 * N;
+                const unsigned long long v2 = gi * P::B + c2;
+                if (v2 >= batch) continue;
+                const cpx<T> z = lds0[(size_t)c2 * (P::LA + P::LB) + k];
+                const unsigned i = (unsigned)k >= io.rot_out ? (unsigned)k - io.rot_out : (unsigned)k + (unsigned)N - io.rot_out;
+                if (io.out_kind == 0) reinterpret_cast<cpx<T>*>(io.out)[v2 * N + i] = z;
+                else if (io.out_kind == 1) io.out[v2 * N + i] = z.x;
+                else io.out[v2 * N + i] = sizeof(T) == 4 ? (T)hypotf((float)z.x, (float)z.y) : (T)hypot((double)z.x, (double)z.y);
             }
         }
     }
@@ -98,7 +164,7 @@ __global__ __launch_bounds__(256) void k_mr_reg3(const cpx<T>* __restrict__ in, 
 constexpr int MR_REG3_NOT_BUILT = 1 << 20;
 
 template <typename T, int R0, int R1, int R2>
-static int mr_reg3_run(const cpx<T>* in, cpx<T>* out, size_t batch, bool inverse, hipStream_t s)
+static int mr_reg3_run(const MrReg3Io<T>& io, size_t batch, bool inverse, hipStream_t s)
 {
     using P = MrReg3<R0, R1, R2>;
     const cpx<T>* wtab;
@@ -111,7 +177,7 @@ static int mr_reg3_run(const cpx<T>* in, cpx<T>* out, size_t batch, bool inverse
             BDSP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_mr_reg3<T, -1, R0, R1, R2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             BDSP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_mr_reg3<T, 1, R0, R1, R2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         }
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, k_mr_reg3<T, -1, R0, R1, R2>, 256, lds) != hipSuccess || o < 1) o = 1;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, k_mr_reg3<T, -1, R0, R1, R2>, P::THREADS, lds) != hipSuccess || o < 1) o = 1;
         occ = o;
     }
     const size_t groups = (batch + P::B - 1) / P::B, slots = (size_t)num_cus() * (size_t)occ;
@@ -119,21 +185,22 @@ static int mr_reg3_run(const cpx<T>* in, cpx<T>* out, size_t batch, bool inverse
     static const int min_rounds = [] { const char* e = lab_env("BDSP_MR_REG3_ROUNDS"); return e ? atoi(e) : 0; }();
     if (groups < (size_t)min_rounds * slots) return MR_REG3_NOT_BUILT;
     const unsigned grid = (unsigned)(groups < slots ? groups : slots);
-    if (inverse) hipLaunchKernelGGL((k_mr_reg3<T, 1, R0, R1, R2>), dim3(grid), dim3(256), lds, s, in, out, wtab, (unsigned long long)batch);
-    else hipLaunchKernelGGL((k_mr_reg3<T, -1, R0, R1, R2>), dim3(grid), dim3(256), lds, s, in, out, wtab, (unsigned long long)batch);
+    if (inverse) hipLaunchKernelGGL((k_mr_reg3<T, 1, R0, R1, R2>), dim3(grid), dim3(P::THREADS), lds, s, io, wtab, (unsigned long long)batch);
+    else hipLaunchKernelGGL((k_mr_reg3<T, -1, R0, R1, R2>), dim3(grid), dim3(P::THREADS), lds, s, io, wtab, (unsigned long long)batch);
     BDSP_LAUNCH_CHECK();
     return BDSP_OK;
 }
 
 // The lengths: every n = R0 R1 R2 <= 4096 (f64: <= 2048, like k_mr_wg) that is not a power of two, with radices out of
-// {4, 5, 6, 8, 9, 10, 12, 15, 16, 20, 25}, the smallest of them as large as possible (n / min radix threads per transform must
-// fit 256), the largest radix first (stage 0 needs no twiddle registers).  tools/gen_reg3_table.py prints this table.
+// {4, 5, 6, 8, 9, 10, 12, 15, 16, 20, 25}, a factorisation whose n / min radix threads fit a 256-thread workgroup where one exists
+// (else 512 threads: five lengths), the smallest radix as large as possible, the largest radix first (stage 0 needs no twiddle
+// registers).  tools/gen_reg3_table.py prints this table.
 template <typename T>
-int mr_reg3_launch(const cpx<T>* in, cpx<T>* out, size_t n, size_t batch, bool inverse, hipStream_t s)
+int mr_reg3_launch(const MrReg3Io<T>& io, size_t n, size_t batch, bool inverse, hipStream_t s)
 {
     static const bool off = lab_flag("BDSP_MR_NO_REG3");
     if (off) return MR_REG3_NOT_BUILT;
-#define BDSP_REG3(NV, A, B_, C_) case NV: return mr_reg3_run<T, A, B_, C_>(in, out, batch, inverse, s);
+#define BDSP_REG3(NV, A, B_, C_) case NV: return mr_reg3_run<T, A, B_, C_>(io, batch, inverse, s);
     switch (n) {
     BDSP_REG3(300, 10, 6, 5)
     BDSP_REG3(320, 8, 8, 5)
@@ -182,6 +249,7 @@ int mr_reg3_launch(const cpx<T>* in, cpx<T>* out, size_t n, size_t batch, bool i
     BDSP_REG3(1620, 15, 12, 9)
     BDSP_REG3(1728, 12, 12, 12)
     BDSP_REG3(1800, 15, 12, 10)
+    BDSP_REG3(1875, 25, 15, 5)
     BDSP_REG3(1920, 16, 12, 10)
     BDSP_REG3(2000, 20, 10, 10)
     BDSP_REG3(2025, 15, 15, 9)
@@ -197,10 +265,14 @@ int mr_reg3_launch(const cpx<T>* in, cpx<T>* out, size_t n, size_t batch, bool i
         BDSP_REG3(2560, 16, 16, 10)
         BDSP_REG3(2700, 15, 15, 12)
         BDSP_REG3(2880, 16, 15, 12)
+        BDSP_REG3(3000, 20, 15, 10)
         BDSP_REG3(3072, 16, 16, 12)
+        BDSP_REG3(3200, 20, 16, 10)
         BDSP_REG3(3375, 15, 15, 15)
         BDSP_REG3(3600, 16, 15, 15)
+        BDSP_REG3(3750, 25, 15, 10)
         BDSP_REG3(3840, 16, 16, 15)
+        BDSP_REG3(4000, 20, 20, 10)
         default: break;
         }
     }

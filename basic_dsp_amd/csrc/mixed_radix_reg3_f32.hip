@@ -1,3 +1,3 @@
 // the f32 instantiations of the register-resident mixed-radix kernel (mixed_radix_reg3.h)
 #include "mixed_radix_reg3.h"
-namespace bdsp { template int mr_reg3_launch<float>(const cpx<float>*, cpx<float>*, size_t, size_t, bool, hipStream_t); }
+namespace bdsp { template int mr_reg3_launch<float>(const MrReg3Io<float>&, size_t, size_t, bool, hipStream_t); }

@@ -285,7 +285,7 @@ def cpu_baseline(points, taps, sample_points, vectors=1, reps=3):
     }
 
 
-PROFILE_TAG = "r05"  # profiles/<tag>_* are the files tools/profile_round.sh writes (TAG=r05)
+PROFILE_TAG = "r06"  # profiles/<tag>_* are the files tools/profile_round.sh writes (TAG=r06)
 
 
 def kernel_source_sha16():

@@ -67,8 +67,8 @@ def test_is_supported_fft_len_contract():
     get, put = b.lib.bdsp_hip_b1_policy_get, b.lib.bdsp_hip_b1_policy_set
     defaults = [get(k) for k in range(4)]
     try:
-        # the shipped defaults: profiles/r06_b1_crossover.txt (f32 8192 points, f64 16384 points; 65 536 / 131 072 points x taps)
-        assert defaults == [2 * 8192, 2 * 16384, 65536, 131072]
+        # the shipped defaults: profiles/r06_b1_crossover.txt (f32 8192 points, f64 16384 points; 65 536 / 98 304 points x taps)
+        assert defaults == [2 * 8192, 2 * 16384, 65536, 98304]
         assert f32(0, 1 << 20) == 0 and f64(0, 1 << 20) == 0                 # real input
         assert f32(1, 2 * 8192) == 1 and f32(1, 2 * 8192 - 2) == 0 and f32(1, 2 * 5000) == 0 and f32(1, 2 * 10000) == 1
         assert f64(1, 2 * 16384) == 1 and f64(1, 2 * 10000) == 0 and f64(1, 2 * 100003) == 1

@@ -606,16 +606,18 @@ def test_interpolatef_fractional_factor_kernel_singularities_and_fallback(cplx, 
         assert rel_l2(v.data(), ref) < (2e-5 if dtype == np.float32 else 1e-12), (fid, big, rel_l2(v.data(), ref))
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
 @pytest.mark.parametrize("cplx", [True, False])
-def test_interpolatef_fractional_factor_packed_f32_kernel(cplx):
-    """Round 6: k_interp_frac_pk, the f32 fractional path with two taps per packed instruction.  Its three shortcuts each get
+def test_interpolatef_fractional_factor_packed_kernel(cplx, dtype):
+    """Round 6: k_interp_frac_pk, the fractional path with two taps per packed instruction (f64: the same structure on pairs of
+    scalar operations).  Its three shortcuts each get
     the case that would break them: (a) the per-launch mask of tap pairs that may hold j == 0 or a tap near / at the raised
     cosine's second singularity -- delays that move those taps to other pairs, roll-offs whose near range spans many taps (0.02)
     or none; (b) the no-wrap fast path -- a vector so short that most waves cross its end, and the 127-tap limit of the mask
     (conv_len 63 packed, 64 the round-4 kernel); (c) z * (w, w) instead of the reference's spelled-out complex product -- inf and
     NaN in the data must reach exactly the outputs and components they reach in the oracle (interpolation.rs:92-131)."""
     e = 2 if cplx else 1
-    dtype, tol = np.float32, 2e-6
+    tol = 2e-6 if dtype == np.float32 else 1e-12
     x = orc.fill_uniform(e * 5000, 201606001, -10, 10, dtype)
     for fid, rolloff, factor, delay, conv_len in [(1, 0.35, 2.5, 7.25, 12), (1, 0.35, 2.5, -5.5, 12), (1, 0.02, 2.5, 0.0, 30), (1, 0.9, 1.7, 0.1, 9),
                                                   (1, 0.35, 1.088, 0.0, 63), (1, 0.35, 1.088, 0.0, 64), (0, 0.0, 2.5, 11.0, 12), (0, 0.0, 0.75, 0.5, 63),
@@ -1707,23 +1709,26 @@ def test_mixed_radix_fft_lengths_and_options(dtype):
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 def test_register_resident_three_stage_batches(dtype):
-    """Round 6: k_mr_reg3 -- plain batched transforms of n = R0 R1 R2 (1000 = 10 10 10, 360 = 10 6 6, 2000 = 20 10 10, 3600 = 16 15
-    15 ...) in registers, persistent workgroups, two LDS exchanges.  Batches of a thousand or two rows (a ragged count, so that
-    the last workgroup's second transform is empty), forward and inverse, every built length; rows against the f64
-    oracle, and the whole batch against the same rows transformed ONE AT A TIME (the general kernel k_mr_wg), which pins every row
-    and the row order.  Matches time_freq/mod.rs:47-58 (any length)."""
+    """Round 6: k_mr_reg3 -- transforms of n = R0 R1 R2 (1000 = 10 10 10, 360 = 10 6 6, 2000 = 20 10 10, 3000 = 20 15 10 with
+    512-thread workgroups ...) in registers, persistent workgroups, two LDS exchanges.  EVERY built length, batches of a thousand
+    or two rows (a ragged count, so that the last workgroup's second transform is empty), forward and inverse: rows against the
+    f64 oracle; real rows (the LDS-staged input path) against the same rows as complex data (the plain path), which pins every
+    row and the row order; fft() / ifft() with their fused shift and scale, odd lengths included.  Matches
+    time_freq/mod.rs:47-58 (any length), time_to_freq.rs:158-165."""
     tol = 1e-6 if dtype == np.float32 else 1e-12
     # every built length: the table of basic_dsp_amd/csrc/mixed_radix_reg3.h (tools/gen_reg3_table.py), restated
     import itertools
     best = {}
     for t in itertools.combinations_with_replacement([4, 5, 6, 8, 9, 10, 12, 15, 16, 20, 25], 3):
         n = t[0] * t[1] * t[2]
-        if n > 4096 or n < 300 or n & (n - 1) == 0 or n // min(t) > 256:
+        if n > 4096 or n < 300 or n & (n - 1) == 0 or n // min(t) > 512:
             continue
-        if n not in best or (min(t), -max(t)) > best[n]:
-            best[n] = (min(t), -max(t))
+        key = (n // min(t) <= 256, min(t), -max(t))
+        if n not in best or key > best[n]:
+            best[n] = key
     lengths = [n for n in sorted(best) if dtype == np.float32 or n <= 2048]
-    assert len(lengths) == (62 if dtype == np.float32 else 50) and 1000 in lengths and 360 in lengths and 2000 in lengths
+    assert len(lengths) == (67 if dtype == np.float32 else 51) and all(n in lengths for n in (360, 1000, 2000)) and (3000 in lengths) == (dtype == np.float32)
+    from basic_dsp_amd import DspMat
     for n in lengths:
         rows = 2051 if n <= 1200 else 1027
         xs = orc.fill_uniform(2 * n * rows, 600 + n, -10, 10, dtype).reshape(rows, 2 * n)
@@ -1732,8 +1737,8 @@ def test_register_resident_three_stage_batches(dtype):
         got = m.data()
         for k in (0, 1, rows // 2, rows - 2, rows - 1):
             assert rel_l2(got[k], orc.fft(xs[k].astype(np.float64))) < tol, (n, k, rel_l2(got[k], orc.fft(xs[k].astype(np.float64))))
-        # REAL rows take the general kernel k_mr_wg (real input is a fused option); the same rows as complex data with zero
-        # imaginary parts take k_mr_reg3: same values to rounding, row for row -- which pins every row and the row order
+        # REAL rows (real input is a fused option: the kernel's LDS-staged input path) against the same rows as complex data with
+        # zero imaginary parts (its plain path): same values to rounding, row for row -- which pins every row and the row order
         xr = np.ascontiguousarray(xs[:, :n])
         zc = np.zeros_like(xs)
         zc[:, 0::2] = xr
@@ -1743,6 +1748,16 @@ def test_register_resident_three_stage_batches(dtype):
         assert m.plain_ifft() == 0
         back = m.data() / n
         assert rel_l2(back.ravel(), xs.ravel()) < 4 * tol, (n, "round trip")
+        # the fused options the kernel stages through LDS: fft() = transform + fft_shift (odd lengths rotate by n - n/2),
+        # ifft() = scale(1/n) + ifft_shift + inverse transform (time_to_freq.rs:158-165, freq_to_time.rs:160-168)
+        f = DspMat(xs, is_complex=True)
+        assert f.fft() == 0
+        gf = f.data()
+        for k in (0, rows - 1):
+            ref = orc.swap_halves(orc.fft(xs[k].astype(np.float64)), True, True)
+            assert rel_l2(gf[k], ref) < tol, (n, k, "fft() with the shift fused")
+        assert f.ifft() == 0
+        assert rel_l2(f.data().ravel(), xs.ravel()) < 4 * tol, (n, "fft() -> ifft()")
 
 
 def test_b1_convolve_vector_from_concurrent_threads():

@@ -20,10 +20,24 @@ def rel(got, ref):
     d = np.linalg.norm(ref)
     return np.linalg.norm(got - ref) / (d if d > 0 else 1.0)
 
+def _reg3_lengths():
+    """the lengths of the register-resident mixed-radix kernel (round 6; tools/gen_reg3_table.py, restated)"""
+    import itertools
+    best = {}
+    for t in itertools.combinations_with_replacement([4, 5, 6, 8, 9, 10, 12, 15, 16, 20, 25], 3):
+        n = t[0] * t[1] * t[2]
+        if n > 4096 or n < 300 or n & (n - 1) == 0 or n // min(t) > 512: continue
+        best[n] = 1
+    return sorted(best)
+REG3 = _reg3_lengths()
+
 def pick_n(hi):
     hi = hi * SCALE
-    k = rng.integers(0, 5)
+    k = rng.integers(0, 6)
     if k == 0: return int(2 ** rng.integers(0, int(np.log2(hi)) + 1))
+    if k == 5:  # a length k_mr_reg3 is built for (every transform family then runs through it, plain and with fused options)
+        c = [n for n in REG3 if n <= hi]
+        if c: return int(rng.choice(c))
     if k == 1:  # smooth
         n = 1
         while True:
