@@ -291,8 +291,11 @@ def test_fft_type_state_errors():
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 def test_b1_fft_host_slices(dtype):
-    # GpuSupport::fft (gpu_support/mod.rs:35): in place on a host slice, unnormalised both ways
-    for n in (16, 4096, 1 << 16, 100, 1 << 21):
+    # GpuSupport::fft (gpu_support/mod.rs:35): in place on a host slice, unnormalised both ways.  The sizes walk through every
+    # staging route of round 6: kernels reading and writing the pinned stage (one-kernel powers of two incl. 8192, two-pass
+    # ones, smooth lengths resident -- 1000 and 3000 in the register-resident kernel -- and four-step: 5000, 10 000), pinned
+    # copies (chirp-z: 100, 1009, 100 003), the 1 MiB limit (131 072 f32 points) and the pageable path above it
+    for n in (16, 4096, 8192, 16384, 1 << 16, 100, 1000, 1009, 3000, 5000, 10000, 100003, 1 << 17, 1 << 18, 1 << 21):
         x = orc.fill_uniform(2 * n, n, -10, 10, dtype)
         got = V.gpu_fft(x.copy())
         ref = np.fft.fft(x.astype(np.float64).view(np.complex128)).view(np.float64)
@@ -422,6 +425,20 @@ def test_b1_gpu_convolve_vector(dtype):
     assert rng == (0, xr.size)
     assert rel_l2(target, orc.convolve_direct(xr.astype(np.float64), hr.astype(np.float64), False)) < tol_for(dtype)
     assert V.gpu_convolve_vector(h, x, True) == (None, None)  # declines taps longer than the signal
+    # the other staging routes of round 6: long taps (pinned copies, the multi-pass long-filter path), a signal above the
+    # 1 MiB staging limit (pageable copies), real data above it
+    for n, m, cplx in ((30000, 4000, True), (200000, 300, True), (400000, 500, False)):
+        e = 2 if cplx else 1
+        xx = orc.fill_uniform(e * n, 3 + n, -10, 10, dtype)
+        hh = orc.fill_uniform(e * m, 4 + m, -1, 1, dtype) / dtype(m)
+        target, rng = V.gpu_convolve_vector(xx, hh, cplx)
+        assert rng == (0, xx.size)
+        v = DspVec(xx, is_complex=cplx)
+        assert v.convolve_signal(DspVec(hh, is_complex=cplx)) == 0
+        assert np.array_equal(target, v.data()), (n, m, cplx)      # the same kernels on the same data: the same bits
+        first = n - 2048
+        ref = orc.convolve_direct(xx.astype(np.float64), hh.astype(np.float64), cplx, first, 2048)
+        assert rel_l2(target[e * first:], ref) < tol_for(dtype), (n, m, cplx)
 
 
 def _min_time(fn, reset=None, reps=25):
