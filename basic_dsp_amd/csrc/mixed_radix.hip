@@ -503,7 +503,8 @@ struct MrReg3Io { // (layout: mixed_radix_reg3.h)
     T* out;
     unsigned rot_in, rot_out;
     T in_scale;
-    int in_real, out_kind, plain;
+    int in_real, out_kind, plain, window_id, window_div;
+    T alpha;
 };
 template <typename T>
 int mr_reg3_launch(const MrReg3Io<T>& io, size_t n, size_t batch, bool inverse, hipStream_t s);
@@ -525,13 +526,14 @@ int mr_fft(const T* in, T* out, T* scratch, size_t n, size_t batch, bool inverse
     io.alpha = window_alpha;
     if (batch == 0) return BDSP_OK;
     if (n <= mr_wg_max<T>()) {
-        // the lengths k_mr_reg3 is built for, any batch, every fused option but a window: register-resident, persistent
-        if (window_id < 0) {
+        // the lengths k_mr_reg3 is built for, any batch, every fused option: register-resident, persistent
+        {
             MrReg3Io<T> r{};
             r.in = in; r.out = out;
             r.rot_in = (unsigned)io.rot_in; r.rot_out = (unsigned)io.rot_out;
             r.in_scale = in_scale; r.in_real = io.in_real; r.out_kind = io.out_kind;
-            r.plain = (io.rot_in == 0 && io.rot_out == 0 && in_scale == (T)1 && !io.in_real && io.out_kind == 0) ? 1 : 0;
+            r.window_id = window_id; r.window_div = io.window_div; r.alpha = window_alpha;
+            r.plain = (io.rot_in == 0 && io.rot_out == 0 && in_scale == (T)1 && !io.in_real && io.out_kind == 0 && window_id < 0) ? 1 : 0;
             const int c = mr_reg3_launch<T>(r, n, batch, inverse, s);
             if (c != MR_REG3_NOT_BUILT) return c;
         }

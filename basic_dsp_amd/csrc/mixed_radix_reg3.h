@@ -5,6 +5,7 @@
 #pragma once
 #include "bdsp_internal.h"
 #include "mr_dft.h"
+#include "dsp_funcs.h"
 
 namespace bdsp {
 
@@ -41,8 +42,8 @@ struct MrReg3 {
     static_assert(NT <= 512 && B >= 1, "a transform fits a workgroup");
 };
 
-// What the kernel fuses besides the transform (everything but windows, which stay with k_mr_wg): input rotation (ifft_shift),
-// input scale, real input, output rotation (fft_shift), real-part / magnitude output.  `plain` = none of them: stage 0 loads
+// What the kernel fuses besides the transform: input rotation (ifft_shift), input scale, a window on the input or divided out of
+// the output, real input, output rotation (fft_shift), real-part / magnitude output -- every option k_mr_wg has.  `plain` = none of them: stage 0 loads
 // from HBM and stage 2 stores to it straight from registers.  Otherwise the workgroup stages its transforms' inputs and outputs
 // through the two LDS buffers in natural order, in rolled loops that carry the index arithmetic (with it in the unrolled
 // register code the plain path's f32 kernels went from 84 to 139 VGPRs and the f64 ones lost a wave per SIMD): three more
@@ -56,6 +57,9 @@ struct MrReg3Io {
     int in_real;              // the input holds n reals per vector
     int out_kind;             // 0 complex, 1 real part, 2 magnitude
     int plain;
+    int window_id;            // >= 0: multiply the input by the window (evaluated like the reference, symmetrically) ...
+    int window_div;           // ... or divide the output by it (windowed_ifft)
+    T alpha;
 };
 
 template <typename T, int DIR, int R0, int R1, int R2>
@@ -96,7 +100,9 @@ __global__ __launch_bounds__((MrReg3<R0, R1, R2>::THREADS)) void k_mr_reg3(MrReg
                     if (io.in_real) z.x = io.in[v2 * N + i];
                     else z = reinterpret_cast<const cpx<T>*>(io.in)[v2 * N + i];
                 }
-                lds0[(size_t)c2 * (P::LA + P::LB) + P::LA + i0] = cpx<T>{z.x * io.in_scale, z.y * io.in_scale};
+                T w = io.in_scale;
+                if (io.window_id >= 0 && !io.window_div) w = w * window_value_sym<T>(io.window_id, io.alpha, (size_t)i0, (size_t)N);
+                lds0[(size_t)c2 * (P::LA + P::LB) + P::LA + i0] = cpx<T>{z.x * w, z.y * w};
             }
             __syncthreads();
         }
@@ -151,8 +157,12 @@ __global__ __launch_bounds__((MrReg3<R0, R1, R2>::THREADS)) void k_mr_reg3(MrReg
                 const int c2 = e / N, k = e - c2 * N;
                 const unsigned long long v2 = gi * P::B + c2;
                 if (v2 >= batch) continue;
-                const cpx<T> z = lds0[(size_t)c2 * (P::LA + P::LB) + k];
+                cpx<T> z = lds0[(size_t)c2 * (P::LA + P::LB) + k];
                 const unsigned i = (unsigned)k >= io.rot_out ? (unsigned)k - io.rot_out : (unsigned)k + (unsigned)N - io.rot_out;
+                if (io.window_id >= 0 && io.window_div) {
+                    const T w = window_value_sym<T>(io.window_id, io.alpha, (size_t)i, (size_t)N);
+                    z = cpx<T>{z.x / w, z.y / w};
+                }
                 if (io.out_kind == 0) reinterpret_cast<cpx<T>*>(io.out)[v2 * N + i] = z;
                 else if (io.out_kind == 1) io.out[v2 * N + i] = z.x;
                 else io.out[v2 * N + i] = sizeof(T) == 4 ? (T)hypotf((float)z.x, (float)z.y) : (T)hypot((double)z.x, (double)z.y);

@@ -1775,6 +1775,16 @@ def test_register_resident_three_stage_batches(dtype):
             assert rel_l2(gf[k], ref) < tol, (n, k, "fft() with the shift fused")
         assert f.ifft() == 0
         assert rel_l2(f.data().ravel(), xs.ravel()) < 4 * tol, (n, "fft() -> ifft()")
+        if n in (375, 1000, 1875, 2000, 3000, 3375):
+            # windows ride in the same staging loops: windowed_fft = window + transform + shift, every reference window
+            for wid, orc_id, alpha in ((V.WINDOW_TRIANGULAR, 0, 0.0), (V.WINDOW_HAMMING, 1, 0.54), (V.WINDOW_BLACKMAN_HARRIS, 2, 0.0), (V.WINDOW_HANN, 1, 0.5)):
+                w = DspMat(xs[:9], is_complex=True)
+                assert w.windowed_fft(wid) == 0
+                ref = orc.swap_halves(orc.fft(orc.apply_window(xs[8].astype(np.float64), True, orc_id, alpha)), True, True)
+                assert rel_l2(w.data()[8], ref) < tol, (n, wid, "windowed_fft")
+            w = DspMat(xs[:9], is_complex=True)
+            assert w.windowed_fft(V.WINDOW_HAMMING) == 0 and w.windowed_ifft(V.WINDOW_HAMMING) == 0
+            assert rel_l2(w.data().ravel(), xs[:9].ravel()) < 20 * tol, (n, "windowed_fft -> windowed_ifft")
 
 
 def test_b1_convolve_vector_from_concurrent_threads():
