@@ -508,6 +508,8 @@ struct MrReg3Io { // (layout: mixed_radix_reg3.h)
 };
 template <typename T>
 int mr_reg3_launch(const MrReg3Io<T>& io, size_t n, size_t batch, bool inverse, hipStream_t s);
+template <typename T>
+int mr_reg2_launch(const MrReg3Io<T>& io, size_t n, size_t batch, bool inverse, hipStream_t s); // (mixed_radix_reg2.h: n < 300)
 
 // in -> out (may alias for the workgroup-resident path; the four-step path needs `scratch` of n * batch complex)
 template <typename T>
@@ -534,7 +536,9 @@ int mr_fft(const T* in, T* out, T* scratch, size_t n, size_t batch, bool inverse
             r.in_scale = in_scale; r.in_real = io.in_real; r.out_kind = io.out_kind;
             r.window_id = window_id; r.window_div = io.window_div; r.alpha = window_alpha;
             r.plain = (io.rot_in == 0 && io.rot_out == 0 && in_scale == (T)1 && !io.in_real && io.out_kind == 0 && window_id < 0) ? 1 : 0;
-            const int c = mr_reg3_launch<T>(r, n, batch, inverse, s);
+            int c = MR_REG3_NOT_BUILT;
+            if (n >= 300) c = mr_reg3_launch<T>(r, n, batch, inverse, s);
+            else if constexpr (sizeof(T) == 4) c = mr_reg2_launch<T>(r, n, batch, inverse, s); // (f64: measured slower than k_mr_wg)
             if (c != MR_REG3_NOT_BUILT) return c;
         }
         MrStages st;

@@ -1746,8 +1746,8 @@ def test_mixed_radix_fft_lengths_and_options(dtype):
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 def test_register_resident_three_stage_batches(dtype):
     """Round 6: k_mr_reg3 -- transforms of n = R0 R1 R2 (1000 = 10 10 10, 360 = 10 6 6, 2000 = 20 10 10, 3000 = 20 15 10 with
-    512-thread workgroups ...) in registers, persistent workgroups, two LDS exchanges.  EVERY built length, batches of 515 or
-    1027 rows (a ragged count, so that the last workgroup's second transform is empty), forward and inverse: rows against the
+    512-thread workgroups ...) in registers, persistent workgroups, two LDS exchanges -- and k_mr_reg2, its two-stage sibling
+    for n = R0 R1 < 300 (100 = 10 10, 240 = 16 15 ...).  EVERY built length, batches of 515 ... 2053 rows (a ragged count, so that the last workgroup's second transform is empty), forward and inverse: rows against the
     f64 oracle; real rows (the LDS-staged input path) against the same rows as complex data (the plain path), which pins every
     row and the row order; fft() / ifft() with their fused shift and scale, odd lengths included.  Matches
     time_freq/mod.rs:47-58 (any length), time_to_freq.rs:158-165."""
@@ -1764,9 +1764,13 @@ def test_register_resident_three_stage_batches(dtype):
             best[n] = key
     lengths = [n for n in sorted(best) if dtype == np.float32 or n <= 2048]
     assert len(lengths) == (67 if dtype == np.float32 else 51) and all(n in lengths for n in (360, 1000, 2000)) and (3000 in lengths) == (dtype == np.float32)
+    # ... and the two-stage kernel k_mr_reg2 (mixed_radix_reg2.h): every n = R0 R1 < 300, the same radix set
+    short = sorted({a * b for a in (4, 5, 6, 8, 9, 10, 12, 15, 16, 20, 25) for b in (4, 5, 6, 8, 9, 10, 12, 15, 16, 20, 25)
+                    if a * b < 300 and (a * b) & (a * b - 1)})
+    assert len(short) == 31 and short[0] == 20 and 100 in short and 250 in short
     from basic_dsp_amd import DspMat
-    for n in lengths:
-        rows = 1027 if n <= 1200 else 515
+    for n in short + lengths:
+        rows = 2053 if n < 300 else (1027 if n <= 1200 else 515)
         xs = orc.fill_uniform(2 * n * rows, 600 + n, -10, 10, dtype).reshape(rows, 2 * n)
         m = DspMat(xs, is_complex=True)
         assert m.plain_fft() == 0
@@ -1794,7 +1798,7 @@ def test_register_resident_three_stage_batches(dtype):
             assert rel_l2(gf[k], ref) < tol, (n, k, "fft() with the shift fused")
         assert f.ifft() == 0
         assert rel_l2(f.data().ravel(), xs.ravel()) < 4 * tol, (n, "fft() -> ifft()")
-        if n in (375, 1000, 1875, 2000, 3000, 3375):
+        if n in (45, 100, 250, 375, 1000, 1875, 2000, 3000, 3375):
             # windows ride in the same staging loops: windowed_fft = window + transform + shift, every reference window
             for wid, orc_id, alpha in ((V.WINDOW_TRIANGULAR, 0, 0.0), (V.WINDOW_HAMMING, 1, 0.54), (V.WINDOW_BLACKMAN_HARRIS, 2, 0.0), (V.WINDOW_HANN, 1, 0.5)):
                 w = DspMat(xs[:9], is_complex=True)

@@ -28,6 +28,10 @@ def _reg3_lengths():
         n = t[0] * t[1] * t[2]
         if n > 4096 or n < 300 or n & (n - 1) == 0 or n // min(t) > 512: continue
         best[n] = 1
+    R = [4, 5, 6, 8, 9, 10, 12, 15, 16, 20, 25]
+    for a in R:          # ... and of its two-stage sibling k_mr_reg2: n = R0 R1 < 300
+        for b in R:
+            if a * b < 300 and (a * b) & (a * b - 1): best[a * b] = 1
     return sorted(best)
 REG3 = _reg3_lengths()
 
