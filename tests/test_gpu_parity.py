@@ -770,6 +770,19 @@ def test_b3_device_pointer_api():
     got = (s if flag.value else d).cpu().numpy()[:n]
     ref = orc.magnitude(orc.swap_halves(orc.fft(x.astype(np.float64)), True, True))
     assert rel_l2(got, ref) < 1e-6
+    # the same fused pair (shift + magnitude output) on batches of smooth lengths: the register-resident mixed-radix kernels'
+    # staged output path (100 = 10 10 two stages, 1000 and 3000 three), the general kernel (1001 = 7 11 13)
+    for m, rows in ((100, 700), (250, 300), (1000, 300), (3000, 70), (1001, 50)):
+        xb = orc.fill_uniform(2 * m * rows, 78 + m, -10, 10, np.float32).reshape(rows, 2 * m)
+        d = torch.from_numpy(xb.copy()).cuda()
+        s = torch.empty_like(d)
+        assert lib.bdsp_hip_dev_fft(0, d.data_ptr(), s.data_ptr(), m, rows, bd._lib.FFT_SHIFT_OUT | bd._lib.FFT_MAGNITUDE,
+                                    1.0, -1, 0.0, C.byref(flag), sp) == 0
+        torch.cuda.synchronize()
+        got = (s if flag.value else d).cpu().numpy().ravel()[:m * rows].reshape(rows, m)
+        for k in (0, rows // 2, rows - 1):
+            ref = orc.magnitude(orc.swap_halves(orc.fft(xb[k].astype(np.float64)), True, True))
+            assert rel_l2(got[k], ref) < 1e-6, (m, k)
     d = torch.from_numpy(x).cuda()
     assert lib.bdsp_hip_dev_real_scale(0, d.data_ptr(), 2 * n, 2.5, sp) == 0
     assert lib.bdsp_hip_dev_real_offset(0, d.data_ptr(), 2 * n, 0, -1.25, sp) == 0
@@ -842,6 +855,15 @@ def test_symmetric_fft_family(dtype):
     assert v.plain_sfft() == 0 and v.plain_sifft() == 0
     assert not v.is_complex() and len(v) == n
     assert rel_l2(v.data().astype(np.float64) / n, x) < 4 * tol
+    # odd lengths the register-resident mixed-radix kernels are built for (round 6): real input on the way in, the real part
+    # straight out of the inverse transform (FFT_OUT_REAL) on the way back
+    for m in (45, 225, 375, 1125, 3375):
+        xm = orc.fill_uniform(m, 201511211 + m, -10, 10, dtype)
+        v = DspVec(xm)
+        assert v.plain_sfft() == 0 and v.points() == m // 2 + 1
+        assert rel_l2(v.datac(), np.fft.fft(xm.astype(np.float64))[:m // 2 + 1]) < 2 * tol, m
+        assert v.plain_sifft() == 0 and not v.is_complex() and len(v) == m
+        assert rel_l2(v.data().astype(np.float64) / m, xm) < 4 * tol, m
     assert DspVec(x[:1000]).plain_sfft() == 9                       # InputMustHaveAnOddLength
     assert DspVec(np.zeros(10, dtype), is_complex=True).plain_sfft() == 5   # must be real time data
     assert DspVec(np.zeros(10, dtype), is_complex=True).plain_sifft() == 6  # must be frequency domain
