@@ -62,10 +62,15 @@ struct MrReg3Io {
     T alpha;
 };
 
-template <typename T, int DIR, int R0, int R1, int R2>
-__global__ __launch_bounds__((MrReg3<R0, R1, R2>::THREADS)) void k_mr_reg3(MrReg3Io<T> io, const cpx<T>* __restrict__ wtab,
+// OPTS = false: the plain path alone.  Built for the five 512-thread lengths only: with the option code in the same kernel their f32
+// instantiations need 132-150 VGPRs -- over the 128 that let TWO 8-wave workgroups share a CU -- and a plain 4096 x 3000-point
+// batch went from 45 to 61 us (*measured*, rocprofv3: profiles/r06_new_kernels_kernel_stats.csv); forcing 128 registers spills.
+template <typename T, int DIR, int R0, int R1, int R2, bool OPTS = true>
+__global__ __launch_bounds__((MrReg3<R0, R1, R2>::THREADS)) void k_mr_reg3(MrReg3Io<T> io_, const cpx<T>* __restrict__ wtab,
                                                                             unsigned long long batch)
 {
+    MrReg3Io<T> io = io_;
+    if constexpr (!OPTS) io.plain = 1;
     using P = MrReg3<R0, R1, R2>;
     constexpr int N = P::N, NB0 = N / R0, NB1 = N / R1, NB2 = N / R2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -195,6 +200,26 @@ static int mr_reg3_run(const MrReg3Io<T>& io, size_t batch, bool inverse, hipStr
     static const int min_rounds = [] { const char* e = lab_env("BDSP_MR_REG3_ROUNDS"); return e ? atoi(e) : 0; }();
     if (groups < (size_t)min_rounds * slots) return MR_REG3_NOT_BUILT;
     const unsigned grid = (unsigned)(groups < slots ? groups : slots);
+    if constexpr (P::THREADS == 512 && sizeof(T) == 4) {
+        if (io.plain) { // the plain-only instantiation: two workgroups per CU (see k_mr_reg3 OPTS)
+            static int occ_plain = 0;
+            if (occ_plain == 0) {
+                int o = 0;
+                if (lds > 64 * 1024) {
+                    BDSP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_mr_reg3<T, -1, R0, R1, R2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                    BDSP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_mr_reg3<T, 1, R0, R1, R2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                }
+                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, k_mr_reg3<T, -1, R0, R1, R2, false>, P::THREADS, lds) != hipSuccess || o < 1) o = 1;
+                occ_plain = o;
+            }
+            const size_t slots_p = (size_t)num_cus() * (size_t)occ_plain;
+            const unsigned grid_p = (unsigned)(groups < slots_p ? groups : slots_p);
+            if (inverse) hipLaunchKernelGGL((k_mr_reg3<T, 1, R0, R1, R2, false>), dim3(grid_p), dim3(P::THREADS), lds, s, io, wtab, (unsigned long long)batch);
+            else hipLaunchKernelGGL((k_mr_reg3<T, -1, R0, R1, R2, false>), dim3(grid_p), dim3(P::THREADS), lds, s, io, wtab, (unsigned long long)batch);
+            BDSP_LAUNCH_CHECK();
+            return BDSP_OK;
+        }
+    }
     if (inverse) hipLaunchKernelGGL((k_mr_reg3<T, 1, R0, R1, R2>), dim3(grid), dim3(P::THREADS), lds, s, io, wtab, (unsigned long long)batch);
     else hipLaunchKernelGGL((k_mr_reg3<T, -1, R0, R1, R2>), dim3(grid), dim3(P::THREADS), lds, s, io, wtab, (unsigned long long)batch);
     BDSP_LAUNCH_CHECK();
